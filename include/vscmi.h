@@ -1,0 +1,177 @@
+/*
+ * vscmi.h -- C ABI of libvscmi.so: the MI355X (gfx950) descriptor-search / candidate /
+ * temporal-localisation engine that sits under the vsc.index / vsc.candidates / vcsl.vta call
+ * surface of facebookresearch/vsc2022.
+ *
+ * Conventions
+ *   - Plain pointers and sizes only.  Every array is owned by the caller; the library frees
+ *     nothing it did not allocate and hands back no memory except opaque handles that have an
+ *     explicit *_destroy.
+ *   - Each array argument carries a memory kind: VSC_MEM_HOST (pageable host memory, e.g. a
+ *     numpy array) or VSC_MEM_DEVICE (HBM of the handle's device, e.g. a torch tensor's
+ *     data_ptr).  Scalars written through pointers (counts, radii) are always host memory.
+ *   - All feature matrices are fp32, C-contiguous, row-major [n][dim]; frame-row and video
+ *     ordinals are int32 (row counts < 2^31).
+ *   - Return value: VSC_OK (0) or a negative VSC_ERR_* code; vsc_last_error() returns a
+ *     thread-local message.  The Python layer raises RuntimeError / ValueError from these,
+ *     matching the reference's exception/assert convention (vsc/index.py:37-40,
+ *     vsc/storage.py:49-57, vsc/baseline/localization.py:59,64).
+ *   - A handle owns one HIP stream; calls on one handle are serialised by the caller, distinct
+ *     handles may be used from distinct threads.  No callbacks into the caller.
+ *   - Arithmetic contract: every similarity is the fp32 fma chain in ascending k
+ *     (acc = fmaf(q[k], r[k], acc), acc0 = +0), produced on the matrix cores by
+ *     v_mfma_f32_32x32x2_f32.  Results are bit-identical to oracle/vsc_oracle.c.
+ *
+ * Paths below are relative to the reference checkout (/root/reference).
+ */
+#ifndef VSCMI_H
+#define VSCMI_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VSC_OK 0
+#define VSC_ERR_INVALID (-1)  /* bad argument */
+#define VSC_ERR_HIP (-2)      /* HIP runtime failure */
+#define VSC_ERR_NOMEM (-3)    /* device allocation failed */
+#define VSC_ERR_CAPACITY (-4) /* caller-provided output capacity too small; *n_out holds the need */
+#define VSC_ERR_OVERFLOW (-5) /* internal hit buffer overflowed (pathological score distribution) */
+#define VSC_ERR_NODEVICE (-6) /* no gfx950 device */
+
+#define VSC_MEM_HOST 0
+#define VSC_MEM_DEVICE 1
+
+/* same numeric values as faiss.METRIC_INNER_PRODUCT / faiss.METRIC_L2 (vsc/index.py:78,145) */
+#define VSC_METRIC_INNER_PRODUCT 0
+#define VSC_METRIC_L2 1
+
+#define VSC_TN_MAX_BOXES 16
+
+typedef struct vsc_index vsc_index_t;
+
+const char* vsc_last_error(void);
+int vsc_version(void);
+/* number of visible HIP devices whose arch is gfx950 (0 => the library cannot run) */
+int vsc_device_count(void);
+
+/* ---------------------------------------------------------------- flat index
+ * Replaces faiss.index_factory(dim, "Flat", metric) + index.add(x) (vsc/index.py:82,94).
+ * The reference set stays resident in HBM across searches; add is incremental. */
+int vsc_index_create(int dim, int metric, int device, vsc_index_t** out);
+int vsc_index_destroy(vsc_index_t* idx);
+int vsc_index_add(vsc_index_t* idx, const float* x, int64_t n, int x_mem);
+int64_t vsc_index_ntotal(const vsc_index_t* idx);
+int vsc_index_dim(const vsc_index_t* idx);
+int vsc_index_metric(const vsc_index_t* idx);
+/* Capacity (entries) of the internal kept-hit buffer used by vsc_index_global_topk; 0 restores the
+ * default max(32*ntotal, 2K) + 2K.  A search that overflows it returns VSC_ERR_OVERFLOW. */
+int vsc_index_set_hit_capacity(vsc_index_t* idx, int64_t cap);
+/* block until all work queued on the handle's stream has finished */
+int vsc_index_sync(vsc_index_t* idx);
+
+/* Replaces faiss index.search(x, k) (vsc/index.py:174; vsc/baseline/score_normalization.py:96).
+ * Per query row the k best refs ordered by (score desc, ref asc) [L2: (dist asc, ref asc)].
+ * out_s[nq*k] fp32, out_j[nq*k] int64 (faiss idx_t); missing slots hold -1 and -/+FLT_MAX.
+ * k <= 64. */
+int vsc_index_knn(vsc_index_t* idx, const float* q, int64_t nq, int q_mem, int k, float* out_s,
+                  int64_t* out_j, int out_mem);
+
+/* Replaces faiss index.range_search(x, radius) (reached through
+ * faiss.contrib.exhaustive_search.range_search_max_results at vsc/index.py:147-154): all (row, ref)
+ * with score > radius (IP) or dist < radius (L2), STRICT.  Rows ascending, refs ascending within a
+ * row.  lims[nq+1] cumulative counts; D/I written when cap >= *n_out, else VSC_ERR_CAPACITY (*n_out
+ * = required).  All outputs host memory. */
+int vsc_index_range_search(vsc_index_t* idx, const float* q, int64_t nq, int q_mem, float radius,
+                           int64_t* lims, float* D, int64_t* I, int64_t cap, int64_t* n_out);
+
+/* Replaces VideoIndex._global_threshold_knn_search (vsc/index.py:142-165): the adaptive
+ * global-threshold search of range_search_max_results(exponential_query_iterator(Q), radius=-/+1e10,
+ * max_results=2K, min_results=K) followed by the stable sort + truncate to K.  Reproduces the
+ * reference's batch schedule (32, 64, ... rows) and strict re-thresholding, ties included.
+ * Output: <= K hits ordered by (score desc, row asc, ref asc) [L2: dist asc].
+ * out_* capacity `cap` (>= K suffices).  *final_radius receives the last radius. */
+int vsc_index_global_topk(vsc_index_t* idx, const float* q, int64_t nq, int q_mem, int64_t K,
+                          int32_t* out_i, int32_t* out_j, float* out_s, int64_t cap, int out_mem,
+                          int64_t* n_out, float* final_radius);
+
+/* ------------------------------------------------------- candidate generation
+ * Replaces the regroup loop of VideoIndex.search (vsc/index.py:121-140) fused with
+ * MaxScoreAggregation + the stable descending sort of CandidateGeneration.query
+ * (vsc/candidates.py:24-40).  hits must be in search order (as produced by
+ * vsc_index_global_topk).  row2q[nq_rows] / row2r[nr_rows] map frame rows to video ordinals.
+ * Output pairs in first-appearance order (== score-descending, stable): video ordinals, max score
+ * and the index of the pair's first hit.  cap >= n suffices.  device selects the GPU. */
+int vsc_pair_max(const int32_t* hit_i, const int32_t* hit_j, const float* hit_s, int64_t n,
+                 int hits_mem, const int32_t* row2q, int64_t nq_rows, const int32_t* row2r,
+                 int64_t nr_rows, int maps_mem, int32_t* out_q, int32_t* out_r, float* out_s,
+                 int64_t* out_first, int64_t cap, int out_mem, int64_t* n_pairs, int device);
+
+/* Replaces sklearn.preprocessing.normalize(x) (row L2; vsc/baseline/score_normalization.py:84,
+ * vsc/baseline/sscd_baseline.py:129-130): out = x / max(||x||, 0 -> 1). */
+int vsc_row_normalize(const float* x, int64_t n, int dim, int x_mem, float* out, int out_mem,
+                      int device);
+
+/* --------------------------------------------------- temporal localisation
+ * Replaces VCSLLocalization over batches of candidates (vsc/baseline/localization.py:28-96):
+ * per pair sims = q.feature @ r.feature.T + bias (localization.py:36,52-54), the VCSL
+ * Temporal-Network aligner reached through model.forward_sim (localization.py:58; vcsl.vta `tn`,
+ * third-party -- see DESIGN.md for the unpinned-parity note), and the MaxSim box score
+ * (localization.py:88-91).
+ *
+ * A context keeps the query and reference descriptors of LocalizationWithMetadata.__init__
+ * (localization.py:29-31) resident in HBM: qfeat[total_q_rows][dim] with q_off[n_qvid+1] row
+ * offsets per query video; same for refs. */
+typedef struct vsc_tn_ctx vsc_tn_ctx_t;
+
+typedef struct vsc_tn_params {
+    int32_t tn_max_step; /* VCSL default 10; reference passes 5 (sscd_baseline.py:122,132) */
+    int32_t tn_top_k;    /* 5 */
+    int32_t max_path;    /* 10 */
+    int32_t min_length;  /* VCSL default 5; reference passes 4 */
+    float min_sim;       /* 0.2 */
+    float max_iou;       /* 0.3 */
+} vsc_tn_params;
+
+int vsc_tn_create(const float* qfeat, const int64_t* q_off, int64_t n_qvid, const float* rfeat,
+                  const int64_t* r_off, int64_t n_rvid, int dim, int feat_mem, int device,
+                  vsc_tn_ctx_t** out);
+int vsc_tn_destroy(vsc_tn_ctx_t* ctx);
+
+/* One localize_all batch.  pair_q/pair_r[n_pairs] are video ordinals.  Outputs (host or device):
+ *   out_nbox[n_pairs]                       number of boxes (<= VSC_TN_MAX_BOXES)
+ *   out_boxes[n_pairs][VSC_TN_MAX_BOXES][4] q_lo, r_lo, q_hi, r_hi (frame indices, inclusive ends)
+ *   out_boxmax[n_pairs][VSC_TN_MAX_BOXES]   max(sims[q_lo:q_hi, r_lo:r_hi]) - bias (half-open slice,
+ *                                           localization.py:91); -inf for an empty slice */
+int vsc_tn_localize(vsc_tn_ctx_t* ctx, const int32_t* pair_q, const int32_t* pair_r, int64_t n_pairs,
+                    int pairs_mem, const vsc_tn_params* params, float bias, int32_t* out_nbox,
+                    int32_t* out_boxes, float* out_boxmax, int out_mem);
+
+/* vcsl.vta.build_vta_model("TN").forward_sim([(name, sims), ...]) (vsc/baseline/localization.py:58)
+ * on caller-supplied similarity matrices (host memory): pair p is the row-major lq[p] x lr[p] fp32
+ * matrix at sims + sims_off[p]; sims_off[n_pairs] is the total length.  Outputs (host) as in
+ * vsc_tn_localize with bias = 0. */
+int vsc_tn_forward_sim(const float* sims, const int64_t* sims_off, const int32_t* lq, const int32_t* lr,
+                       int64_t n_pairs, const vsc_tn_params* params, int32_t* out_nbox,
+                       int32_t* out_boxes, float* out_boxmax, int device);
+
+/* LocalizationWithMetadata.similarity / VCSLLocalization.similarity (localization.py:33-36,48-54)
+ * for one pair: out[lq*lr] (host) = q.feature @ r.feature.T + bias; *lq / *lr receive the shape.
+ * cap is the capacity of out in floats (VSC_ERR_CAPACITY if too small). */
+int vsc_tn_similarity(vsc_tn_ctx_t* ctx, int32_t q_vid, int32_t r_vid, float bias, float* out,
+                      int64_t cap, int32_t* lq, int32_t* lr);
+
+/* ---------------------------------------------------------- instrumentation
+ * Kernel-time accounting for bench.py: HIP events recorded on the handle's stream around the
+ * dominant similarity kernel.  vsc_index_profile(idx, 1) enables it; vsc_index_profile_read
+ * returns accumulated kernel milliseconds, launches and algorithmic flops since the last reset. */
+int vsc_index_profile(vsc_index_t* idx, int enable);
+int vsc_index_profile_read(vsc_index_t* idx, double* sim_ms, int64_t* sim_launches, double* sim_flops,
+                           int reset);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VSCMI_H */

@@ -1,0 +1,144 @@
+"""GPU parity: Temporal-Network localisation kernel vs the CPU oracle (boxes exact, fp32 bit-exact)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def unit(rng, n, d):
+    x = rng.standard_normal((n, d)).astype(np.float32)
+    return x / np.linalg.norm(x, axis=1, keepdims=True)
+
+
+def bits(x):
+    return np.ascontiguousarray(x, dtype=np.float32).view(np.uint32)
+
+
+def rand_sims(rng, trial):
+    lq = int(rng.integers(1, 70))
+    lr = int(rng.integers(1, 90))
+    mode = trial % 6
+    sims = rng.normal(0, 0.12, size=(lq, lr)).astype(np.float32)
+    if mode in (1, 3, 5):
+        for _ in range(rng.integers(1, 4)):
+            L = int(rng.integers(3, 30))
+            q0 = int(rng.integers(0, max(1, lq - 2)))
+            r0 = int(rng.integers(0, max(1, lr - 2)))
+            for t in range(L):
+                if q0 + t < lq and r0 + t < lr:
+                    sims[q0 + t, r0 + t] = 0.8 + 0.2 * rng.random()
+    if mode in (2, 3):
+        sims = np.round(sims * 4) / 4
+    if mode == 4:
+        sims += 0.5
+    if mode == 5:
+        sims = np.round(sims * 8) / 8 + 0.5
+    return sims.astype(np.float32)
+
+
+@pytest.mark.parametrize("kw", [{}, dict(tn_max_step=5, min_length=4),
+                                dict(tn_max_step=3, tn_top_k=2, min_length=1, max_path=3),
+                                dict(tn_top_k=7, min_sim=0.05)])
+def test_forward_sim_matches_oracle(gpu, orc, kw):
+    """build_vta_model('TN').forward_sim == oracle tn on 400 random matrices (ties, plants, bias)."""
+    from vsc2022_amd.vcsl.vta import build_vta_model
+
+    rng = np.random.default_rng(0)
+    data = [(f"p{t}", rand_sims(rng, t)) for t in range(400)]
+    model = build_vta_model("TN", concurrency=16, **kw)
+    got = model.forward_sim(data)
+    assert [g[0] for g in got] == [d[0] for d in data]
+    nboxes = 0
+    for (name, sims), (_, boxes) in zip(data, got):
+        exp = orc.tn(sims, **kw)
+        assert boxes == exp, (name, sims.shape, boxes, exp)
+        nboxes += len(exp)
+    assert nboxes > 100
+
+
+def test_forward_sim_large_matrices(gpu, orc):
+    from vsc2022_amd.vcsl.vta import build_vta_model
+
+    rng = np.random.default_rng(1)
+    data = []
+    for t, (lq, lr) in enumerate([(300, 280), (500, 40), (40, 700), (257, 129), (1, 500), (600, 1)]):
+        sims = rng.normal(0, 0.1, size=(lq, lr)).astype(np.float32)
+        for k in range(min(lq, lr) // 2):
+            sims[k + min(lq, lr) // 4, k + min(lq, lr) // 5] = 0.9
+        data.append((f"big{t}", sims))
+    got = build_vta_model("TN", tn_max_step=5, min_length=4).forward_sim(data)
+    for (name, sims), (_, boxes) in zip(data, got):
+        assert boxes == orc.tn(sims, tn_max_step=5, min_length=4), name
+
+
+def _videos(rng, n, d, lo, hi, cls, prefix):
+    out = []
+    for v in range(n):
+        L = int(rng.integers(lo, hi + 1))
+        ts = np.stack([np.arange(L, dtype=np.float32), np.arange(1, L + 1, dtype=np.float32)], axis=1)
+        out.append(cls(video_id=f"{prefix}{v:06d}", timestamps=ts, feature=unit(rng, L, d)))
+    return out
+
+
+@pytest.mark.parametrize("bias,kw", [(0.0, dict(tn_max_step=5, min_length=4)), (0.5, dict(tn_max_step=5, min_length=4)),
+                                     (0.0, {})])
+def test_fused_localize_matches_oracle(gpu, orc, bias, kw):
+    """Fused path (descriptors in HBM -> MFMA sims -> TN -> MaxSim score) vs oracle sims + oracle tn."""
+    from vsc2022_amd.vsc.baseline.localization import VCSLLocalizationMaxSim
+    from vsc2022_amd.vsc.index import VideoFeature
+    from vsc2022_amd.vsc.metrics import CandidatePair
+
+    rng = np.random.default_rng(42)
+    d = 512
+    queries = _videos(rng, 12, d, 5, 60, VideoFeature, "Q")
+    refs = _videos(rng, 14, d, 5, 80, VideoFeature, "R")
+    refs.append(_videos(rng, 1, d, 300, 300, VideoFeature, "RL")[0])   # spills out of the LDS tile budget
+    queries.append(_videos(rng, 1, d, 280, 280, VideoFeature, "QL")[0])
+    # plant copies
+    for (qi, ri, q0, r0, L) in [(0, 1, 2, 3, 20), (3, 3, 0, 10, 30), (5, 7, 10, 0, 12), (12, 14, 100, 50, 120)]:
+        q, r = queries[qi], refs[ri]
+        L = min(L, len(q) - q0, len(r) - r0)
+        seg = r.feature[r0:r0 + L] + 0.05 * rng.standard_normal((L, d)).astype(np.float32)
+        q.feature[q0:q0 + L] = seg / np.linalg.norm(seg, axis=1, keepdims=True)
+    loc = VCSLLocalizationMaxSim(queries, refs, "TN", similarity_bias=bias, **kw)
+    cands = [CandidatePair(q.video_id, r.video_id, 1.0) for q in queries for r in refs]
+    got = loc.localize_all(cands)
+    # oracle
+    exp = []
+    for c in cands:
+        q = loc.queries[c.query_id]
+        r = loc.refs[c.ref_id]
+        sims = orc.pair_sims(q.feature, r.feature, bias)
+        assert np.array_equal(bits(loc.similarity(c)), bits(sims))
+        for (x1, y1, x2, y2) in orc.tn(sims, **kw):
+            score = sims[x1:x2, y1:y2].max() - np.float32(bias)
+            exp.append((c.query_id, c.ref_id, np.float32(score), q.timestamps[x1][0], q.timestamps[x2][1],
+                        r.timestamps[y1][0], r.timestamps[y2][1]))
+    assert len(got) == len(exp) and len(exp) >= 4
+    for g, e in zip(got, exp):
+        assert (g.query_id, g.ref_id) == (e[0], e[1])
+        assert np.float32(g.score).view(np.uint32) == e[2].view(np.uint32)
+        assert (g.query_start, g.query_end, g.ref_start, g.ref_end) == e[3:]
+
+
+def test_reference_localization_properties(gpu):
+    """tests/test_localization.py:46-66 of the reference, seeded (all-default TN parameters)."""
+    from sklearn.preprocessing import normalize
+    from vsc2022_amd.vsc.baseline.localization import VCSLLocalizationMaxSim
+    from vsc2022_amd.vsc.index import VideoFeature
+    from vsc2022_amd.vsc.metrics import CandidatePair
+
+    rng = np.random.default_rng(7)
+    D = 64
+
+    def feat(n):
+        return normalize(rng.normal(size=(n, D)))
+
+    a, b, c = feat(45), feat(30), feat(60)
+    a[20:30, :] = c[30:40, :]
+    mk = lambda i, f: VideoFeature(video_id=i, feature=f, timestamps=np.arange(f.shape[0]) * 1.0)
+    loc = VCSLLocalizationMaxSim([mk(1, a)], [mk(2, b), mk(3, c)], "TN")
+    assert len(loc.localize(CandidatePair(1, 2, 1.0))) == 0
+    assert len(loc.localize(CandidatePair(1, 3, 2.0))) >= 1
+    ms = loc.localize_all([CandidatePair(1, 2, 1.0), CandidatePair(1, 3, 2.0)])
+    assert len(ms) >= 1 and all(m.query_id == 1 and m.ref_id == 3 for m in ms)

@@ -1,0 +1,166 @@
+"""ctypes binding of libvscmi.so (the C ABI declared in include/vscmi.h).
+
+The shared library is the product; this module only loads it, declares the prototypes and turns
+VSC_ERR_* codes into Python exceptions (the reference's convention is exceptions/asserts:
+vsc/index.py:37-40, vsc/storage.py:49-57, vsc/baseline/localization.py:59,64).
+
+There is NO CPU fallback: if the library is missing, or no gfx950 device is visible when an
+operation is issued, the call raises.
+"""
+import ctypes
+import os
+import subprocess
+import threading
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libvscmi.so")
+CSRC = os.path.join(_HERE, "csrc")
+
+VSC_OK = 0
+VSC_ERR_INVALID = -1
+VSC_ERR_HIP = -2
+VSC_ERR_NOMEM = -3
+VSC_ERR_CAPACITY = -4
+VSC_ERR_OVERFLOW = -5
+VSC_ERR_NODEVICE = -6
+MEM_HOST = 0
+MEM_DEVICE = 1
+METRIC_INNER_PRODUCT = 0
+METRIC_L2 = 1
+TN_MAX_BOXES = 16
+
+# every symbol include/vscmi.h declares
+EXPORTS = (
+    "vsc_last_error", "vsc_version", "vsc_device_count",
+    "vsc_index_create", "vsc_index_destroy", "vsc_index_add", "vsc_index_ntotal", "vsc_index_dim",
+    "vsc_index_metric", "vsc_index_set_hit_capacity", "vsc_index_sync", "vsc_index_knn",
+    "vsc_index_range_search", "vsc_index_global_topk", "vsc_pair_max", "vsc_row_normalize",
+    "vsc_tn_create", "vsc_tn_destroy", "vsc_tn_localize", "vsc_tn_forward_sim", "vsc_tn_similarity",
+    "vsc_index_profile", "vsc_index_profile_read",
+)
+
+
+class TNParams(ctypes.Structure):
+    _fields_ = [
+        ("tn_max_step", ctypes.c_int32),
+        ("tn_top_k", ctypes.c_int32),
+        ("max_path", ctypes.c_int32),
+        ("min_length", ctypes.c_int32),
+        ("min_sim", ctypes.c_float),
+        ("max_iou", ctypes.c_float),
+    ]
+
+
+class VscError(RuntimeError):
+    def __init__(self, code, message):
+        super().__init__(f"libvscmi error {code}: {message}")
+        self.code = code
+
+
+_lib = None
+_lock = threading.Lock()
+
+
+def build(force: bool = False) -> str:
+    """Compile libvscmi.so for gfx950 with hipcc (cross-compiles without a GPU)."""
+    srcs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".h"))]
+    srcs.append(os.path.join(os.path.dirname(_HERE), "include", "vscmi.h"))
+    if (
+        not force
+        and os.path.exists(LIB_PATH)
+        and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(s) for s in srcs)
+    ):
+        return LIB_PATH
+    subprocess.check_call(["make", "-C", CSRC, "-j", str(os.cpu_count() or 4)])
+    return LIB_PATH
+
+
+def lib():
+    global _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; "
+                "g.build()'` (hipcc --offload-arch=gfx950).  There is no CPU fallback."
+            )
+        L = ctypes.CDLL(LIB_PATH)
+        vp, i64, i32, f32 = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_float
+        pi64 = ctypes.POINTER(ctypes.c_int64)
+        pf32 = ctypes.POINTER(ctypes.c_float)
+        pi32 = ctypes.POINTER(ctypes.c_int32)
+        L.vsc_last_error.restype = ctypes.c_char_p
+        L.vsc_version.restype = i32
+        L.vsc_device_count.restype = i32
+        L.vsc_index_create.argtypes = [i32, i32, i32, ctypes.POINTER(vp)]
+        L.vsc_index_destroy.argtypes = [vp]
+        L.vsc_index_add.argtypes = [vp, vp, i64, i32]
+        L.vsc_index_ntotal.argtypes = [vp]
+        L.vsc_index_ntotal.restype = i64
+        L.vsc_index_dim.argtypes = [vp]
+        L.vsc_index_metric.argtypes = [vp]
+        L.vsc_index_set_hit_capacity.argtypes = [vp, i64]
+        L.vsc_index_sync.argtypes = [vp]
+        L.vsc_index_knn.argtypes = [vp, vp, i64, i32, i32, vp, vp, i32]
+        L.vsc_index_range_search.argtypes = [vp, vp, i64, i32, f32, vp, vp, vp, i64, pi64]
+        L.vsc_index_global_topk.argtypes = [vp, vp, i64, i32, i64, vp, vp, vp, i64, i32, pi64, pf32]
+        L.vsc_pair_max.argtypes = [vp, vp, vp, i64, i32, vp, i64, vp, i64, i32, vp, vp, vp, vp, i64,
+                                   i32, pi64, i32]
+        L.vsc_row_normalize.argtypes = [vp, i64, i32, i32, vp, i32, i32]
+        L.vsc_tn_create.argtypes = [vp, vp, i64, vp, vp, i64, i32, i32, i32, ctypes.POINTER(vp)]
+        L.vsc_tn_destroy.argtypes = [vp]
+        L.vsc_tn_localize.argtypes = [vp, vp, vp, i64, i32, ctypes.POINTER(TNParams), f32, vp, vp, vp, i32]
+        L.vsc_tn_forward_sim.argtypes = [vp, vp, vp, vp, i64, ctypes.POINTER(TNParams), vp, vp, vp, i32]
+        L.vsc_tn_similarity.argtypes = [vp, ctypes.c_int32, ctypes.c_int32, f32, vp, i64, pi32, pi32]
+        L.vsc_index_profile.argtypes = [vp, i32]
+        L.vsc_index_profile_read.argtypes = [vp, ctypes.POINTER(ctypes.c_double), pi64,
+                                             ctypes.POINTER(ctypes.c_double), i32]
+        for name in EXPORTS:
+            fn = getattr(L, name)
+            if fn.restype is ctypes.c_int and name not in ("vsc_version", "vsc_device_count"):
+                fn.restype = ctypes.c_int
+        _lib = L
+        return _lib
+
+
+def check(rc: int):
+    if rc == VSC_OK:
+        return
+    msg = lib().vsc_last_error().decode("utf-8", "replace")
+    if rc == VSC_ERR_INVALID:
+        raise ValueError(f"libvscmi: {msg}")
+    raise VscError(rc, msg)
+
+
+def device_count() -> int:
+    return int(lib().vsc_device_count())
+
+
+def default_device() -> int:
+    """One process per GPU: LOCAL_RANK picks the device (torch.distributed launch convention)."""
+    n = device_count()
+    if n <= 0:
+        raise RuntimeError(
+            "libvscmi: no gfx950 (MI355X) device is visible; this engine has no CPU fallback"
+        )
+    return int(os.environ.get("LOCAL_RANK", "0")) % n
+
+
+def ptr(a):
+    """(address, mem kind) of a numpy array (host) or a torch tensor (host or HBM)."""
+    if a is None:
+        return None, MEM_HOST
+    if isinstance(a, np.ndarray):
+        assert a.flags["C_CONTIGUOUS"], "array must be C-contiguous"
+        return a.ctypes.data, MEM_HOST
+    # torch tensor (duck-typed: no torch import needed here)
+    assert a.is_contiguous(), "tensor must be contiguous"
+    return a.data_ptr(), (MEM_DEVICE if a.is_cuda else MEM_HOST)
+
+
+def f32c(x):
+    """fp32 C-contiguous numpy view/copy (inputs may be fp16/float64: vsc/index.py a-1)."""
+    return np.ascontiguousarray(x, dtype=np.float32)

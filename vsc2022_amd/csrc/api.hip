@@ -1,0 +1,950 @@
+// C ABI of libvscmi.so (declared in include/vscmi.h).  Host orchestration only: handles, HBM
+// residency, the stream-ordered batch schedule of the global-threshold search, staging of host
+// buffers.  Every arithmetic step runs in the HIP kernels of the sibling translation units.
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "kernels.h"
+
+namespace vscmi {
+
+// ---- errors
+static thread_local std::string g_err;
+void set_error(const char* fmt, ...) {
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_err = buf;
+}
+
+static int check_device(int device) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) {
+        set_error("no HIP device visible (libvscmi needs an MI355X / gfx950 GPU)");
+        return VSC_ERR_NODEVICE;
+    }
+    if (device < 0 || device >= n) {
+        set_error("device %d out of range (have %d)", device, n);
+        return VSC_ERR_INVALID;
+    }
+    hipDeviceProp_t p;
+    VSC_HIP(hipGetDeviceProperties(&p, device));
+    if (strncmp(p.gcnArchName, "gfx950", 6) != 0) {
+        set_error("device %d is %s; libvscmi is built for gfx950 only", device, p.gcnArchName);
+        return VSC_ERR_NODEVICE;
+    }
+    return VSC_OK;
+}
+
+// Workspace shared by the operations of one stream owner.
+struct Workspace {
+    DevBuf stage;   // host->device staging of raw fp32 rows
+    DevBuf qbuf;    // packed query rows
+    DevBuf hA[3], hB[3];  // kept hits (i, j, s) + compaction target
+    DevBuf ctl;     // SelectCtl
+    DevBuf w0, w1, w2, w3, tmp, cnt;  // sort scratch
+    DevBuf out[4];  // device-side outputs when the caller wants host results
+    DevBuf parts, partj, mat, maps0, maps1;
+    void release() {
+        stage.release(); qbuf.release();
+        for (auto& b : hA) b.release();
+        for (auto& b : hB) b.release();
+        ctl.release(); w0.release(); w1.release(); w2.release(); w3.release(); tmp.release(); cnt.release();
+        for (auto& b : out) b.release();
+        parts.release(); partj.release(); mat.release(); maps0.release(); maps1.release();
+    }
+};
+
+// Bring raw fp32 rows (host or device) into the packed engine layout at dst (rows_out rows are
+// written, rows >= n zero).  Host sources are staged in chunks.
+static int pack_into(const float* x, int64_t n, int dim, int mem, float* dst, int64_t rows_out, int dpad,
+                     Workspace& ws, hipStream_t stream) {
+    if (mem == VSC_MEM_DEVICE || n == 0) return launch_pack_rows(x, n, dim, dst, rows_out, dpad, stream);
+    const int64_t chunk_rows = std::max<int64_t>(1, (int64_t)(256ll << 20) / ((int64_t)dim * 4));
+    VSC_TRY(ws.stage.reserve((size_t)std::min(chunk_rows, n) * dim * 4));
+    for (int64_t r0 = 0; r0 < n; r0 += chunk_rows) {
+        const int64_t rows = std::min(chunk_rows, n - r0);
+        VSC_HIP(hipMemcpyAsync(ws.stage.p, x + r0 * dim, (size_t)rows * dim * 4, hipMemcpyHostToDevice, stream));
+        const bool last = (r0 + rows == n);
+        const int64_t out_rows = last ? rows_out - r0 : rows;
+        VSC_TRY(launch_pack_rows(ws.stage.as<float>(), rows, dim, dst + r0 * dpad, out_rows, dpad, stream));
+        VSC_HIP(hipStreamSynchronize(stream));  // staging buffer is reused
+    }
+    return VSC_OK;
+}
+
+}  // namespace vscmi
+
+using namespace vscmi;
+
+struct vsc_index {
+    int dim = 0, dpad = 0, metric = 0, device = 0;
+    int64_t ntotal = 0, cap_rows = 0;
+    DevBuf ref;
+    hipStream_t stream = nullptr;
+    Workspace ws;
+    int64_t hit_cap_user = 0;
+    // profiling of the dominant similarity kernel
+    bool prof = false;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
+    size_t ev_used = 0;
+    double prof_ms = 0.0, prof_flops = 0.0, pending_flops = 0.0;
+    int64_t prof_launches = 0;
+};
+
+static int prof_begin(vsc_index* idx, hipEvent_t* stop_out) {
+    *stop_out = nullptr;
+    if (!idx->prof) return VSC_OK;
+    if (idx->ev_used == idx->ev_pool.size()) {
+        hipEvent_t a, b;
+        VSC_HIP(hipEventCreate(&a));
+        VSC_HIP(hipEventCreate(&b));
+        idx->ev_pool.emplace_back(a, b);
+    }
+    auto& e = idx->ev_pool[idx->ev_used++];
+    VSC_HIP(hipEventRecord(e.first, idx->stream));
+    *stop_out = e.second;
+    return VSC_OK;
+}
+static int prof_end(vsc_index* idx, hipEvent_t stop, double flops) {
+    if (!stop) return VSC_OK;
+    VSC_HIP(hipEventRecord(stop, idx->stream));
+    idx->pending_flops += flops;
+    return VSC_OK;
+}
+// call after a stream sync
+static int prof_collect(vsc_index* idx) {
+    for (size_t e = 0; e < idx->ev_used; ++e) {
+        float ms = 0.0f;
+        VSC_HIP(hipEventElapsedTime(&ms, idx->ev_pool[e].first, idx->ev_pool[e].second));
+        idx->prof_ms += ms;
+        idx->prof_launches += 1;
+    }
+    idx->prof_flops += idx->pending_flops;
+    idx->pending_flops = 0.0;
+    idx->ev_used = 0;
+    return VSC_OK;
+}
+
+extern "C" {
+
+const char* vsc_last_error(void) { return g_err.c_str(); }
+int vsc_version(void) { return 100; }
+
+int vsc_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    int ok = 0;
+    for (int d = 0; d < n; ++d) {
+        hipDeviceProp_t p;
+        if (hipGetDeviceProperties(&p, d) == hipSuccess && strncmp(p.gcnArchName, "gfx950", 6) == 0) ++ok;
+    }
+    return ok;
+}
+
+int vsc_index_create(int dim, int metric, int device, vsc_index_t** out) {
+    if (!out || dim <= 0 || (metric != VSC_METRIC_INNER_PRODUCT && metric != VSC_METRIC_L2)) {
+        set_error("vsc_index_create: invalid argument (dim=%d metric=%d)", dim, metric);
+        return VSC_ERR_INVALID;
+    }
+    VSC_TRY(check_device(device));
+    VSC_HIP(hipSetDevice(device));
+    vsc_index* idx = new vsc_index();
+    idx->dim = dim;
+    idx->dpad = round_up(dim, K_PAD);
+    idx->metric = metric;
+    idx->device = device;
+    hipError_t e = hipStreamCreateWithFlags(&idx->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) {
+        set_error("hipStreamCreate failed: %s", hipGetErrorString(e));
+        delete idx;
+        return VSC_ERR_HIP;
+    }
+    int rc = set_thresh_kernel_attrs();
+    if (rc != VSC_OK) {
+        (void)hipStreamDestroy(idx->stream);
+        delete idx;
+        return rc;
+    }
+    *out = idx;
+    return VSC_OK;
+}
+
+int vsc_index_destroy(vsc_index_t* idx) {
+    if (!idx) return VSC_OK;
+    (void)hipSetDevice(idx->device);
+    (void)hipStreamSynchronize(idx->stream);
+    idx->ref.release();
+    idx->ws.release();
+    for (auto& e : idx->ev_pool) {
+        (void)hipEventDestroy(e.first);
+        (void)hipEventDestroy(e.second);
+    }
+    (void)hipStreamDestroy(idx->stream);
+    delete idx;
+    return VSC_OK;
+}
+
+int64_t vsc_index_ntotal(const vsc_index_t* idx) { return idx ? idx->ntotal : 0; }
+int vsc_index_dim(const vsc_index_t* idx) { return idx ? idx->dim : 0; }
+int vsc_index_metric(const vsc_index_t* idx) { return idx ? idx->metric : 0; }
+
+int vsc_index_set_hit_capacity(vsc_index_t* idx, int64_t cap) {
+    if (!idx || cap < 0) {
+        set_error("vsc_index_set_hit_capacity: invalid argument");
+        return VSC_ERR_INVALID;
+    }
+    idx->hit_cap_user = cap;
+    return VSC_OK;
+}
+
+int vsc_index_sync(vsc_index_t* idx) {
+    if (!idx) return VSC_ERR_INVALID;
+    VSC_HIP(hipSetDevice(idx->device));
+    VSC_HIP(hipStreamSynchronize(idx->stream));
+    return VSC_OK;
+}
+
+int vsc_index_add(vsc_index_t* idx, const float* x, int64_t n, int x_mem) {
+    if (!idx || n < 0 || (n > 0 && !x)) {
+        set_error("vsc_index_add: invalid argument");
+        return VSC_ERR_INVALID;
+    }
+    if (n == 0) return VSC_OK;
+    if (idx->ntotal + n >= 0x7fffff00LL) {
+        set_error("vsc_index_add: more than 2^31 reference rows");
+        return VSC_ERR_INVALID;
+    }
+    VSC_HIP(hipSetDevice(idx->device));
+    const int64_t need_rows = round_up64(idx->ntotal + n, ROW_PAD);
+    if (need_rows > idx->cap_rows) {
+        // grow geometrically; keep the old rows
+        int64_t cap = std::max<int64_t>(need_rows, idx->cap_rows + idx->cap_rows / 2);
+        cap = round_up64(cap, ROW_PAD);
+        DevBuf nb;
+        VSC_TRY(nb.reserve((size_t)cap * idx->dpad * 4));
+        if (idx->ntotal > 0) {
+            VSC_HIP(hipMemcpyAsync(nb.p, idx->ref.p, (size_t)idx->ntotal * idx->dpad * 4,
+                                   hipMemcpyDeviceToDevice, idx->stream));
+            VSC_HIP(hipStreamSynchronize(idx->stream));
+        }
+        idx->ref.release();
+        idx->ref = nb;
+        idx->cap_rows = cap;
+    }
+    float* dst = idx->ref.as<float>() + idx->ntotal * idx->dpad;
+    VSC_TRY(pack_into(x, n, idx->dim, x_mem, dst, need_rows - idx->ntotal, idx->dpad, idx->ws, idx->stream));
+    VSC_HIP(hipStreamSynchronize(idx->stream));
+    idx->ntotal += n;
+    return VSC_OK;
+}
+
+// Pack the query rows: returns device pointer; buffer holds round_up(nq,128)+128 zero-padded rows.
+static int pack_queries(vsc_index* idx, const float* q, int64_t nq, int q_mem, float** out) {
+    const int64_t rows = round_up64(nq, ROW_PAD) + ROW_PAD;
+    VSC_TRY(idx->ws.qbuf.reserve((size_t)rows * idx->dpad * 4));
+    VSC_TRY(pack_into(q, nq, idx->dim, q_mem, idx->ws.qbuf.as<float>(), rows, idx->dpad, idx->ws, idx->stream));
+    *out = idx->ws.qbuf.as<float>();
+    return VSC_OK;
+}
+
+static int ensure_hit_buffers(vsc_index* idx, int64_t cap) {
+    for (int c = 0; c < 3; ++c) {
+        VSC_TRY(idx->ws.hA[c].reserve((size_t)cap * 4));
+        VSC_TRY(idx->ws.hB[c].reserve((size_t)cap * 4));
+    }
+    VSC_TRY(idx->ws.ctl.reserve(sizeof(SelectCtl)));
+    return VSC_OK;
+}
+
+// Append every (row, ref) of query rows [i0, i1) with score > *radius (score space: IP as is, L2
+// negated) to the hit buffer A.
+static int enqueue_batch(vsc_index* idx, const float* qpacked, int64_t i0, int64_t i1, int64_t cap) {
+    SelectCtl* ctl = idx->ws.ctl.as<SelectCtl>();
+    const int nqb = (int)(i1 - i0);
+    if (idx->metric == VSC_METRIC_INNER_PRODUCT) {
+        SimThreshArgs a;
+        a.Q = qpacked + i0 * idx->dpad;
+        a.R = idx->ref.as<float>();
+        a.dpad = idx->dpad;
+        a.nq = nqb;
+        a.i0 = (int)i0;
+        a.nr = (int)idx->ntotal;
+        a.tq = (nqb + 127) / 128;
+        a.tr = (int)((idx->ntotal + 127) / 128);
+        a.radius = &ctl->radius;
+        a.out_i = idx->ws.hA[0].as<int32_t>();
+        a.out_j = idx->ws.hA[1].as<int32_t>();
+        a.out_s = idx->ws.hA[2].as<float>();
+        a.counter = &ctl->n;
+        a.cap = cap;
+        a.overflow = &ctl->overflow;
+        hipEvent_t stop;
+        VSC_TRY(prof_begin(idx, &stop));
+        VSC_TRY(launch_sim_thresh(a, idx->stream));
+        VSC_TRY(prof_end(idx, stop, 2.0 * (double)nqb * (double)idx->ntotal * (double)idx->dim));
+        return VSC_OK;
+    }
+    // generic metric: explicit score matrix in row chunks
+    const int64_t nr = idx->ntotal;
+    const int64_t chunk = std::max<int64_t>(1, std::min<int64_t>(nqb, (int64_t)(1ll << 28) / std::max<int64_t>(nr, 1)));
+    VSC_TRY(idx->ws.mat.reserve((size_t)chunk * nr * 4));
+    for (int64_t r0 = i0; r0 < i1; r0 += chunk) {
+        const int rows = (int)std::min(chunk, i1 - r0);
+        ScoreMatArgs m{qpacked + r0 * idx->dpad, idx->ref.as<float>(), idx->dpad, idx->dim, rows, (int)nr,
+                       idx->metric, idx->ws.mat.as<float>()};
+        VSC_TRY(launch_score_matrix(m, idx->stream));
+        MatThreshArgs t{idx->ws.mat.as<float>(), rows, (int)nr, (int)r0, &ctl->radius,
+                        idx->ws.hA[0].as<int32_t>(), idx->ws.hA[1].as<int32_t>(), idx->ws.hA[2].as<float>(),
+                        &ctl->n, cap, &ctl->overflow};
+        VSC_TRY(launch_matrix_thresh(t, idx->stream));
+    }
+    return VSC_OK;
+}
+
+static int init_ctl(vsc_index* idx, float radius_score_space) {
+    SelectCtl h;
+    memset(&h, 0, sizeof(h));
+    h.radius = radius_score_space;
+    VSC_HIP(hipMemcpyAsync(idx->ws.ctl.p, &h, sizeof(h), hipMemcpyHostToDevice, idx->stream));
+    VSC_HIP(hipStreamSynchronize(idx->stream));  // h is a stack object
+    return VSC_OK;
+}
+
+int vsc_index_global_topk(vsc_index_t* idx, const float* q, int64_t nq, int q_mem, int64_t K,
+                          int32_t* out_i, int32_t* out_j, float* out_s, int64_t cap_out, int out_mem,
+                          int64_t* n_out, float* final_radius) {
+    if (!idx || nq < 0 || K < 0 || !n_out || (nq > 0 && !q)) {
+        set_error("vsc_index_global_topk: invalid argument");
+        return VSC_ERR_INVALID;
+    }
+    *n_out = 0;
+    const bool ip = idx->metric == VSC_METRIC_INNER_PRODUCT;
+    if (final_radius) *final_radius = ip ? -1e10f : 1e10f;
+    if (nq == 0 || idx->ntotal == 0) return VSC_OK;
+    VSC_HIP(hipSetDevice(idx->device));
+    float* qp = nullptr;
+    VSC_TRY(pack_queries(idx, q, nq, q_mem, &qp));
+    int64_t cap = idx->hit_cap_user;
+    if (cap <= 0) cap = std::max<int64_t>(32 * idx->ntotal, 2 * K) + 2 * K + 1024;
+    cap = std::min<int64_t>(cap, nq * idx->ntotal + 1024);
+    VSC_TRY(ensure_hit_buffers(idx, cap));
+    // initial radius -1e10 (IP) / +1e10 (L2) -> -1e10 in score space either way (vsc/index.py:146)
+    VSC_TRY(init_ctl(idx, -1e10f));
+    SelectCtl* ctl = idx->ws.ctl.as<SelectCtl>();
+    // exponential_query_iterator: 32, 64, ... doubling while bs < 20000
+    int64_t bs = 32, i0 = 0;
+    while (i0 < nq) {
+        const int64_t i1 = std::min(nq, i0 + bs);
+        VSC_TRY(enqueue_batch(idx, qp, i0, i1, cap));
+        VSC_TRY(enqueue_rethreshold(ctl, idx->ws.hA[0].as<int32_t>(), idx->ws.hA[1].as<int32_t>(),
+                                    idx->ws.hA[2].as<float>(), idx->ws.hB[0].as<int32_t>(),
+                                    idx->ws.hB[1].as<int32_t>(), idx->ws.hB[2].as<float>(),
+                                    (unsigned long long)K, idx->stream));
+        if (bs < 20000) bs *= 2;
+        i0 = i1;
+    }
+    SelectCtl h;
+    VSC_HIP(hipMemcpyAsync(&h, ctl, sizeof(h), hipMemcpyDeviceToHost, idx->stream));
+    VSC_HIP(hipStreamSynchronize(idx->stream));
+    VSC_TRY(prof_collect(idx));
+    if (h.overflow) {
+        set_error("global_topk: kept-hit buffer (%lld entries) overflowed; raise it with "
+                  "vsc_index_set_hit_capacity", (long long)cap);
+        return VSC_ERR_OVERFLOW;
+    }
+    if (final_radius) *final_radius = ip ? h.radius : -h.radius;
+    const int64_t n = (int64_t)h.n;
+    const int64_t m = std::min(n, K);
+    if (m > cap_out) {
+        *n_out = m;
+        set_error("global_topk: output capacity %lld < %lld", (long long)cap_out, (long long)m);
+        return VSC_ERR_CAPACITY;
+    }
+    int32_t *di = out_i, *dj = out_j;
+    float* ds = out_s;
+    if (out_mem == VSC_MEM_HOST) {
+        VSC_TRY(idx->ws.out[0].reserve((size_t)std::max<int64_t>(m, 1) * 4));
+        VSC_TRY(idx->ws.out[1].reserve((size_t)std::max<int64_t>(m, 1) * 4));
+        VSC_TRY(idx->ws.out[2].reserve((size_t)std::max<int64_t>(m, 1) * 4));
+        di = idx->ws.out[0].as<int32_t>();
+        dj = idx->ws.out[1].as<int32_t>();
+        ds = idx->ws.out[2].as<float>();
+    }
+    int64_t mm = 0;
+    VSC_TRY(sort_hits_topk(idx->ws.hA[0].as<int32_t>(), idx->ws.hA[1].as<int32_t>(), idx->ws.hA[2].as<float>(),
+                           n, K, nq, idx->ws.w0, idx->ws.w1, idx->ws.w2, idx->ws.w3, idx->ws.tmp, di, dj, ds,
+                           ip ? 0 : 1, &mm, idx->stream));
+    if (out_mem == VSC_MEM_HOST && mm > 0) {
+        VSC_HIP(hipMemcpyAsync(out_i, di, (size_t)mm * 4, hipMemcpyDeviceToHost, idx->stream));
+        VSC_HIP(hipMemcpyAsync(out_j, dj, (size_t)mm * 4, hipMemcpyDeviceToHost, idx->stream));
+        VSC_HIP(hipMemcpyAsync(out_s, ds, (size_t)mm * 4, hipMemcpyDeviceToHost, idx->stream));
+    }
+    VSC_HIP(hipStreamSynchronize(idx->stream));
+    *n_out = mm;
+    return VSC_OK;
+}
+
+int vsc_index_range_search(vsc_index_t* idx, const float* q, int64_t nq, int q_mem, float radius,
+                           int64_t* lims, float* D, int64_t* I, int64_t cap_out, int64_t* n_out) {
+    if (!idx || nq < 0 || !lims || !n_out || (nq > 0 && !q)) {
+        set_error("vsc_index_range_search: invalid argument");
+        return VSC_ERR_INVALID;
+    }
+    *n_out = 0;
+    for (int64_t i = 0; i <= nq; ++i) lims[i] = 0;
+    if (nq == 0 || idx->ntotal == 0) return VSC_OK;
+    const bool ip = idx->metric == VSC_METRIC_INNER_PRODUCT;
+    VSC_HIP(hipSetDevice(idx->device));
+    float* qp = nullptr;
+    VSC_TRY(pack_queries(idx, q, nq, q_mem, &qp));
+    int64_t cap = idx->hit_cap_user > 0 ? idx->hit_cap_user : std::min<int64_t>(nq * idx->ntotal, (int64_t)1 << 28);
+    cap = std::max<int64_t>(cap, 1024);
+    VSC_TRY(ensure_hit_buffers(idx, cap));
+    VSC_TRY(init_ctl(idx, ip ? radius : -radius));
+    SelectCtl* ctl = idx->ws.ctl.as<SelectCtl>();
+    const int64_t step = 32768;
+    for (int64_t i0 = 0; i0 < nq; i0 += step) VSC_TRY(enqueue_batch(idx, qp, i0, std::min(nq, i0 + step), cap));
+    SelectCtl h;
+    VSC_HIP(hipMemcpyAsync(&h, ctl, sizeof(h), hipMemcpyDeviceToHost, idx->stream));
+    VSC_HIP(hipStreamSynchronize(idx->stream));
+    VSC_TRY(prof_collect(idx));
+    if (h.overflow) {
+        set_error("range_search: more than %lld hits; raise vsc_index_set_hit_capacity", (long long)cap);
+        return VSC_ERR_OVERFLOW;
+    }
+    const int64_t n = (int64_t)h.n;
+    *n_out = n;
+    if (n == 0) return VSC_OK;
+    // rows ascending, refs ascending (reuse B as the sorted target)
+    VSC_TRY(sort_hits_rowcol(idx->ws.hA[0].as<int32_t>(), idx->ws.hA[1].as<int32_t>(), idx->ws.hA[2].as<float>(), n,
+                             idx->ws.w0, idx->ws.w1, idx->ws.w2, idx->ws.w3, idx->ws.tmp, idx->ws.hB[0].as<int32_t>(),
+                             idx->ws.hB[1].as<int32_t>(), idx->ws.hB[2].as<float>(), ip ? 0 : 1, idx->stream));
+    std::vector<int32_t> hi((size_t)n);
+    VSC_HIP(hipMemcpyAsync(hi.data(), idx->ws.hB[0].p, (size_t)n * 4, hipMemcpyDeviceToHost, idx->stream));
+    VSC_HIP(hipStreamSynchronize(idx->stream));
+    for (int64_t x = 0; x < n; ++x) lims[hi[(size_t)x] + 1] += 1;
+    for (int64_t i = 0; i < nq; ++i) lims[i + 1] += lims[i];
+    if (!D || !I || cap_out < n) {
+        if (D || I) {
+            set_error("range_search: output capacity %lld < %lld", (long long)cap_out, (long long)n);
+            return VSC_ERR_CAPACITY;
+        }
+        return VSC_OK;  // size query
+    }
+    std::vector<int32_t> hj((size_t)n);
+    VSC_HIP(hipMemcpyAsync(hj.data(), idx->ws.hB[1].p, (size_t)n * 4, hipMemcpyDeviceToHost, idx->stream));
+    VSC_HIP(hipMemcpyAsync(D, idx->ws.hB[2].p, (size_t)n * 4, hipMemcpyDeviceToHost, idx->stream));
+    VSC_HIP(hipStreamSynchronize(idx->stream));
+    for (int64_t x = 0; x < n; ++x) I[x] = hj[(size_t)x];
+    return VSC_OK;
+}
+
+int vsc_index_knn(vsc_index_t* idx, const float* q, int64_t nq, int q_mem, int k, float* out_s,
+                  int64_t* out_j, int out_mem) {
+    if (!idx || nq < 0 || k <= 0 || k > 64 || (nq > 0 && (!q || !out_s || !out_j))) {
+        set_error("vsc_index_knn: invalid argument (k must be in 1..64, got %d)", k);
+        return VSC_ERR_INVALID;
+    }
+    if (nq == 0) return VSC_OK;
+    if (nq >= 0x7fffff00LL) {
+        set_error("vsc_index_knn: too many query rows");
+        return VSC_ERR_INVALID;
+    }
+    VSC_HIP(hipSetDevice(idx->device));
+    const bool ip = idx->metric == VSC_METRIC_INNER_PRODUCT;
+    float* qp = nullptr;
+    VSC_TRY(pack_queries(idx, q, nq, q_mem, &qp));
+    float* ds = out_s;
+    int64_t* dj = out_j;
+    if (out_mem == VSC_MEM_HOST) {
+        VSC_TRY(idx->ws.out[0].reserve((size_t)nq * k * 4));
+        VSC_TRY(idx->ws.out[1].reserve((size_t)nq * k * 8));
+        ds = idx->ws.out[0].as<float>();
+        dj = idx->ws.out[1].as<int64_t>();
+    }
+    const int64_t nr = idx->ntotal;
+    if (ip && nr > 0) {
+        const int tq = (int)((nq + 127) / 128);
+        const int tr = (int)((nr + 127) / 128);
+        // enough workgroups to fill 256 CUs several times over, but no more runs than ref tiles
+        int nchunk = (int)std::min<int64_t>(tr, std::max<int64_t>(1, (2048 + tq - 1) / tq));
+        nchunk = std::min(nchunk, 64);
+        const int64_t nq_pad = (int64_t)tq * 128;
+        VSC_TRY(idx->ws.parts.reserve((size_t)nq_pad * nchunk * k * 4));
+        VSC_TRY(idx->ws.partj.reserve((size_t)nq_pad * nchunk * k * 4));
+        SimKnnArgs a{qp, idx->ref.as<float>(), idx->dpad, (int)nq, (int)nr, tq, tr, nchunk, k,
+                     idx->ws.parts.as<float>(), idx->ws.partj.as<int32_t>()};
+        hipEvent_t stop;
+        VSC_TRY(prof_begin(idx, &stop));
+        VSC_TRY(launch_sim_knn(a, idx->stream));
+        VSC_TRY(prof_end(idx, stop, 2.0 * (double)nq * (double)nr * (double)idx->dim));
+        KnnMergeArgs m{idx->ws.parts.as<float>(), idx->ws.partj.as<int32_t>(), (int)nq, nchunk, k, ds, dj, 0};
+        VSC_TRY(launch_knn_merge(m, idx->stream));
+    } else {
+        // generic metric (or empty index): explicit score matrix, one run per row
+        VSC_TRY(idx->ws.parts.reserve((size_t)nq * k * 4));
+        VSC_TRY(idx->ws.partj.reserve((size_t)nq * k * 4));
+        const int64_t chunk = std::max<int64_t>(1, std::min<int64_t>(nq, (int64_t)(1ll << 28) / std::max<int64_t>(nr, 1)));
+        VSC_TRY(idx->ws.mat.reserve((size_t)chunk * std::max<int64_t>(nr, 1) * 4));
+        for (int64_t r0 = 0; r0 < nq; r0 += chunk) {
+            const int rows = (int)std::min(chunk, nq - r0);
+            ScoreMatArgs sm{qp + r0 * idx->dpad, idx->ref.as<float>(), idx->dpad, idx->dim, rows, (int)nr,
+                            idx->metric, idx->ws.mat.as<float>()};
+            VSC_TRY(launch_score_matrix(sm, idx->stream));
+            MatKnnArgs mk{idx->ws.mat.as<float>(), rows, (int)nr, k, idx->ws.parts.as<float>() + r0 * k,
+                          idx->ws.partj.as<int32_t>() + r0 * k};
+            VSC_TRY(launch_matrix_knn(mk, idx->stream));
+        }
+        KnnMergeArgs m{idx->ws.parts.as<float>(), idx->ws.partj.as<int32_t>(), (int)nq, 1, k, ds, dj, ip ? 0 : 1};
+        VSC_TRY(launch_knn_merge(m, idx->stream));
+    }
+    if (out_mem == VSC_MEM_HOST) {
+        VSC_HIP(hipMemcpyAsync(out_s, ds, (size_t)nq * k * 4, hipMemcpyDeviceToHost, idx->stream));
+        VSC_HIP(hipMemcpyAsync(out_j, dj, (size_t)nq * k * 8, hipMemcpyDeviceToHost, idx->stream));
+    }
+    VSC_HIP(hipStreamSynchronize(idx->stream));
+    VSC_TRY(prof_collect(idx));
+    return VSC_OK;
+}
+
+int vsc_index_profile(vsc_index_t* idx, int enable) {
+    if (!idx) return VSC_ERR_INVALID;
+    idx->prof = enable != 0;
+    return VSC_OK;
+}
+
+int vsc_index_profile_read(vsc_index_t* idx, double* sim_ms, int64_t* sim_launches, double* sim_flops,
+                           int reset) {
+    if (!idx) return VSC_ERR_INVALID;
+    if (sim_ms) *sim_ms = idx->prof_ms;
+    if (sim_launches) *sim_launches = idx->prof_launches;
+    if (sim_flops) *sim_flops = idx->prof_flops;
+    if (reset) {
+        idx->prof_ms = 0.0;
+        idx->prof_flops = 0.0;
+        idx->prof_launches = 0;
+    }
+    return VSC_OK;
+}
+
+// ------------------------------------------------------------------ stand-alone device ops
+
+struct DeviceCtx {
+    hipStream_t stream = nullptr;
+    Workspace ws;
+    std::mutex mu;
+};
+static DeviceCtx* device_ctx(int device) {
+    static std::mutex g_mu;
+    static std::vector<DeviceCtx*> ctxs;
+    std::lock_guard<std::mutex> lk(g_mu);
+    if ((int)ctxs.size() <= device) ctxs.resize(device + 1, nullptr);
+    if (!ctxs[device]) {
+        DeviceCtx* c = new DeviceCtx();
+        if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
+            delete c;
+            return nullptr;
+        }
+        ctxs[device] = c;
+    }
+    return ctxs[device];
+}
+
+// fetch `bytes` of a caller array into device memory (no copy if already there)
+static int to_device(const void* p, size_t bytes, int mem, DevBuf& buf, const void** out, hipStream_t s) {
+    if (mem == VSC_MEM_DEVICE) {
+        *out = p;
+        return VSC_OK;
+    }
+    VSC_TRY(buf.reserve(std::max<size_t>(bytes, 16)));
+    if (bytes) VSC_HIP(hipMemcpyAsync(buf.p, p, bytes, hipMemcpyHostToDevice, s));
+    *out = buf.p;
+    return VSC_OK;
+}
+
+int vsc_pair_max(const int32_t* hit_i, const int32_t* hit_j, const float* hit_s, int64_t n,
+                 int hits_mem, const int32_t* row2q, int64_t nq_rows, const int32_t* row2r,
+                 int64_t nr_rows, int maps_mem, int32_t* out_q, int32_t* out_r, float* out_s,
+                 int64_t* out_first, int64_t cap, int out_mem, int64_t* n_pairs, int device) {
+    if (n < 0 || !n_pairs || (n > 0 && (!hit_i || !hit_j || !hit_s || !row2q || !row2r))) {
+        set_error("vsc_pair_max: invalid argument");
+        return VSC_ERR_INVALID;
+    }
+    *n_pairs = 0;
+    if (n == 0) return VSC_OK;
+    VSC_TRY(check_device(device));
+    VSC_HIP(hipSetDevice(device));
+    DeviceCtx* c = device_ctx(device);
+    if (!c) {
+        set_error("vsc_pair_max: cannot create device context");
+        return VSC_ERR_HIP;
+    }
+    std::lock_guard<std::mutex> lk(c->mu);
+    Workspace& ws = c->ws;
+    const void *di, *dj, *ds, *dq, *dr;
+    VSC_TRY(to_device(hit_i, (size_t)n * 4, hits_mem, ws.hA[0], &di, c->stream));
+    VSC_TRY(to_device(hit_j, (size_t)n * 4, hits_mem, ws.hA[1], &dj, c->stream));
+    VSC_TRY(to_device(hit_s, (size_t)n * 4, hits_mem, ws.hA[2], &ds, c->stream));
+    VSC_TRY(to_device(row2q, (size_t)nq_rows * 4, maps_mem, ws.maps0, &dq, c->stream));
+    VSC_TRY(to_device(row2r, (size_t)nr_rows * 4, maps_mem, ws.maps1, &dr, c->stream));
+    int32_t *oq = out_q, *orr = out_r;
+    float* os = out_s;
+    int64_t* of = out_first;
+    const int64_t ocap = out_mem == VSC_MEM_HOST ? n : cap;
+    if (out_mem == VSC_MEM_HOST) {
+        VSC_TRY(ws.out[0].reserve((size_t)n * 4));
+        VSC_TRY(ws.out[1].reserve((size_t)n * 4));
+        VSC_TRY(ws.out[2].reserve((size_t)n * 4));
+        VSC_TRY(ws.out[3].reserve((size_t)n * 8));
+        oq = ws.out[0].as<int32_t>();
+        orr = ws.out[1].as<int32_t>();
+        os = ws.out[2].as<float>();
+        of = ws.out[3].as<int64_t>();
+    }
+    int64_t np = 0;
+    VSC_TRY(pair_max_device((const int32_t*)di, (const int32_t*)dj, (const float*)ds, n, (const int32_t*)dq,
+                            (const int32_t*)dr, 0, ws.w0, ws.w1, ws.w2, ws.w3, ws.tmp, ws.cnt, oq, orr, os, of,
+                            ocap, &np, c->stream));
+    *n_pairs = np;
+    if (out_mem == VSC_MEM_HOST) {
+        if (np > cap) {
+            set_error("vsc_pair_max: output capacity %lld < %lld pairs", (long long)cap, (long long)np);
+            return VSC_ERR_CAPACITY;
+        }
+        VSC_HIP(hipMemcpyAsync(out_q, oq, (size_t)np * 4, hipMemcpyDeviceToHost, c->stream));
+        VSC_HIP(hipMemcpyAsync(out_r, orr, (size_t)np * 4, hipMemcpyDeviceToHost, c->stream));
+        VSC_HIP(hipMemcpyAsync(out_s, os, (size_t)np * 4, hipMemcpyDeviceToHost, c->stream));
+        if (out_first) VSC_HIP(hipMemcpyAsync(out_first, of, (size_t)np * 8, hipMemcpyDeviceToHost, c->stream));
+    }
+    VSC_HIP(hipStreamSynchronize(c->stream));
+    return VSC_OK;
+}
+
+int vsc_row_normalize(const float* x, int64_t n, int dim, int x_mem, float* out, int out_mem, int device) {
+    if (n < 0 || dim <= 0 || (n > 0 && (!x || !out))) {
+        set_error("vsc_row_normalize: invalid argument");
+        return VSC_ERR_INVALID;
+    }
+    if (n == 0) return VSC_OK;
+    VSC_TRY(check_device(device));
+    VSC_HIP(hipSetDevice(device));
+    DeviceCtx* c = device_ctx(device);
+    if (!c) {
+        set_error("vsc_row_normalize: cannot create device context");
+        return VSC_ERR_HIP;
+    }
+    std::lock_guard<std::mutex> lk(c->mu);
+    const void* dx;
+    VSC_TRY(to_device(x, (size_t)n * dim * 4, x_mem, c->ws.stage, &dx, c->stream));
+    float* dout = out;
+    if (out_mem == VSC_MEM_HOST) {
+        VSC_TRY(c->ws.out[0].reserve((size_t)n * dim * 4));
+        dout = c->ws.out[0].as<float>();
+    }
+    VSC_TRY(launch_row_normalize((const float*)dx, n, dim, dout, c->stream));
+    if (out_mem == VSC_MEM_HOST)
+        VSC_HIP(hipMemcpyAsync(out, dout, (size_t)n * dim * 4, hipMemcpyDeviceToHost, c->stream));
+    VSC_HIP(hipStreamSynchronize(c->stream));
+    return VSC_OK;
+}
+
+}  // extern "C"
+
+// ------------------------------------------------------------------------ TN launches
+
+// Split the pairs of one call into launches by LDS footprint and run them.  `base` carries
+// everything except the per-launch fields.  In forward_sim mode (base.sims_in set) tiles are read
+// in place; otherwise they live in LDS when they fit the launch's budget and spill to `slab`.
+static int tn_run_buckets(TnPairArgs base, const std::vector<int32_t>& lqs, const std::vector<int32_t>& lrs,
+                          DevBuf& d_work, DevBuf& slab, hipStream_t stream) {
+    const int64_t n_pairs = (int64_t)lqs.size();
+    const int ms = base.prm.tn_max_step > 1 ? base.prm.tn_max_step : 1;
+    const int topc = base.prm.tn_top_k;
+    const bool fused = base.sims_in == nullptr;
+    struct Bucket { int max_lq; int64_t max_tile; std::vector<int32_t> work; int seen_lq; int64_t seen_tile; };
+    Bucket buckets[3] = {{64, 4096, {}, 0, 0}, {256, 24576, {}, 0, 0}, {0x7fffffff, 0, {}, 0, 0}};
+    for (int64_t p = 0; p < n_pairs; ++p) {
+        const int64_t lq = lqs[(size_t)p], lr = lrs[(size_t)p];
+        if (lq > 32000 || lr > 32000) {
+            set_error("TN: videos longer than 32000 frames are not supported");
+            return VSC_ERR_INVALID;
+        }
+        int b = 2;
+        if (lq <= 64 && (!fused || lq * lr <= 4096)) b = 0;
+        else if (lq <= 256 && (!fused || lq * lr <= 24576)) b = 1;
+        buckets[b].work.push_back((int32_t)p);
+        buckets[b].seen_lq = std::max<int>(buckets[b].seen_lq, (int)lq);
+        buckets[b].seen_tile = std::max<int64_t>(buckets[b].seen_tile, lq * lr);
+    }
+    VSC_TRY(d_work.reserve((size_t)std::max<int64_t>(n_pairs, 1) * 4));
+    int64_t woff = 0;
+    for (int b = 0; b < 3; ++b) {
+        Bucket& B = buckets[b];
+        if (B.work.empty()) continue;
+        const int max_lq = std::max(1, B.seen_lq);
+        const size_t state = tn_state_bytes_host(max_lq, topc, ms);
+        if (state > 150 * 1024) {
+            set_error("TN: a %d-frame query video needs %zu B of LDS state (limit 150 KiB)", max_lq, state);
+            return VSC_ERR_INVALID;
+        }
+        int tile_floats = 0;
+        int64_t slab_floats = 0;
+        if (fused) {
+            if (b < 2) tile_floats = (int)std::min<int64_t>(B.seen_tile, B.max_tile);
+            else {
+                slab_floats = (B.seen_tile + 63) / 64 * 64;
+                VSC_TRY(slab.reserve((size_t)slab_floats * 4 * B.work.size()));
+            }
+        }
+        const size_t lds = state + (size_t)tile_floats * 4;
+        int32_t* dwork = d_work.as<int32_t>() + woff;
+        VSC_HIP(hipMemcpyAsync(dwork, B.work.data(), B.work.size() * 4, hipMemcpyHostToDevice, stream));
+        TnPairArgs a = base;
+        a.work = dwork;
+        a.n_work = (int)B.work.size();
+        a.max_lq = max_lq;
+        a.lds_tile_floats = tile_floats;
+        a.slab = slab.as<float>();
+        a.slab_floats = slab_floats;
+        VSC_TRY(launch_tn_pairs(a, lds, stream));
+        VSC_HIP(hipStreamSynchronize(stream));  // B.work (host) and the slab are reused
+        woff += (int64_t)B.work.size();
+    }
+    return VSC_OK;
+}
+
+// ------------------------------------------------------------------------ TN context
+
+struct vsc_tn_ctx {
+    int device = 0, dim = 0, dpad = 0;
+    int64_t n_qvid = 0, n_rvid = 0;
+    std::vector<int64_t> q_off, r_off;  // host copies
+    DevBuf qfeat, rfeat, d_qoff, d_roff;
+    DevBuf d_pq, d_pr, d_work, d_nbox, d_boxes, d_bmax, slab, sims;
+    Workspace ws;
+    hipStream_t stream = nullptr;
+};
+
+extern "C" {
+
+int vsc_tn_create(const float* qfeat, const int64_t* q_off, int64_t n_qvid, const float* rfeat,
+                  const int64_t* r_off, int64_t n_rvid, int dim, int feat_mem, int device,
+                  vsc_tn_ctx_t** out) {
+    if (!out || dim <= 0 || n_qvid < 0 || n_rvid < 0 || !q_off || !r_off) {
+        set_error("vsc_tn_create: invalid argument");
+        return VSC_ERR_INVALID;
+    }
+    VSC_TRY(check_device(device));
+    VSC_HIP(hipSetDevice(device));
+    vsc_tn_ctx* c = new vsc_tn_ctx();
+    c->device = device;
+    c->dim = dim;
+    c->dpad = round_up(dim, K_PAD);
+    c->n_qvid = n_qvid;
+    c->n_rvid = n_rvid;
+    c->q_off.assign(q_off, q_off + n_qvid + 1);
+    c->r_off.assign(r_off, r_off + n_rvid + 1);
+    int rc = VSC_OK;
+    auto fail = [&](int code) {
+        vsc_tn_destroy(c);
+        return code;
+    };
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
+        set_error("hipStreamCreate failed");
+        delete c;
+        return VSC_ERR_HIP;
+    }
+    const int64_t nq = c->q_off.back(), nr = c->r_off.back();
+    // +32 rows of slack: the 32-row MFMA blocks of the last video read past its end
+    const int64_t q_rows = round_up64(nq + 32, ROW_PAD), r_rows = round_up64(nr + 32, ROW_PAD);
+    if ((rc = c->qfeat.reserve((size_t)q_rows * c->dpad * 4)) != VSC_OK) return fail(rc);
+    if ((rc = c->rfeat.reserve((size_t)r_rows * c->dpad * 4)) != VSC_OK) return fail(rc);
+    if ((rc = pack_into(qfeat, nq, dim, feat_mem, c->qfeat.as<float>(), q_rows, c->dpad, c->ws, c->stream)) != VSC_OK) return fail(rc);
+    if ((rc = pack_into(rfeat, nr, dim, feat_mem, c->rfeat.as<float>(), r_rows, c->dpad, c->ws, c->stream)) != VSC_OK) return fail(rc);
+    if ((rc = c->d_qoff.reserve((size_t)(n_qvid + 1) * 8)) != VSC_OK) return fail(rc);
+    if ((rc = c->d_roff.reserve((size_t)(n_rvid + 1) * 8)) != VSC_OK) return fail(rc);
+    if (hipMemcpyAsync(c->d_qoff.p, c->q_off.data(), (size_t)(n_qvid + 1) * 8, hipMemcpyHostToDevice, c->stream) != hipSuccess ||
+        hipMemcpyAsync(c->d_roff.p, c->r_off.data(), (size_t)(n_rvid + 1) * 8, hipMemcpyHostToDevice, c->stream) != hipSuccess ||
+        hipStreamSynchronize(c->stream) != hipSuccess) {
+        set_error("vsc_tn_create: offset upload failed");
+        return fail(VSC_ERR_HIP);
+    }
+    *out = c;
+    return VSC_OK;
+}
+
+int vsc_tn_destroy(vsc_tn_ctx_t* c) {
+    if (!c) return VSC_OK;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    c->qfeat.release(); c->rfeat.release(); c->d_qoff.release(); c->d_roff.release();
+    c->d_pq.release(); c->d_pr.release(); c->d_work.release(); c->d_nbox.release();
+    c->d_boxes.release(); c->d_bmax.release(); c->slab.release(); c->sims.release();
+    c->ws.release();
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+    return VSC_OK;
+}
+
+int vsc_tn_localize(vsc_tn_ctx_t* c, const int32_t* pair_q, const int32_t* pair_r, int64_t n_pairs,
+                    int pairs_mem, const vsc_tn_params* params, float bias, int32_t* out_nbox,
+                    int32_t* out_boxes, float* out_boxmax, int out_mem) {
+    if (!c || n_pairs < 0 || !params || (n_pairs > 0 && (!pair_q || !pair_r || !out_nbox || !out_boxes || !out_boxmax))) {
+        set_error("vsc_tn_localize: invalid argument");
+        return VSC_ERR_INVALID;
+    }
+    if (n_pairs == 0) return VSC_OK;
+    if (params->tn_top_k < 1 || params->tn_top_k > 16 || params->tn_max_step < 1 || params->tn_max_step > 64 ||
+        params->max_path < 0) {
+        set_error("vsc_tn_localize: unsupported TN parameters (tn_top_k 1..16, tn_max_step 1..64)");
+        return VSC_ERR_INVALID;
+    }
+    VSC_HIP(hipSetDevice(c->device));
+    // pair lists on both sides: host for bucketing, device for the kernel
+    std::vector<int32_t> hq((size_t)n_pairs), hr((size_t)n_pairs);
+    VSC_TRY(c->d_pq.reserve((size_t)n_pairs * 4));
+    VSC_TRY(c->d_pr.reserve((size_t)n_pairs * 4));
+    if (pairs_mem == VSC_MEM_HOST) {
+        memcpy(hq.data(), pair_q, (size_t)n_pairs * 4);
+        memcpy(hr.data(), pair_r, (size_t)n_pairs * 4);
+        VSC_HIP(hipMemcpyAsync(c->d_pq.p, pair_q, (size_t)n_pairs * 4, hipMemcpyHostToDevice, c->stream));
+        VSC_HIP(hipMemcpyAsync(c->d_pr.p, pair_r, (size_t)n_pairs * 4, hipMemcpyHostToDevice, c->stream));
+    } else {
+        VSC_HIP(hipMemcpyAsync(hq.data(), pair_q, (size_t)n_pairs * 4, hipMemcpyDeviceToHost, c->stream));
+        VSC_HIP(hipMemcpyAsync(hr.data(), pair_r, (size_t)n_pairs * 4, hipMemcpyDeviceToHost, c->stream));
+        VSC_HIP(hipMemcpyAsync(c->d_pq.p, pair_q, (size_t)n_pairs * 4, hipMemcpyDeviceToDevice, c->stream));
+        VSC_HIP(hipMemcpyAsync(c->d_pr.p, pair_r, (size_t)n_pairs * 4, hipMemcpyDeviceToDevice, c->stream));
+    }
+    VSC_HIP(hipStreamSynchronize(c->stream));
+    std::vector<int32_t> lqs((size_t)n_pairs), lrs((size_t)n_pairs);
+    for (int64_t p = 0; p < n_pairs; ++p) {
+        const int32_t qv = hq[(size_t)p], rv = hr[(size_t)p];
+        if (qv < 0 || qv >= c->n_qvid || rv < 0 || rv >= c->n_rvid) {
+            set_error("vsc_tn_localize: pair %lld has video ordinal out of range", (long long)p);
+            return VSC_ERR_INVALID;
+        }
+        lqs[(size_t)p] = (int32_t)std::min<int64_t>(c->q_off[qv + 1] - c->q_off[qv], 0x7fffffff);
+        lrs[(size_t)p] = (int32_t)std::min<int64_t>(c->r_off[rv + 1] - c->r_off[rv], 0x7fffffff);
+    }
+    int32_t* d_nbox = out_nbox;
+    int32_t* d_boxes = out_boxes;
+    float* d_bmax = out_boxmax;
+    if (out_mem == VSC_MEM_HOST) {
+        VSC_TRY(c->d_nbox.reserve((size_t)n_pairs * 4));
+        VSC_TRY(c->d_boxes.reserve((size_t)n_pairs * VSC_TN_MAX_BOXES * 16));
+        VSC_TRY(c->d_bmax.reserve((size_t)n_pairs * VSC_TN_MAX_BOXES * 4));
+        d_nbox = c->d_nbox.as<int32_t>();
+        d_boxes = c->d_boxes.as<int32_t>();
+        d_bmax = c->d_bmax.as<float>();
+    }
+    TnPairArgs base;
+    memset(&base, 0, sizeof(base));
+    base.qfeat = c->qfeat.as<float>();
+    base.rfeat = c->rfeat.as<float>();
+    base.q_off = c->d_qoff.as<int64_t>();
+    base.r_off = c->d_roff.as<int64_t>();
+    base.dpad = c->dpad;
+    base.pair_q = c->d_pq.as<int32_t>();
+    base.pair_r = c->d_pr.as<int32_t>();
+    base.prm = *params;
+    base.bias = bias;
+    base.out_nbox = d_nbox;
+    base.out_boxes = d_boxes;
+    base.out_boxmax = d_bmax;
+    VSC_TRY(tn_run_buckets(base, lqs, lrs, c->d_work, c->slab, c->stream));
+    if (out_mem == VSC_MEM_HOST) {
+        VSC_HIP(hipMemcpyAsync(out_nbox, d_nbox, (size_t)n_pairs * 4, hipMemcpyDeviceToHost, c->stream));
+        VSC_HIP(hipMemcpyAsync(out_boxes, d_boxes, (size_t)n_pairs * VSC_TN_MAX_BOXES * 16, hipMemcpyDeviceToHost, c->stream));
+        VSC_HIP(hipMemcpyAsync(out_boxmax, d_bmax, (size_t)n_pairs * VSC_TN_MAX_BOXES * 4, hipMemcpyDeviceToHost, c->stream));
+    }
+    VSC_HIP(hipStreamSynchronize(c->stream));
+    return VSC_OK;
+}
+
+int vsc_tn_forward_sim(const float* sims, const int64_t* sims_off, const int32_t* lq, const int32_t* lr,
+                       int64_t n_pairs, const vsc_tn_params* params, int32_t* out_nbox, int32_t* out_boxes,
+                       float* out_boxmax, int device) {
+    if (n_pairs < 0 || !params || (n_pairs > 0 && (!sims || !sims_off || !lq || !lr || !out_nbox || !out_boxes || !out_boxmax))) {
+        set_error("vsc_tn_forward_sim: invalid argument");
+        return VSC_ERR_INVALID;
+    }
+    if (n_pairs == 0) return VSC_OK;
+    if (params->tn_top_k < 1 || params->tn_top_k > 16 || params->tn_max_step < 1 || params->tn_max_step > 64 ||
+        params->max_path < 0) {
+        set_error("vsc_tn_forward_sim: unsupported TN parameters (tn_top_k 1..16, tn_max_step 1..64)");
+        return VSC_ERR_INVALID;
+    }
+    VSC_TRY(check_device(device));
+    VSC_HIP(hipSetDevice(device));
+    DeviceCtx* c = device_ctx(device);
+    if (!c) {
+        set_error("vsc_tn_forward_sim: cannot create device context");
+        return VSC_ERR_HIP;
+    }
+    std::lock_guard<std::mutex> lk(c->mu);
+    Workspace& ws = c->ws;
+    const int64_t total = sims_off[n_pairs];
+    VSC_TRY(ws.mat.reserve((size_t)std::max<int64_t>(total, 1) * 4));
+    VSC_TRY(ws.w0.reserve((size_t)(n_pairs + 1) * 8));
+    VSC_TRY(ws.w2.reserve((size_t)n_pairs * 4));
+    VSC_TRY(ws.w3.reserve((size_t)n_pairs * 4));
+    VSC_TRY(ws.out[0].reserve((size_t)n_pairs * 4));
+    VSC_TRY(ws.out[1].reserve((size_t)n_pairs * VSC_TN_MAX_BOXES * 16));
+    VSC_TRY(ws.out[2].reserve((size_t)n_pairs * VSC_TN_MAX_BOXES * 4));
+    if (total) VSC_HIP(hipMemcpyAsync(ws.mat.p, sims, (size_t)total * 4, hipMemcpyHostToDevice, c->stream));
+    VSC_HIP(hipMemcpyAsync(ws.w0.p, sims_off, (size_t)(n_pairs + 1) * 8, hipMemcpyHostToDevice, c->stream));
+    VSC_HIP(hipMemcpyAsync(ws.w2.p, lq, (size_t)n_pairs * 4, hipMemcpyHostToDevice, c->stream));
+    VSC_HIP(hipMemcpyAsync(ws.w3.p, lr, (size_t)n_pairs * 4, hipMemcpyHostToDevice, c->stream));
+    TnPairArgs base;
+    memset(&base, 0, sizeof(base));
+    base.prm = *params;
+    base.bias = 0.0f;
+    base.out_nbox = ws.out[0].as<int32_t>();
+    base.out_boxes = ws.out[1].as<int32_t>();
+    base.out_boxmax = ws.out[2].as<float>();
+    base.sims_in = ws.mat.as<float>();
+    base.sims_off = ws.w0.as<int64_t>();
+    base.sims_lq = ws.w2.as<int32_t>();
+    base.sims_lr = ws.w3.as<int32_t>();
+    std::vector<int32_t> lqs(lq, lq + n_pairs), lrs(lr, lr + n_pairs);
+    VSC_TRY(tn_run_buckets(base, lqs, lrs, ws.maps0, ws.maps1, c->stream));
+    VSC_HIP(hipMemcpyAsync(out_nbox, ws.out[0].p, (size_t)n_pairs * 4, hipMemcpyDeviceToHost, c->stream));
+    VSC_HIP(hipMemcpyAsync(out_boxes, ws.out[1].p, (size_t)n_pairs * VSC_TN_MAX_BOXES * 16, hipMemcpyDeviceToHost, c->stream));
+    VSC_HIP(hipMemcpyAsync(out_boxmax, ws.out[2].p, (size_t)n_pairs * VSC_TN_MAX_BOXES * 4, hipMemcpyDeviceToHost, c->stream));
+    VSC_HIP(hipStreamSynchronize(c->stream));
+    return VSC_OK;
+}
+
+int vsc_tn_similarity(vsc_tn_ctx_t* c, int32_t q_vid, int32_t r_vid, float bias, float* out, int64_t cap,
+                      int32_t* lq_out, int32_t* lr_out) {
+    if (!c || q_vid < 0 || q_vid >= c->n_qvid || r_vid < 0 || r_vid >= c->n_rvid) {
+        set_error("vsc_tn_similarity: invalid argument");
+        return VSC_ERR_INVALID;
+    }
+    const int64_t lq = c->q_off[q_vid + 1] - c->q_off[q_vid], lr = c->r_off[r_vid + 1] - c->r_off[r_vid];
+    if (lq_out) *lq_out = (int32_t)lq;
+    if (lr_out) *lr_out = (int32_t)lr;
+    if (lq * lr > cap || !out) {
+        set_error("vsc_tn_similarity: output capacity %lld < %lld", (long long)cap, (long long)(lq * lr));
+        return VSC_ERR_CAPACITY;
+    }
+    if (lq * lr == 0) return VSC_OK;
+    VSC_HIP(hipSetDevice(c->device));
+    VSC_TRY(c->sims.reserve((size_t)lq * lr * 4));
+    TnSimsArgs a{c->qfeat.as<float>(), c->rfeat.as<float>(), c->q_off[q_vid], c->r_off[r_vid], (int)lq, (int)lr,
+                 c->dpad, bias, c->sims.as<float>()};
+    VSC_TRY(launch_tn_sims(a, c->stream));
+    VSC_HIP(hipMemcpyAsync(out, c->sims.p, (size_t)lq * lr * 4, hipMemcpyDeviceToHost, c->stream));
+    VSC_HIP(hipStreamSynchronize(c->stream));
+    return VSC_OK;
+}
+
+}  // extern "C"

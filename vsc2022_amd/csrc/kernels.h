@@ -1,0 +1,63 @@
+// Argument blocks and launchers of the HIP kernels (shared by the kernel translation units and
+// the C-ABI layer in api.hip).
+#pragma once
+#include "vscmi_common.h"
+
+namespace vscmi {
+
+struct SimThreshArgs {
+    const float* Q; const float* R; int dpad; int nq; int i0; int nr; int tq; int tr;
+    const float* radius; int32_t* out_i; int32_t* out_j; float* out_s;
+    unsigned long long* counter; long long cap; int* overflow;
+};
+struct SimKnnArgs {
+    const float* Q; const float* R; int dpad; int nq; int nr; int tq; int tr; int nchunk; int k;
+    float* part_s; int32_t* part_j;
+};
+struct KnnMergeArgs {
+    const float* part_s; const int32_t* part_j; int nq; int nchunk; int k; float* out_s; int64_t* out_j; int l2;
+};
+struct ScoreMatArgs { const float* Q; const float* R; int dpad; int dim; int nq; int nr; int metric; float* S; };
+struct MatThreshArgs {
+    const float* S; int nq; int nr; int i0; const float* radius; int32_t* out_i; int32_t* out_j; float* out_s;
+    unsigned long long* counter; long long cap; int* overflow;
+};
+struct MatKnnArgs { const float* S; int nq; int nr; int k; float* part_s; int32_t* part_j; };
+struct SelectCtl {
+    unsigned long long n; unsigned long long n_tmp; float radius; int overflow; int active;
+    unsigned int prefix; unsigned int prefix_mask; unsigned long long rank; unsigned int hist[256];
+    unsigned long long n_rethreshold;
+};
+struct TnPairArgs {
+    const float* qfeat; const float* rfeat; const int64_t* q_off; const int64_t* r_off; int dpad;
+    const int32_t* pair_q; const int32_t* pair_r; const int32_t* work; int n_work; vsc_tn_params prm;
+    float bias; int max_lq; int lds_tile_floats; float* slab; int64_t slab_floats;
+    int32_t* out_nbox; int32_t* out_boxes; float* out_boxmax;
+    // forward_sim mode (sims_in != nullptr): precomputed matrices, pair p at sims_in + sims_off[p]
+    const float* sims_in; const int64_t* sims_off; const int32_t* sims_lq; const int32_t* sims_lr;
+};
+struct TnSimsArgs { const float* qfeat; const float* rfeat; int64_t qrow0, rrow0; int lq, lr, dpad; float bias; float* out; };
+
+int launch_sim_thresh(const SimThreshArgs&, hipStream_t);
+int launch_sim_knn(const SimKnnArgs&, hipStream_t);
+int launch_knn_merge(const KnnMergeArgs&, hipStream_t);
+int launch_score_matrix(const ScoreMatArgs&, hipStream_t);
+int launch_matrix_thresh(const MatThreshArgs&, hipStream_t);
+int launch_matrix_knn(const MatKnnArgs&, hipStream_t);
+int set_thresh_kernel_attrs();
+int enqueue_rethreshold(SelectCtl*, int32_t*, int32_t*, float*, int32_t*, int32_t*, float*, unsigned long long, hipStream_t);
+int sort_hits_topk(const int32_t*, const int32_t*, const float*, int64_t, int64_t, int64_t, DevBuf&, DevBuf&,
+                   DevBuf&, DevBuf&, DevBuf&, int32_t*, int32_t*, float*, int, int64_t*, hipStream_t);
+int sort_hits_rowcol(const int32_t*, const int32_t*, const float*, int64_t, DevBuf&, DevBuf&, DevBuf&, DevBuf&,
+                     DevBuf&, int32_t*, int32_t*, float*, int, hipStream_t);
+int pair_max_device(const int32_t*, const int32_t*, const float*, int64_t, const int32_t*, const int32_t*, int64_t,
+                    DevBuf&, DevBuf&, DevBuf&, DevBuf&, DevBuf&, DevBuf&, int32_t*, int32_t*, float*, int64_t*,
+                    int64_t, int64_t*, hipStream_t);
+int launch_pack_rows(const float*, int64_t, int, float*, int64_t, int, hipStream_t);
+int launch_row_normalize(const float*, int64_t, int, float*, hipStream_t);
+size_t tn_state_bytes_host(int, int, int);
+int launch_tn_pairs(const TnPairArgs&, size_t, hipStream_t);
+int launch_tn_sims(const TnSimsArgs&, hipStream_t);
+
+
+}  // namespace vscmi

@@ -1,0 +1,66 @@
+// HBM layout transforms (gfx950): HBM-bound, one read + one write per element.
+//   pack_rows      row-major fp32 [n][dim] -> padded, k-interleaved engine layout (see vscmi_common.h)
+//   row_normalize  sklearn.preprocessing.normalize (row L2), vsc/baseline/score_normalization.py:84
+#include "kernels.h"
+
+namespace vscmi {
+
+// one thread per (row, group of 8 k): reads 8 floats, writes two float4
+__global__ __launch_bounds__(256) void pack_rows_kernel(const float* __restrict__ src, int64_t n, int dim,
+                                                        float* __restrict__ dst, int64_t rows_pad,
+                                                        int dpad) {
+    const int groups = dpad / 8;
+    const int64_t x = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (x >= rows_pad * groups) return;
+    const int64_t row = x / groups;
+    const int g = (int)(x % groups);
+    float v[8];
+#pragma unroll
+    for (int w = 0; w < 8; ++w) {
+        const int k = g * 8 + w;
+        v[w] = (row < n && k < dim) ? src[row * dim + k] : 0.0f;
+    }
+    float4 even = make_float4(v[0], v[2], v[4], v[6]);
+    float4 odd = make_float4(v[1], v[3], v[5], v[7]);
+    float4* o = reinterpret_cast<float4*>(dst + row * dpad + g * 8);
+    o[0] = even;
+    o[1] = odd;
+}
+
+int launch_pack_rows(const float* src, int64_t n, int dim, float* dst, int64_t rows_pad, int dpad,
+                     hipStream_t stream) {
+    const int64_t total = rows_pad * (dpad / 8);
+    if (total <= 0) return VSC_OK;
+    hipLaunchKernelGGL(pack_rows_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, src,
+                       n, dim, dst, rows_pad, dpad);
+    VSC_HIP(hipGetLastError());
+    return VSC_OK;
+}
+
+// One wave per row.  The squared norm is the ascending-k fp32 fma chain (the oracle's order), so a
+// single lane walks the row for the norm; the division is done by all lanes.  Rows are short
+// (<= a few KB) and the kernel is bandwidth-trivial next to the search.
+__global__ __launch_bounds__(256) void row_normalize_kernel(const float* __restrict__ x, int64_t n,
+                                                            int dim, float* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= n) return;
+    const float* r = x + row * dim;
+    float acc = 0.0f;
+    if (lane == 0)
+        for (int k = 0; k < dim; ++k) acc = __fmaf_rn(r[k], r[k], acc);
+    acc = __shfl(acc, 0);
+    float nrm = __fsqrt_rn(acc);
+    if (nrm == 0.0f) nrm = 1.0f;
+    for (int k = lane; k < dim; k += 64) out[row * dim + k] = __fdiv_rn(r[k], nrm);
+}
+
+int launch_row_normalize(const float* x, int64_t n, int dim, float* out, hipStream_t stream) {
+    if (n <= 0) return VSC_OK;
+    hipLaunchKernelGGL(row_normalize_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, stream, x, n,
+                       dim, out);
+    VSC_HIP(hipGetLastError());
+    return VSC_OK;
+}
+
+}  // namespace vscmi

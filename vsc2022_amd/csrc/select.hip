@@ -1,0 +1,129 @@
+// Device-side re-thresholding of the kept hit list (gfx950).
+//
+// Restates faiss.contrib.exhaustive_search.apply_maxres as called from
+// range_search_max_results (reached at vsc/index.py:147-154): when more than max_results = 2K hits
+// are kept, the radius becomes the (K+1)-th best kept score and every kept hit is re-filtered with
+// a STRICT comparison.  Everything is stream-ordered and predicated on device memory, so the whole
+// batch schedule of a search is enqueued without a host round trip.
+//
+// HBM-bound: one radix-select = 4 passes over <= ~2K + batch scores (4 B each); one compaction
+// pass over 12 B/hit.  Negligible next to the similarity kernel; kept simple.
+#include "kernels.h"
+
+namespace vscmi {
+
+
+__global__ void select_begin_kernel(SelectCtl* c, unsigned long long max_results,
+                                    unsigned long long min_results) {
+    if (threadIdx.x < 256) c->hist[threadIdx.x] = 0;
+    if (threadIdx.x == 0) {
+        const bool act = c->n > max_results;
+        c->active = act ? 1 : 0;
+        c->prefix = 0;
+        c->prefix_mask = 0;
+        c->rank = min_results;  // 0-based descending rank of the (K+1)-th best
+        c->n_tmp = 0;
+        if (act) c->n_rethreshold += 1;
+    }
+}
+
+__global__ __launch_bounds__(256) void select_hist_kernel(SelectCtl* c, const float* s, int shift) {
+    if (!c->active) return;
+    __shared__ unsigned int lh[256];
+    lh[threadIdx.x] = 0;
+    __syncthreads();
+    const unsigned long long n = c->n;
+    const unsigned int prefix = c->prefix, pmask = c->prefix_mask;
+    for (unsigned long long x = (unsigned long long)blockIdx.x * 256 + threadIdx.x; x < n;
+         x += (unsigned long long)gridDim.x * 256) {
+        const unsigned int key = f2key(s[x]);
+        if ((key & pmask) == prefix) atomicAdd(&lh[(key >> shift) & 255u], 1u);
+    }
+    __syncthreads();
+    if (lh[threadIdx.x]) atomicAdd(&c->hist[threadIdx.x], lh[threadIdx.x]);
+}
+
+__global__ void select_pick_kernel(SelectCtl* c, int shift) {
+    if (!c->active) return;
+    __shared__ unsigned int h[256];
+    h[threadIdx.x] = c->hist[threadIdx.x];
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long rank = c->rank;
+        int d = 255;
+        for (; d > 0; --d) {
+            if (rank < h[d]) break;
+            rank -= h[d];
+        }
+        c->rank = rank;
+        c->prefix |= (unsigned int)d << shift;
+        c->prefix_mask |= 255u << shift;
+        if (shift == 0) c->radius = key2f(c->prefix);
+    }
+    __syncthreads();
+    c->hist[threadIdx.x] = 0;
+}
+
+// copy hits with score > radius from A to B
+__global__ __launch_bounds__(256) void select_compact_kernel(SelectCtl* c, const int32_t* ai,
+                                                             const int32_t* aj, const float* as,
+                                                             int32_t* bi, int32_t* bj, float* bs) {
+    if (!c->active) return;
+    const unsigned long long n = c->n;
+    const float radius = c->radius;
+    const int lane = threadIdx.x & 63;
+    const unsigned long long stride = (unsigned long long)gridDim.x * 256;
+    const unsigned long long n_round = (n + 255) / 256 * 256;
+    for (unsigned long long x = (unsigned long long)blockIdx.x * 256 + threadIdx.x; x < n_round;
+         x += stride) {
+        const bool in = x < n;
+        const float s = in ? as[x] : 0.0f;
+        const bool keep = in && (s > radius);
+        const unsigned long long m = __ballot(keep);
+        if (!m) continue;
+        unsigned long long base = 0;
+        if (lane == 0) base = atomicAdd(&c->n_tmp, (unsigned long long)__popcll(m));
+        base = __shfl(base, 0);
+        if (keep) {
+            const unsigned long long pos = base + __popcll(m & ((1ull << lane) - 1));
+            bi[pos] = ai[x];
+            bj[pos] = aj[x];
+            bs[pos] = s;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void select_copyback_kernel(SelectCtl* c, const int32_t* bi,
+                                                              const int32_t* bj, const float* bs,
+                                                              int32_t* ai, int32_t* aj, float* as) {
+    if (!c->active) return;
+    const unsigned long long n = c->n_tmp;
+    for (unsigned long long x = (unsigned long long)blockIdx.x * 256 + threadIdx.x; x < n;
+         x += (unsigned long long)gridDim.x * 256) {
+        ai[x] = bi[x];
+        aj[x] = bj[x];
+        as[x] = bs[x];
+    }
+}
+
+__global__ void select_end_kernel(SelectCtl* c) {
+    if (c->active) c->n = c->n_tmp;
+}
+
+// Enqueue one "if n > 2K: radius <- (K+1)-th best; keep score > radius" round.
+int enqueue_rethreshold(SelectCtl* ctl, int32_t* ai, int32_t* aj, float* as, int32_t* bi, int32_t* bj,
+                        float* bs, unsigned long long K, hipStream_t stream) {
+    constexpr int GRID = 1024;
+    hipLaunchKernelGGL(select_begin_kernel, dim3(1), dim3(256), 0, stream, ctl, 2 * K, K);
+    for (int shift = 24; shift >= 0; shift -= 8) {
+        hipLaunchKernelGGL(select_hist_kernel, dim3(GRID), dim3(256), 0, stream, ctl, as, shift);
+        hipLaunchKernelGGL(select_pick_kernel, dim3(1), dim3(256), 0, stream, ctl, shift);
+    }
+    hipLaunchKernelGGL(select_compact_kernel, dim3(GRID), dim3(256), 0, stream, ctl, ai, aj, as, bi, bj, bs);
+    hipLaunchKernelGGL(select_copyback_kernel, dim3(GRID), dim3(256), 0, stream, ctl, bi, bj, bs, ai, aj, as);
+    hipLaunchKernelGGL(select_end_kernel, dim3(1), dim3(1), 0, stream, ctl);
+    VSC_HIP(hipGetLastError());
+    return VSC_OK;
+}
+
+}  // namespace vscmi

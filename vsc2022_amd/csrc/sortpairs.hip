@@ -1,0 +1,201 @@
+// Final ordering of the kept hits and (query video, ref video) aggregation (gfx950).
+//
+//   sort_hits_topk : vsc/index.py:158-165 -- flatten in (row asc, ref asc) order, stable sort by
+//                    score descending, truncate to K.  Done as two stable LSD radix sorts:
+//                    by the 64-bit (row, ref) key, then by the 32-bit score key descending.
+//   pair_max       : vsc/index.py:121-140 + vsc/candidates.py:24-40 -- group hits by
+//                    (query video, ref video) in first-appearance order of the score-sorted list;
+//                    because the list is score-descending the first hit of a pair carries its max,
+//                    and first-appearance order IS the stable descending order of the pair scores.
+//
+// HBM-bound plumbing on <= 2K hits (12-16 B each); the device-wide radix sort is rocPRIM's
+// (AMD's native primitive library) -- it is not on the critical path.
+#include <cstring>
+
+#include <rocprim/rocprim.hpp>
+
+#include "kernels.h"
+
+namespace vscmi {
+
+__global__ __launch_bounds__(256) void pack_hits_kernel(const int32_t* i, const int32_t* j,
+                                                        const float* s, int64_t n, uint64_t* key64,
+                                                        uint32_t* key32) {
+    const int64_t x = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (x >= n) return;
+    key64[x] = ((uint64_t)(uint32_t)i[x] << 32) | (uint32_t)j[x];
+    key32[x] = f2key(s[x]);
+}
+
+__global__ __launch_bounds__(256) void unpack_hits_kernel(const uint64_t* key64, const uint32_t* key32,
+                                                          int64_t n, int32_t* i, int32_t* j, float* s,
+                                                          int negate) {
+    const int64_t x = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (x >= n) return;
+    i[x] = (int32_t)(key64[x] >> 32);
+    j[x] = (int32_t)(key64[x] & 0xffffffffu);
+    const float v = key2f(key32[x]);
+    s[x] = negate ? -v : v;
+}
+
+static inline unsigned grid_for(int64_t n) { return (unsigned)((n + 255) / 256); }
+
+static int bits_for(uint64_t maxval) {
+    int b = 1;
+    while (b < 64 && (maxval >> b)) ++b;
+    return b;
+}
+
+// Orders hits (device arrays, arbitrary order) by (score desc, i asc, j asc) and writes the first
+// min(n, K) to out_* (device).  `negate`: stored scores are negated distances (L2).
+int sort_hits_topk(const int32_t* hi, const int32_t* hj, const float* hs, int64_t n, int64_t K,
+                   int64_t max_i, DevBuf& w0, DevBuf& w1, DevBuf& w2, DevBuf& w3, DevBuf& tmp,
+                   int32_t* out_i, int32_t* out_j, float* out_s, int negate, int64_t* n_out,
+                   hipStream_t stream) {
+    const int64_t m = n < K ? n : K;
+    *n_out = m;
+    if (n <= 0) return VSC_OK;
+    VSC_TRY(w0.reserve(sizeof(uint64_t) * n));
+    VSC_TRY(w1.reserve(sizeof(uint64_t) * n));
+    VSC_TRY(w2.reserve(sizeof(uint32_t) * n));
+    VSC_TRY(w3.reserve(sizeof(uint32_t) * n));
+    uint64_t* k64a = w0.as<uint64_t>();
+    uint64_t* k64b = w1.as<uint64_t>();
+    uint32_t* k32a = w2.as<uint32_t>();
+    uint32_t* k32b = w3.as<uint32_t>();
+    hipLaunchKernelGGL(pack_hits_kernel, dim3(grid_for(n)), dim3(256), 0, stream, hi, hj, hs, n, k64a, k32a);
+    VSC_HIP(hipGetLastError());
+    const int end_bit = 32 + bits_for((uint64_t)(max_i > 0 ? max_i : 1));
+    size_t need1 = 0, need2 = 0;
+    VSC_HIP(rocprim::radix_sort_pairs(nullptr, need1, k64a, k64b, k32a, k32b, (size_t)n, 0, end_bit, stream));
+    VSC_HIP(rocprim::radix_sort_pairs_desc(nullptr, need2, k32b, k32a, k64b, k64a, (size_t)n, 0, 32, stream));
+    VSC_TRY(tmp.reserve(need1 > need2 ? need1 : need2));
+    size_t tb = tmp.bytes;
+    VSC_HIP(rocprim::radix_sort_pairs(tmp.p, tb, k64a, k64b, k32a, k32b, (size_t)n, 0, end_bit, stream));
+    tb = tmp.bytes;
+    VSC_HIP(rocprim::radix_sort_pairs_desc(tmp.p, tb, k32b, k32a, k64b, k64a, (size_t)n, 0, 32, stream));
+    hipLaunchKernelGGL(unpack_hits_kernel, dim3(grid_for(m)), dim3(256), 0, stream, k64a, k32a, m, out_i, out_j, out_s, negate);
+    VSC_HIP(hipGetLastError());
+    return VSC_OK;
+}
+
+// ----------------------------------------------------------------------------- pair max
+
+__global__ __launch_bounds__(256) void pair_key_kernel(const int32_t* hi, const int32_t* hj, int64_t n,
+                                                       const int32_t* row2q, const int32_t* row2r,
+                                                       uint64_t* key, uint32_t* rank) {
+    const int64_t x = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (x >= n) return;
+    key[x] = ((uint64_t)(uint32_t)row2q[hi[x]] << 32) | (uint32_t)row2r[hj[x]];
+    rank[x] = (uint32_t)x;
+}
+
+__global__ __launch_bounds__(256) void pair_heads_kernel(const uint64_t* key, const uint32_t* rank,
+                                                         int64_t n, uint32_t* head_rank,
+                                                         uint64_t* head_key, unsigned long long* count) {
+    const int64_t x = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const bool head = (x < n) && (x == 0 || key[x] != key[x - 1]);
+    const unsigned long long m = __ballot(head);
+    if (!m) return;
+    unsigned long long base = 0;
+    if (lane == 0) base = atomicAdd(count, (unsigned long long)__popcll(m));
+    base = __shfl(base, 0);
+    if (head) {
+        const unsigned long long pos = base + __popcll(m & ((1ull << lane) - 1));
+        head_rank[pos] = rank[x];  // stable sort => smallest rank of the run == first appearance
+        head_key[pos] = key[x];
+    }
+}
+
+__global__ __launch_bounds__(256) void pair_out_kernel(const uint32_t* head_rank, const uint64_t* head_key,
+                                                       const float* hs, int64_t np, int32_t* out_q,
+                                                       int32_t* out_r, float* out_s, int64_t* out_first) {
+    const int64_t x = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (x >= np) return;
+    out_q[x] = (int32_t)(head_key[x] >> 32);
+    out_r[x] = (int32_t)(head_key[x] & 0xffffffffu);
+    out_s[x] = hs[head_rank[x]];
+    if (out_first) out_first[x] = (int64_t)head_rank[x];
+}
+
+// All pointers device.  hits are in search order (score-descending).  Synchronises the stream once
+// (the pair count sizes the second sort).
+int pair_max_device(const int32_t* hi, const int32_t* hj, const float* hs, int64_t n,
+                    const int32_t* row2q, const int32_t* row2r, int64_t n_qvid_hint, DevBuf& w0,
+                    DevBuf& w1, DevBuf& w2, DevBuf& w3, DevBuf& tmp, DevBuf& cnt, int32_t* out_q,
+                    int32_t* out_r, float* out_s, int64_t* out_first, int64_t cap, int64_t* n_pairs,
+                    hipStream_t stream) {
+    (void)n_qvid_hint;
+    *n_pairs = 0;
+    if (n <= 0) return VSC_OK;
+    if (n > 0xffffffffLL) {
+        set_error("pair_max: more than 2^32 hits");
+        return VSC_ERR_INVALID;
+    }
+    VSC_TRY(w0.reserve(sizeof(uint64_t) * n));
+    VSC_TRY(w1.reserve(sizeof(uint64_t) * n));
+    VSC_TRY(w2.reserve(sizeof(uint32_t) * n));
+    VSC_TRY(w3.reserve(sizeof(uint32_t) * n));
+    VSC_TRY(cnt.reserve(sizeof(unsigned long long)));
+    uint64_t* ka = w0.as<uint64_t>();
+    uint64_t* kb = w1.as<uint64_t>();
+    uint32_t* ra = w2.as<uint32_t>();
+    uint32_t* rb = w3.as<uint32_t>();
+    hipLaunchKernelGGL(pair_key_kernel, dim3(grid_for(n)), dim3(256), 0, stream, hi, hj, n, row2q, row2r, ka, ra);
+    VSC_HIP(hipGetLastError());
+    size_t need = 0;
+    VSC_HIP(rocprim::radix_sort_pairs(nullptr, need, ka, kb, ra, rb, (size_t)n, 0, 64, stream));
+    VSC_TRY(tmp.reserve(need));
+    size_t tb = tmp.bytes;
+    VSC_HIP(rocprim::radix_sort_pairs(tmp.p, tb, ka, kb, ra, rb, (size_t)n, 0, 64, stream));
+    VSC_HIP(hipMemsetAsync(cnt.p, 0, sizeof(unsigned long long), stream));
+    // heads compacted into (ra, ka) -- both free again after the sort
+    hipLaunchKernelGGL(pair_heads_kernel, dim3(grid_for(n)), dim3(256), 0, stream, kb, rb, n, ra, ka,
+                       cnt.as<unsigned long long>());
+    VSC_HIP(hipGetLastError());
+    unsigned long long np = 0;
+    VSC_HIP(hipMemcpyAsync(&np, cnt.p, sizeof(np), hipMemcpyDeviceToHost, stream));
+    VSC_HIP(hipStreamSynchronize(stream));
+    *n_pairs = (int64_t)np;
+    if ((int64_t)np > cap) {
+        set_error("pair_max: output capacity %lld < %llu pairs", (long long)cap, np);
+        return VSC_ERR_CAPACITY;
+    }
+    size_t need2 = 0;
+    VSC_HIP(rocprim::radix_sort_pairs(nullptr, need2, ra, rb, ka, kb, (size_t)np, 0, 32, stream));
+    VSC_TRY(tmp.reserve(need2));
+    tb = tmp.bytes;
+    VSC_HIP(rocprim::radix_sort_pairs(tmp.p, tb, ra, rb, ka, kb, (size_t)np, 0, 32, stream));
+    hipLaunchKernelGGL(pair_out_kernel, dim3(grid_for((int64_t)np)), dim3(256), 0, stream, rb, kb, hs,
+                       (int64_t)np, out_q, out_r, out_s, out_first);
+    VSC_HIP(hipGetLastError());
+    return VSC_OK;
+}
+
+// faiss range_search order: rows ascending, refs ascending within a row (device in/out).
+int sort_hits_rowcol(const int32_t* hi, const int32_t* hj, const float* hs, int64_t n, DevBuf& w0,
+                     DevBuf& w1, DevBuf& w2, DevBuf& w3, DevBuf& tmp, int32_t* out_i, int32_t* out_j,
+                     float* out_s, int negate, hipStream_t stream) {
+    if (n <= 0) return VSC_OK;
+    VSC_TRY(w0.reserve(sizeof(uint64_t) * n));
+    VSC_TRY(w1.reserve(sizeof(uint64_t) * n));
+    VSC_TRY(w2.reserve(sizeof(uint32_t) * n));
+    VSC_TRY(w3.reserve(sizeof(uint32_t) * n));
+    uint64_t* k64a = w0.as<uint64_t>();
+    uint64_t* k64b = w1.as<uint64_t>();
+    uint32_t* k32a = w2.as<uint32_t>();
+    uint32_t* k32b = w3.as<uint32_t>();
+    hipLaunchKernelGGL(pack_hits_kernel, dim3(grid_for(n)), dim3(256), 0, stream, hi, hj, hs, n, k64a, k32a);
+    VSC_HIP(hipGetLastError());
+    size_t need = 0;
+    VSC_HIP(rocprim::radix_sort_pairs(nullptr, need, k64a, k64b, k32a, k32b, (size_t)n, 0, 64, stream));
+    VSC_TRY(tmp.reserve(need));
+    size_t tb = tmp.bytes;
+    VSC_HIP(rocprim::radix_sort_pairs(tmp.p, tb, k64a, k64b, k32a, k32b, (size_t)n, 0, 64, stream));
+    hipLaunchKernelGGL(unpack_hits_kernel, dim3(grid_for(n)), dim3(256), 0, stream, k64b, k32b, n, out_i, out_j, out_s, negate);
+    VSC_HIP(hipGetLastError());
+    return VSC_OK;
+}
+
+}  // namespace vscmi

@@ -1,0 +1,574 @@
+// Temporal-Network localisation, one candidate pair per (single-wavefront) workgroup (gfx950).
+//
+// Replaces, per candidate pair (paths relative to /root/reference):
+//   vsc/baseline/localization.py:36,52-54   sims = q.feature @ r.feature.T + bias
+//   vsc/baseline/localization.py:58         vcsl.vta `tn` (third-party alipay/VCSL; the source is
+//                                           absent from the reference checkout -> PARITY UNPINNED,
+//                                           algorithm per SURVEY.md Appendix B, kept bit-identical
+//                                           to oracle/vsc_oracle_tn.c)
+//   vsc/baseline/localization.py:88-91      MaxSim box score
+//
+// Structure: the frame x frame similarity tile is produced on the matrix cores
+// (v_mfma_f32_32x32x2_f32, operands straight from L2/HBM in the engine's k-interleaved layout,
+// ascending-k fp32 chain) and held in LDS; per-row top-k, the banded DAG (edges are recomputed
+// from per-row intermediate-range tables, never stored), the longest-path DP (one wavefront step
+// per predecessor set, first-max tie-breaks as networkx) and the box logic all run out of LDS.
+// Tiles that do not fit the LDS budget of a launch spill to a per-workgroup slab in HBM with
+// identical results.
+//
+// Bound: HBM/L2 (algorithmic bytes per pair = 4*dim*(Lq+Lr) read + 16 B/box written); in practice
+// latency/occupancy-bound -- see DESIGN.md.
+#include <cfloat>
+
+#include "kernels.h"
+
+namespace vscmi {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+
+struct TnState {
+    int lq, lr, top, ms, n_nodes, sink, sink_q, sink_r;
+    float min_sim;
+    const short* tidx;
+    const float* tsim;
+    const short* ilo;
+    const short* ihi;
+};
+
+__device__ __forceinline__ int tn_node_q(const TnState& g, int v) { return v == 0 ? -1 : (v - 1) / g.top; }
+__device__ __forceinline__ int tn_node_k(const TnState& g, int v) { return (v - 1) % g.top; }
+__device__ __forceinline__ int tn_node_r(const TnState& g, int v) { return v == 0 ? -1 : g.tidx[v - 1]; }
+
+__device__ __forceinline__ bool tn_edge_ok(const TnState& g, int qi, int a, int d, int b) {
+    const int qj = qi + d;
+    const int ra = g.tidx[qi * g.top + a], rb = g.tidx[qj * g.top + b];
+    const int rd = rb - ra;
+    if (!(rd > 0 && rd < g.ms)) return false;
+    const int lo = g.ilo[qi * g.ms + d], hi = g.ihi[qi * g.ms + d];
+    if (lo <= hi && !(hi < ra || lo > rb)) return false;
+    return g.tsim[qj * g.top + b] >= g.min_sim;
+}
+
+__device__ __forceinline__ bool tn_sink_ok(const TnState& g, int u) {
+    if (u == g.sink) return false;
+    const int qu = tn_node_q(g, u), ru = tn_node_r(g, u);
+    return g.sink_q > qu && g.sink_r > ru && g.sink_q - qu <= g.ms && g.sink_r - ru <= g.ms;
+}
+
+__device__ __forceinline__ int tn_edge_bit(const TnState& g, int qi, int a, int d, int b) {
+    return (((qi + d) * g.top + b) * g.ms + d) * g.top + a;
+}
+
+// (value, order) wave arg-max: larger value wins, ties go to the smaller order index
+__device__ __forceinline__ void wave_first_max(float& v, int& o) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        const float ov = __shfl_xor(v, off);
+        const int oo = __shfl_xor(o, off);
+        if (oo >= 0 && (o < 0 || ov > v || (ov == v && oo < o))) {
+            v = ov;
+            o = oo;
+        }
+    }
+}
+
+
+__global__ __launch_bounds__(64) void tn_pair_kernel(TnPairArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x;
+    if ((int)blockIdx.x >= a.n_work) return;
+    const int pidx = a.work[blockIdx.x];
+    int64_t qrow0 = 0, rrow0 = 0;
+    int lq, lr;
+    if (a.sims_in) {  // forward_sim mode: the caller supplies the similarity matrices
+        lq = a.sims_lq[pidx];
+        lr = a.sims_lr[pidx];
+    } else {
+        const int qv = a.pair_q[pidx], rv = a.pair_r[pidx];
+        qrow0 = a.q_off[qv];
+        rrow0 = a.r_off[rv];
+        lq = (int)(a.q_off[qv + 1] - qrow0);
+        lr = (int)(a.r_off[rv + 1] - rrow0);
+    }
+    const int ms = a.prm.tn_max_step > 1 ? a.prm.tn_max_step : 1;
+    const int top_cap = a.prm.tn_top_k;
+    const int top = top_cap < lr ? top_cap : lr;
+    int32_t* o_nbox = a.out_nbox + pidx;
+    int32_t* o_boxes = a.out_boxes + (int64_t)pidx * VSC_TN_MAX_BOXES * 4;
+    float* o_bmax = a.out_boxmax + (int64_t)pidx * VSC_TN_MAX_BOXES;
+    if (lq <= 0 || top <= 0) {
+        if (lane == 0) *o_nbox = 0;
+        return;
+    }
+    const int n_nodes = 1 + lq * top;
+
+    // ---- LDS carve (one dynamic array; offsets mirror tn_state_bytes) ----
+    size_t off = 0;
+    short* tidx = reinterpret_cast<short*>(smem + off);
+    off += (size_t)a.max_lq * top_cap * 2;
+    off = (off + 15) & ~(size_t)15;
+    float* tsim = reinterpret_cast<float*>(smem + off);
+    off += (size_t)a.max_lq * top_cap * 4;
+    short* ilo = reinterpret_cast<short*>(smem + off);
+    off += (size_t)a.max_lq * ms * 2;
+    short* ihi = reinterpret_cast<short*>(smem + off);
+    off += (size_t)a.max_lq * ms * 2;
+    off = (off + 15) & ~(size_t)15;
+    unsigned int* zero = reinterpret_cast<unsigned int*>(smem + off);
+    const int zero_words = (lq * top * ms * top + 31) / 32;
+    off += ((size_t)a.max_lq * top_cap * ms * top_cap + 31) / 32 * 4;
+    off = (off + 15) & ~(size_t)15;
+    float* dist = reinterpret_cast<float*>(smem + off);
+    off += (size_t)(1 + a.max_lq * top_cap) * 4;
+    short* par = reinterpret_cast<short*>(smem + off);
+    off += (size_t)(1 + a.max_lq * top_cap) * 2;
+    short* order = reinterpret_cast<short*>(smem + off);
+    off += (size_t)(1 + a.max_lq * top_cap) * 2;
+    short* indeg = reinterpret_cast<short*>(smem + off);
+    off += (size_t)(1 + a.max_lq * top_cap) * 2;
+    off = (off + 15) & ~(size_t)15;
+    int* boxes = reinterpret_cast<int*>(smem + off);
+    off += (size_t)VSC_TN_MAX_BOXES * 16;
+    off = (off + 63) & ~(size_t)63;
+    float* sims;
+    if (a.sims_in) sims = const_cast<float*>(a.sims_in) + a.sims_off[pidx];
+    else if ((int64_t)lq * lr <= a.lds_tile_floats) sims = reinterpret_cast<float*>(smem + off);
+    else sims = a.slab + (int64_t)blockIdx.x * a.slab_floats;
+
+    // ---- 1. similarity tile on the matrix cores: 32x32 output blocks, K ascending ----
+    if (!a.sims_in) {
+        const int hi = lane >> 5, l31 = lane & 31;
+        const int nkg = a.dpad / 8;
+        for (int qb = 0; qb < lq; qb += 32)
+            for (int rb = 0; rb < lr; rb += 32) {
+                // rows past the video end read the (padded) neighbour rows; their results are dropped
+                const float* ap = a.qfeat + (qrow0 + qb + l31) * a.dpad + hi * 4;
+                const float* bp = a.rfeat + (rrow0 + rb + l31) * a.dpad + hi * 4;
+                f32x16 acc;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+#pragma unroll 4
+                for (int g = 0; g < nkg; ++g) {
+                    const f32x4 av = *reinterpret_cast<const f32x4*>(ap + g * 8);
+                    const f32x4 bv = *reinterpret_cast<const f32x4*>(bp + g * 8);
+#pragma unroll
+                    for (int s = 0; s < 4; ++s)
+                        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s], bv[s], acc, 0, 0, 0);
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int q = qb + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                    const int rr = rb + l31;
+                    if (q < lq && rr < lr) sims[(int64_t)q * lr + rr] = acc[r] + a.bias;
+                }
+            }
+    }
+    for (int x = lane; x < zero_words; x += 64) zero[x] = 0;
+    __threadfence_block();
+    __syncthreads();
+
+    // ---- 2. per-row top-k by (sim desc, ref asc): `top` rounds of wave arg-best ----
+    for (int q = 0; q < lq; ++q) {
+        const float* row = sims + (int64_t)q * lr;
+        float prev_s = INFINITY;
+        int prev_r = -1;
+        for (int e = 0; e < top; ++e) {
+            float bs = 0.0f;
+            int br = -1;
+            for (int r = lane; r < lr; r += 64) {
+                const float s = row[r];
+                const bool after = (s < prev_s) || (s == prev_s && r > prev_r);
+                if (after && (br < 0 || s > bs)) {  // r ascends per lane: first max kept
+                    bs = s;
+                    br = r;
+                }
+            }
+            wave_first_max(bs, br);
+            if (lane == 0) {
+                tidx[q * top + e] = (short)br;
+                tsim[q * top + e] = bs;
+            }
+            prev_s = bs;
+            prev_r = br;
+        }
+    }
+    __syncthreads();
+
+    TnState g;
+    g.lq = lq; g.lr = lr; g.top = top; g.ms = ms; g.n_nodes = n_nodes; g.sink = n_nodes - 1;
+    g.sink_q = lq - 1;
+    g.sink_r = tidx[(lq - 1) * top + top - 1];
+    g.min_sim = a.prm.min_sim;
+    g.tidx = tidx; g.tsim = tsim; g.ilo = ilo; g.ihi = ihi;
+
+    // ---- 3. intermediate ranges: one lane per source row q_i, steps d are sequential ----
+    for (int qi = lane; qi < lq; qi += 64) {
+        int lo = 1, hi = 0;
+        for (int d = 1; d < ms; ++d) {
+            ilo[qi * ms + d] = (short)lo;
+            ihi[qi * ms + d] = (short)hi;
+            if (qi + d >= lq) continue;
+            int nlo = lo, nhi = hi;
+            for (int b = 0; b < top; ++b) {
+                bool any = false;
+                for (int aa = 0; aa < top && !any; ++aa) any = tn_edge_ok(g, qi, aa, d, b);
+                if (any) {
+                    const int rb = tidx[(qi + d) * top + b];
+                    if (nlo > nhi) nlo = nhi = rb;
+                    else {
+                        nlo = rb < nlo ? rb : nlo;
+                        nhi = rb > nhi ? rb : nhi;
+                    }
+                }
+            }
+            lo = nlo;
+            hi = nhi;
+        }
+    }
+    __syncthreads();
+
+    // ---- 4. longest-path extractions ----
+    const int P = (ms - 1) * top;  // regular predecessor slots of a node, insertion order
+    int nbox = 0;
+    bool have_order = false;
+    for (int it = 0; it <= a.prm.max_path; ++it) {
+        // DP by query row (a valid topological order; dist does not depend on which one)
+        if (lane == 0) {
+            dist[0] = 0.0f;
+            par[0] = 0;
+        }
+        __syncthreads();
+        for (int qj = 0; qj < lq; ++qj) {
+            for (int b = 0; b < top; ++b) {
+                const int v = 1 + qj * top + b;
+                const bool is_sink = (v == g.sink);
+                float best = 0.0f;
+                int arg = -1;  // order slot of the best predecessor
+                for (int o0 = 0; o0 < P; o0 += 64) {
+                    const int o = o0 + lane;
+                    float c = 0.0f;
+                    int oo = -1;
+                    if (o < P) {
+                        const int d = ms - 1 - o / top, aa = o % top;
+                        const int qi = qj - d;
+                        if (qi >= 0 && tn_edge_ok(g, qi, aa, d, b)) {
+                            const int bit = tn_edge_bit(g, qi, aa, d, b);
+                            const bool z = (zero[bit >> 5] >> (bit & 31)) & 1u;
+                            const float w = (z || is_sink) ? 0.0f : tsim[qj * top + b];
+                            c = dist[1 + qi * top + aa] + w;
+                            oo = o;
+                        }
+                    }
+                    wave_first_max(c, oo);
+                    if (oo >= 0 && (arg < 0 || c > best)) {
+                        best = c;
+                        arg = oo;
+                    }
+                }
+                int arg_node = -1;
+                if (arg >= 0) arg_node = 1 + (qj - (ms - 1 - arg / top)) * top + arg % top;
+                if (is_sink) {
+                    // sink-rule predecessors that are not regular ones, node-id order, weight 0
+                    for (int u0 = 0; u0 < n_nodes - 1; u0 += 64) {
+                        const int u = u0 + lane;
+                        float c = 0.0f;
+                        int oo = -1;
+                        if (u < n_nodes - 1 && tn_sink_ok(g, u)) {
+                            bool regular = false;
+                            if (u != 0) {
+                                const int qi = tn_node_q(g, u), aa = tn_node_k(g, u);
+                                const int d = qj - qi;
+                                if (d >= 1 && d < ms) regular = tn_edge_ok(g, qi, aa, d, b);
+                            }
+                            if (!regular) {
+                                c = dist[u] + 0.0f;
+                                oo = u;
+                            }
+                        }
+                        wave_first_max(c, oo);
+                        if (oo >= 0 && (arg_node < 0 || c > best)) {
+                            best = c;
+                            arg_node = oo;
+                        }
+                    }
+                }
+                if (lane == 0) {
+                    if (arg_node < 0 || !(best >= 0.0f)) {
+                        dist[v] = 0.0f;
+                        par[v] = (short)v;
+                    } else {
+                        dist[v] = best;
+                        par[v] = (short)arg_node;
+                    }
+                }
+            }
+            __syncthreads();
+        }
+
+        // end node: first node in topological order with maximal dist
+        float mx = -FLT_MAX;
+        int mxn = -1;
+        for (int v = lane; v < n_nodes; v += 64) {
+            const float dv = dist[v];
+            if (mxn < 0 || dv > mx) {
+                mx = dv;
+                mxn = v;
+            }
+        }
+        wave_first_max(mx, mxn);  // provisional: smallest node id among the maxima
+        int ties = 0;
+        for (int v = lane; v < n_nodes; v += 64) ties += (dist[v] == mx) ? 1 : 0;
+#pragma unroll
+        for (int off2 = 32; off2 >= 1; off2 >>= 1) ties += __shfl_xor(ties, off2);
+        int vend = mxn;
+        if (!(mx > 0.0f)) {
+            vend = 0;  // all-zero: the source is first in every topological order
+        } else if (ties > 1) {
+            if (!have_order) {
+                // Kahn generations exactly as networkx.topological_generations (lazy: only when a
+                // positive maximum is tied).  in-degrees in parallel, queue by one lane.
+                for (int v = lane; v < n_nodes; v += 64) {
+                    int deg = 0;
+                    if (v != 0) {
+                        const int qj = tn_node_q(g, v), b = tn_node_k(g, v);
+                        for (int d = 1; d < ms; ++d) {
+                            const int qi = qj - d;
+                            if (qi < 0) break;
+                            for (int aa = 0; aa < top; ++aa) deg += tn_edge_ok(g, qi, aa, d, b) ? 1 : 0;
+                        }
+                        if (v == g.sink) {
+                            for (int u = 0; u < n_nodes - 1; ++u) {
+                                if (!tn_sink_ok(g, u)) continue;
+                                bool regular = false;
+                                if (u != 0) {
+                                    const int qi = tn_node_q(g, u), aa = tn_node_k(g, u);
+                                    const int d = qj - qi;
+                                    if (d >= 1 && d < ms) regular = tn_edge_ok(g, qi, aa, d, b);
+                                }
+                                deg += regular ? 0 : 1;
+                            }
+                        }
+                    }
+                    indeg[v] = (short)deg;
+                }
+                __syncthreads();
+                if (lane == 0) {
+                    int head = 0, tail = 0;
+                    for (int v = 0; v < n_nodes; ++v)
+                        if (indeg[v] == 0) order[tail++] = (short)v;
+                    while (head < tail) {
+                        const int u = order[head++];
+                        bool to_sink_regular = false;
+                        if (u != 0) {
+                            const int qi = tn_node_q(g, u), aa = tn_node_k(g, u);
+                            for (int d = 1; d < ms && qi + d < lq; ++d)
+                                for (int b = 0; b < top; ++b)
+                                    if (tn_edge_ok(g, qi, aa, d, b)) {
+                                        const int v = 1 + (qi + d) * top + b;
+                                        if (v == g.sink) to_sink_regular = true;
+                                        if (--indeg[v] == 0) order[tail++] = (short)v;
+                                    }
+                        }
+                        if (!to_sink_regular && tn_sink_ok(g, u))
+                            if (--indeg[g.sink] == 0) order[tail++] = (short)g.sink;
+                    }
+                }
+                have_order = true;
+                __syncthreads();
+            }
+            // first tied node in topological order
+            int bestpos = 0x7fffffff;
+            for (int t = lane; t < n_nodes; t += 64)
+                if (dist[order[t]] == mx && t < bestpos) bestpos = t;
+#pragma unroll
+            for (int off2 = 32; off2 >= 1; off2 >>= 1) {
+                const int o2 = __shfl_xor(bestpos, off2);
+                bestpos = o2 < bestpos ? o2 : bestpos;
+            }
+            vend = order[bestpos];
+        }
+
+        // back-track, zero the path's edge weights, score and box (lane 0; paths are short)
+        int accepted = 0, stop = 0;
+        int bq0 = 0, br0 = 0, bq1 = 0, br1 = 0;
+        if (lane == 0) {
+            // pass 1: zero regular edges (walking end -> start) and count interior nodes
+            int cnt = 0;
+            for (int v = vend;;) {
+                const int u = par[v];
+                if (v != 0 && v != g.sink) ++cnt;
+                if (u == v) break;
+                if (u != 0) {
+                    const int qi = tn_node_q(g, u), aa = tn_node_k(g, u);
+                    const int qj = tn_node_q(g, v), b = tn_node_k(g, v);
+                    const int d = qj - qi;
+                    if (d >= 1 && d < ms && tn_edge_ok(g, qi, aa, d, b)) {
+                        const int bit = tn_edge_bit(g, qi, aa, d, b);
+                        zero[bit >> 5] |= 1u << (bit & 31);
+                    }
+                }
+                v = u;
+            }
+            if (cnt == 0) {
+                stop = 1;
+            } else {
+                // pass 2: the score is summed in FORWARD path order (start -> end).  Reverse the
+                // parent chain in place through `order`-independent scratch: reuse indeg[] as stack.
+                int plen = 0;
+                for (int v = vend;;) {
+                    indeg[plen++] = (short)v;
+                    if (par[v] == v) break;
+                    v = par[v];
+                }
+                float score = 0.0f;
+                int qmin = 0, qmax = 0, rmin = 0, rmax = 0, c2 = 0;
+                for (int x = plen - 1; x >= 0; --x) {
+                    const int v = indeg[x];
+                    if (v == 0 || v == g.sink) continue;
+                    const int q = tn_node_q(g, v), r = tn_node_r(g, v);
+                    score += tsim[v - 1];
+                    if (c2 == 0) {
+                        qmin = qmax = q;
+                        rmin = rmax = r;
+                    } else {
+                        qmin = q < qmin ? q : qmin;
+                        qmax = q > qmax ? q : qmax;
+                        rmin = r < rmin ? r : rmin;
+                        rmax = r > rmax ? r : rmax;
+                    }
+                    ++c2;
+                }
+                if (!(score > 0.0f)) qmin = qmax = rmin = rmax = 0;
+                const int dq = qmax - qmin, dr = rmax - rmin;
+                const float ave = __fdiv_rn((float)(dr + dq), 2.0f);
+                bool ok = (ave != 0.0f) && (__fdiv_rn(score, ave) > a.prm.min_sim) &&
+                          ((dr < dq ? dr : dq) > a.prm.min_length);
+                if (ok && nbox > 0) {
+                    float mxi = -INFINITY;
+                    for (int kx = 0; kx < nbox; ++kx) {
+                        const int* o = boxes + 4 * kx;
+                        const float lt0 = (float)(qmin > o[0] ? qmin : o[0]);
+                        const float lt1 = (float)(rmin > o[1] ? rmin : o[1]);
+                        const float rb0 = (float)(qmax < o[2] ? qmax : o[2]);
+                        const float rb1 = (float)(rmax < o[3] ? rmax : o[3]);
+                        const float w = rb0 - lt0 > 0.0f ? rb0 - lt0 : 0.0f;
+                        const float h = rb1 - lt1 > 0.0f ? rb1 - lt1 : 0.0f;
+                        const float inter = __fmul_rn(w, h);
+                        const float aa2 = __fmul_rn((float)dq, (float)dr);
+                        const float ab = __fmul_rn((float)(o[2] - o[0]), (float)(o[3] - o[1]));
+                        const float iou = __fdiv_rn(inter, __fsub_rn(__fadd_rn(aa2, ab), inter));
+                        mxi = iou > mxi ? iou : mxi;
+                    }
+                    ok = mxi < a.prm.max_iou;
+                }
+                if (ok && nbox < VSC_TN_MAX_BOXES) {
+                    boxes[4 * nbox + 0] = qmin;
+                    boxes[4 * nbox + 1] = rmin;
+                    boxes[4 * nbox + 2] = qmax;
+                    boxes[4 * nbox + 3] = rmax;
+                    accepted = 1;
+                    bq0 = qmin; br0 = rmin; bq1 = qmax; br1 = rmax;
+                }
+            }
+            // indeg[] was used as scratch: a later lazy Kahn run recomputes it (have_order guards
+            // only `order`, which is untouched here)
+        }
+        stop = __shfl(stop, 0);
+        accepted = __shfl(accepted, 0);
+        __syncthreads();
+        if (stop) break;
+        if (accepted) {
+            bq0 = __shfl(bq0, 0); br0 = __shfl(br0, 0); bq1 = __shfl(bq1, 0); br1 = __shfl(br1, 0);
+            // MaxSim box score: max of sims[q_lo:q_hi, r_lo:r_hi] (half-open, localization.py:91) - bias
+            float m = -INFINITY;
+            const int w = br1 - br0, h = bq1 - bq0;
+            for (int x = lane; x < w * h; x += 64) {
+                const float s = sims[(int64_t)(bq0 + x / w) * lr + br0 + x % w];
+                m = s > m ? s : m;
+            }
+#pragma unroll
+            for (int off2 = 32; off2 >= 1; off2 >>= 1) {
+                const float o2 = __shfl_xor(m, off2);
+                m = o2 > m ? o2 : m;
+            }
+            if (lane == 0) {
+                o_boxes[4 * nbox + 0] = bq0;
+                o_boxes[4 * nbox + 1] = br0;
+                o_boxes[4 * nbox + 2] = bq1;
+                o_boxes[4 * nbox + 3] = br1;
+                o_bmax[nbox] = __fsub_rn(m, a.bias);
+            }
+            ++nbox;
+        }
+    }
+    if (lane == 0) *o_nbox = nbox;
+}
+
+size_t tn_state_bytes_host(int max_lq, int top_cap, int ms) {
+    const size_t n_nodes = 1 + (size_t)max_lq * top_cap;
+    size_t b = 0;
+    b += (size_t)max_lq * top_cap * 2;
+    b = (b + 15) & ~(size_t)15;
+    b += (size_t)max_lq * top_cap * 4;
+    b += (size_t)max_lq * ms * 2 * 2;
+    b = (b + 15) & ~(size_t)15;
+    b += ((size_t)max_lq * top_cap * ms * top_cap + 31) / 32 * 4;
+    b = (b + 15) & ~(size_t)15;
+    b += n_nodes * 4;
+    b += n_nodes * 2 * 3;
+    b = (b + 15) & ~(size_t)15;
+    b += (size_t)VSC_TN_MAX_BOXES * 16;
+    b = (b + 63) & ~(size_t)63;
+    return b;
+}
+
+int launch_tn_pairs(const TnPairArgs& a, size_t lds_bytes, hipStream_t stream) {
+    if (a.n_work <= 0) return VSC_OK;
+    static bool attr_set = false;
+    if (!attr_set) {
+        VSC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(tn_pair_kernel),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(tn_pair_kernel, dim3((unsigned)a.n_work), dim3(64), lds_bytes, stream, a);
+    VSC_HIP(hipGetLastError());
+    return VSC_OK;
+}
+
+// LocalizationWithMetadata.similarity (vsc/baseline/localization.py:33-36,48-54) for one pair:
+// out[lq][lr] = q.feature @ r.feature.T + bias, one 32x32 block per wavefront.
+
+__global__ __launch_bounds__(64) void tn_sims_kernel(TnSimsArgs a) {
+    const int lane = threadIdx.x, hi = lane >> 5, l31 = lane & 31;
+    const int qb = blockIdx.y * 32, rb = blockIdx.x * 32;
+    const float* ap = a.qfeat + (a.qrow0 + qb + l31) * a.dpad + hi * 4;
+    const float* bp = a.rfeat + (a.rrow0 + rb + l31) * a.dpad + hi * 4;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+    const int nkg = a.dpad / 8;
+#pragma unroll 4
+    for (int g = 0; g < nkg; ++g) {
+        const f32x4 av = *reinterpret_cast<const f32x4*>(ap + g * 8);
+        const f32x4 bv = *reinterpret_cast<const f32x4*>(bp + g * 8);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s], bv[s], acc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int q = qb + (r & 3) + 8 * (r >> 2) + 4 * hi;
+        const int rr = rb + l31;
+        if (q < a.lq && rr < a.lr) a.out[(int64_t)q * a.lr + rr] = acc[r] + a.bias;
+    }
+}
+
+int launch_tn_sims(const TnSimsArgs& a, hipStream_t stream) {
+    if (a.lq <= 0 || a.lr <= 0) return VSC_OK;
+    hipLaunchKernelGGL(tn_sims_kernel, dim3((a.lr + 31) / 32, (a.lq + 31) / 32), dim3(64), 0, stream, a);
+    VSC_HIP(hipGetLastError());
+    return VSC_OK;
+}
+
+}  // namespace vscmi

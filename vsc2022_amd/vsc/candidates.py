@@ -1,0 +1,119 @@
+"""Candidate generation: host-side mirror of the reference's `vsc/candidates.py`
+(same names and semantics; paths relative to /root/reference).
+
+`CandidateGeneration.query` with the stock `MaxScoreAggregation` never builds per-hit Python
+objects: the score-sorted hit list stays in HBM and libvscmi's vsc_pair_max produces the
+(query video, ref video, max score) table directly.  Any other `ScoreAggregation` subclass goes
+through the generic `VideoIndex.search` -> `PairMatches` route, unchanged.
+"""
+import ctypes
+from abc import ABC, abstractmethod
+from collections.abc import Sequence
+from typing import List
+
+import numpy as np
+
+from vsc2022_amd import _lib
+from vsc2022_amd.vsc.index import PairMatches, VideoFeature, VideoIndex
+from vsc2022_amd.vsc.metrics import CandidatePair
+
+
+class ScoreAggregation(ABC):
+    """vsc/candidates.py:14-21"""
+
+    @abstractmethod
+    def aggregate(self, match: PairMatches) -> float:
+        pass
+
+    def score(self, match: PairMatches) -> CandidatePair:
+        score = self.aggregate(match)
+        return CandidatePair(query_id=match.query_id, ref_id=match.ref_id, score=score)
+
+
+class MaxScoreAggregation(ScoreAggregation):
+    """vsc/candidates.py:24-26"""
+
+    def aggregate(self, match: PairMatches) -> float:
+        scores = getattr(match.matches, "scores", None)
+        if scores is None:
+            scores = [m.score for m in match.matches]
+        return np.max(scores)
+
+
+class CandidateList(Sequence):
+    """Score-descending list of CandidatePair backed by three arrays.
+
+    Behaves like the `List[CandidatePair]` the reference returns (len, indexing, slicing,
+    iteration, ==, +); CandidatePair objects are created only for the elements touched.
+    """
+
+    def __init__(self, q_ord, r_ord, scores, q_ids, r_ids):
+        self.q_ord, self.r_ord, self.scores = q_ord, r_ord, scores
+        self._q_ids, self._r_ids = q_ids, r_ids
+
+    def __len__(self):
+        return len(self.scores)
+
+    def __getitem__(self, k):
+        if isinstance(k, slice):
+            return CandidateList(self.q_ord[k], self.r_ord[k], self.scores[k], self._q_ids, self._r_ids)
+        return CandidatePair(
+            query_id=self._q_ids[self.q_ord[k]], ref_id=self._r_ids[self.r_ord[k]], score=self.scores[k]
+        )
+
+    def __eq__(self, other):
+        if isinstance(other, (list, tuple, Sequence)):
+            return len(self) == len(other) and all(a == b for a, b in zip(self, other))
+        return NotImplemented
+
+    def __add__(self, other):
+        return list(self) + list(other)
+
+    def __repr__(self):
+        head = ", ".join(repr(c) for c in self[:3])
+        return f"CandidateList(n={len(self)}, [{head}{', ...' if len(self) > 3 else ''}])"
+
+    def columns(self):
+        """(query ids, ref ids, scores) without materialising CandidatePair objects."""
+        return ([self._q_ids[q] for q in self.q_ord], [self._r_ids[r] for r in self.r_ord], self.scores)
+
+
+class CandidateGeneration:
+    """vsc/candidates.py:29-40"""
+
+    def __init__(self, references: List[VideoFeature], aggregation: ScoreAggregation):
+        self.aggregation = aggregation
+        dim = references[0].dimensions()
+        self.index = VideoIndex(dim)
+        self.index.add(references)
+
+    def query(self, queries: List[VideoFeature], global_k: int) -> List[CandidatePair]:
+        if type(self.aggregation) is MaxScoreAggregation and global_k >= 0:
+            return self._query_max(queries, global_k)
+        matches = self.index.search(queries, global_k=global_k)
+        candidates = [self.aggregation.score(match) for match in matches]
+        candidates = sorted(candidates, key=lambda match: match.score, reverse=True)
+        return candidates
+
+    def _query_max(self, queries: List[VideoFeature], global_k: int) -> CandidateList:
+        hits = self.index.search_hits(queries, global_k)
+        n = len(hits)
+        q_ids, r_ids = hits.q_layout.video_ids, self.index._video_ids
+        if n == 0:
+            e = np.zeros(0, dtype=np.int32)
+            return CandidateList(e, e, np.zeros(0, dtype=np.float32), q_ids, r_ids)
+        row2q = np.ascontiguousarray(hits.q_layout.row2vid, dtype=np.int32)
+        row2r = np.ascontiguousarray(self.index._row2vid, dtype=np.int32)
+        oq = np.empty(n, dtype=np.int32)
+        orr = np.empty(n, dtype=np.int32)
+        os_ = np.empty(n, dtype=np.float32)
+        first = np.empty(n, dtype=np.int64)
+        n_pairs = ctypes.c_int64(0)
+        hi, hj, hs = (np.ascontiguousarray(a) for a in (hits.i, hits.j, hits.s))
+        _lib.check(_lib.lib().vsc_pair_max(
+            hi.ctypes.data, hj.ctypes.data, hs.ctypes.data, n, _lib.MEM_HOST,
+            row2q.ctypes.data, len(row2q), row2r.ctypes.data, len(row2r), _lib.MEM_HOST,
+            oq.ctypes.data, orr.ctypes.data, os_.ctypes.data, first.ctypes.data, n, _lib.MEM_HOST,
+            ctypes.byref(n_pairs), self.index.index.device))
+        m = n_pairs.value
+        return CandidateList(oq[:m], orr[:m], os_[:m], q_ids, r_ids)
