@@ -332,33 +332,40 @@ int vsc_index_global_topk(vsc_index_t* idx, const float* q, int64_t nq, int q_me
     VSC_HIP(hipSetDevice(idx->device));
     float* qp = nullptr;
     VSC_TRY(pack_queries(idx, q, nq, q_mem, &qp));
+    const int64_t cap_max = nq * idx->ntotal + 1024;  // the whole score matrix always fits
     int64_t cap = idx->hit_cap_user;
     if (cap <= 0) cap = std::max<int64_t>(32 * idx->ntotal, 2 * K) + 2 * K + 1024;
-    cap = std::min<int64_t>(cap, nq * idx->ntotal + 1024);
-    VSC_TRY(ensure_hit_buffers(idx, cap));
-    // initial radius -1e10 (IP) / +1e10 (L2) -> -1e10 in score space either way (vsc/index.py:146)
-    VSC_TRY(init_ctl(idx, -1e10f));
-    SelectCtl* ctl = idx->ws.ctl.as<SelectCtl>();
-    // exponential_query_iterator: 32, 64, ... doubling while bs < 20000
-    int64_t bs = 32, i0 = 0;
-    while (i0 < nq) {
-        const int64_t i1 = std::min(nq, i0 + bs);
-        VSC_TRY(enqueue_batch(idx, qp, i0, i1, cap));
-        VSC_TRY(enqueue_rethreshold(ctl, idx->ws.hA[0].as<int32_t>(), idx->ws.hA[1].as<int32_t>(),
-                                    idx->ws.hA[2].as<float>(), idx->ws.hB[0].as<int32_t>(),
-                                    idx->ws.hB[1].as<int32_t>(), idx->ws.hB[2].as<float>(),
-                                    (unsigned long long)K, idx->stream));
-        if (bs < 20000) bs *= 2;
-        i0 = i1;
-    }
+    cap = std::min<int64_t>(cap, cap_max);
     SelectCtl h;
-    VSC_HIP(hipMemcpyAsync(&h, ctl, sizeof(h), hipMemcpyDeviceToHost, idx->stream));
-    VSC_HIP(hipStreamSynchronize(idx->stream));
-    VSC_TRY(prof_collect(idx));
-    if (h.overflow) {
-        set_error("global_topk: kept-hit buffer (%lld entries) overflowed; raise it with "
-                  "vsc_index_set_hit_capacity", (long long)cap);
-        return VSC_ERR_OVERFLOW;
+    for (;;) {
+        VSC_TRY(ensure_hit_buffers(idx, cap));
+        // initial radius -1e10 (IP) / +1e10 (L2) -> -1e10 in score space either way (vsc/index.py:146)
+        VSC_TRY(init_ctl(idx, -1e10f));
+        SelectCtl* ctl = idx->ws.ctl.as<SelectCtl>();
+        // exponential_query_iterator: 32, 64, ... doubling while bs < 20000
+        int64_t bs = 32, i0 = 0;
+        while (i0 < nq) {
+            const int64_t i1 = std::min(nq, i0 + bs);
+            VSC_TRY(enqueue_batch(idx, qp, i0, i1, cap));
+            VSC_TRY(enqueue_rethreshold(ctl, idx->ws.hA[0].as<int32_t>(), idx->ws.hA[1].as<int32_t>(),
+                                        idx->ws.hA[2].as<float>(), idx->ws.hB[0].as<int32_t>(),
+                                        idx->ws.hB[1].as<int32_t>(), idx->ws.hB[2].as<float>(),
+                                        (unsigned long long)K, idx->stream));
+            if (bs < 20000) bs *= 2;
+            i0 = i1;
+        }
+        VSC_HIP(hipMemcpyAsync(&h, ctl, sizeof(h), hipMemcpyDeviceToHost, idx->stream));
+        VSC_HIP(hipStreamSynchronize(idx->stream));
+        VSC_TRY(prof_collect(idx));
+        if (!h.overflow) break;
+        // A batch emitted more hits than the buffer holds (heavy score ties keep the radius low).
+        // The schedule is deterministic, so simply rerun it with a larger buffer.
+        if (idx->hit_cap_user > 0 || cap >= cap_max) {
+            set_error("global_topk: kept-hit buffer (%lld entries) overflowed; raise it with "
+                      "vsc_index_set_hit_capacity", (long long)cap);
+            return VSC_ERR_OVERFLOW;
+        }
+        cap = std::min<int64_t>(cap * 4, cap_max);
     }
     if (final_radius) *final_radius = ip ? h.radius : -h.radius;
     const int64_t n = (int64_t)h.n;

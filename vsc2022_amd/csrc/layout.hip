@@ -50,9 +50,9 @@ __global__ __launch_bounds__(256) void row_normalize_kernel(const float* __restr
     if (lane == 0)
         for (int k = 0; k < dim; ++k) acc = __fmaf_rn(r[k], r[k], acc);
     acc = __shfl(acc, 0);
-    float nrm = __fsqrt_rn(acc);
+    float nrm = sqrtf(acc);  // correctly rounded (__fsqrt_rn maps to the approximate native sqrt)
     if (nrm == 0.0f) nrm = 1.0f;
-    for (int k = lane; k < dim; k += 64) out[row * dim + k] = __fdiv_rn(r[k], nrm);
+    for (int k = lane; k < dim; k += 64) out[row * dim + k] = r[k] / nrm;
 }
 
 int launch_row_normalize(const float* x, int64_t n, int dim, float* out, hipStream_t stream) {

@@ -425,8 +425,9 @@ int launch_sim_knn(const SimKnnArgs& a, hipStream_t stream) {
     const size_t lds = knn_lds_bytes(a.k);
     static bool attr_set = false;
     if (!attr_set) {
+        // the kernel also owns a few hundred bytes of static LDS (__syncthreads_or)
         VSC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(sim_knn_kernel),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024));
         attr_set = true;
     }
     hipLaunchKernelGGL(sim_knn_kernel, dim3((unsigned)grid), dim3(256), lds, stream, a);

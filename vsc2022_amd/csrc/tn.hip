@@ -529,7 +529,7 @@ int launch_tn_pairs(const TnPairArgs& a, size_t lds_bytes, hipStream_t stream) {
     static bool attr_set = false;
     if (!attr_set) {
         VSC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(tn_pair_kernel),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024));
         attr_set = true;
     }
     hipLaunchKernelGGL(tn_pair_kernel, dim3((unsigned)a.n_work), dim3(64), lds_bytes, stream, a);
