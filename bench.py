@@ -1,0 +1,224 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the MI355X matching engine.
+
+metric   : query-videos localized/sec @ 512-d SSCD descriptors (BASELINE.json)
+workload : BASELINE.json configs[1] shape -- per GPU 200k query frames (8000 videos x 25) against
+           2M reference frames (40000 videos x 50), 512-d fp32, L2-normalised, 20% planted copies,
+           1% static videos; one step = the whole hot path on that batch: global-threshold search
+           (K = 1200/video) -> (query, ref) max aggregation -> top 25/video candidates ->
+           Temporal-Network localisation of the top 5/video pairs.
+           All inputs are resident in HBM before the timed region (synthetic, generated on device).
+multi-GPU: one process per GPU (torchrun), queries sharded (weak scaling: every rank brings its own
+           8000 query videos), references replicated, the two global cuts resolved over RCCL
+           (vsc2022_amd/dist.py).
+
+Prints ONE JSON line on rank 0 (see the driver contract in the task statement); adds
+"roofline" (the dominant kernel, measured live with HIP events on the engine's stream) and, at
+N=1, "cpu_baseline" (the C oracle on the host cores, bounded sample).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FP32_MFMA_PEAK_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md: dense fp32 matrix rate
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--query-videos", type=int, default=8000, help="query videos per GPU")
+    ap.add_argument("--query-frames", type=int, default=25)
+    ap.add_argument("--ref-videos", type=int, default=40000)
+    ap.add_argument("--ref-frames", type=int, default=50)
+    ap.add_argument("--dim", type=int, default=512)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--seed", type=int, default=1)
+    return ap.parse_args()
+
+
+def synth_on_device(torch, dev, seed, n_vid, frames, dim, static_frac=0.01):
+    g = torch.Generator(device=dev)
+    g.manual_seed(seed)
+    x = torch.randn((n_vid * frames, dim), generator=g, device=dev, dtype=torch.float32)
+    x /= x.norm(dim=1, keepdim=True)
+    n_static = int(round(static_frac * n_vid))
+    if n_static:
+        vids = torch.randperm(n_vid, generator=g, device=dev)[:n_static]
+        xv = x.view(n_vid, frames, dim)
+        xv[vids] = xv[vids, :1].expand(-1, frames, -1).clone()
+    return x
+
+
+def plant_copies(torch, dev, seed, q, n_qvid, qf, r, n_rvid, rf, frac=0.2, noise=0.05):
+    """For `frac` of the query videos overwrite a run of frames with a noised reference segment."""
+    g = torch.Generator(device="cpu")
+    g.manual_seed(seed)
+    n_planted = int(round(frac * n_qvid))
+    qv = torch.randperm(n_qvid, generator=g)[:n_planted]
+    rv = torch.randint(0, n_rvid, (n_planted,), generator=g)
+    length = torch.randint(8, min(qf, rf, 25) + 1, (n_planted,), generator=g)
+    q0 = (torch.rand(n_planted, generator=g) * (qf - length + 1).float()).long()
+    r0 = (torch.rand(n_planted, generator=g) * (rf - length + 1).float()).long()
+    gd = torch.Generator(device=dev)
+    gd.manual_seed(seed + 1)
+    gt = []
+    for k in range(n_planted):
+        L = int(length[k])
+        qs = int(qv[k]) * qf + int(q0[k])
+        rs = int(rv[k]) * rf + int(r0[k])
+        seg = r[rs : rs + L] + noise * torch.randn((L, q.shape[1]), generator=gd, device=dev)
+        q[qs : qs + L] = seg / seg.norm(dim=1, keepdim=True)
+        gt.append((int(qv[k]), int(rv[k])))
+    return gt
+
+
+def cpu_baseline(args):
+    """The C oracle (oracle/libvscoracle.so: OpenMP, AVX2 fma chains) on the host cores over a
+    bounded sample of the same workload: 64 query videos against 1/10 of the references.  Per-query
+    cost is linear in the number of reference rows, so the rate is scaled by that 1/10."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import oracle as orc
+
+    orc.build()
+    rng = np.random.default_rng(args.seed)
+    n_qv, qf = 64, args.query_frames
+    n_rv, rf = max(1, args.ref_videos // 10), args.ref_frames
+    dim = args.dim
+
+    def unit(n):
+        x = rng.standard_normal((n, dim)).astype(np.float32)
+        return x / np.linalg.norm(x, axis=1, keepdims=True)
+
+    q, r = unit(n_qv * qf), unit(n_rv * rf)
+    for v in range(0, n_qv, 5):  # planted copies
+        rv = int(rng.integers(0, n_rv))
+        q[v * qf : v * qf + 12] = r[rv * rf + 3 : rv * rf + 15]
+    row2q = np.repeat(np.arange(n_qv, dtype=np.int32), qf)
+    row2r = np.repeat(np.arange(n_rv, dtype=np.int32), rf)
+    threads = orc.num_threads()
+    t0 = time.perf_counter()
+    hi, hj, hs = orc.global_threshold_search(q, r, 1200 * n_qv)
+    pq, pr, ps, _ = orc.pair_max(hi, hj, hs, row2q, row2r)
+    n_loc = min(len(ps), 5 * n_qv)
+    n_boxes = 0
+    for k in range(n_loc):
+        a = q[pq[k] * qf : (pq[k] + 1) * qf]
+        b = r[pr[k] * rf : (pr[k] + 1) * rf]
+        n_boxes += len(orc.tn(orc.pair_sims(a, b, 0.0), tn_max_step=5, min_length=4))
+    dt = time.perf_counter() - t0
+    scale = (n_rv * rf) / float(args.ref_videos * args.ref_frames)
+    return {
+        "value": (n_qv / dt) * scale,
+        "unit": "query-videos/s",
+        "cores": threads,
+        "kind": "port",
+        "sample": f"{n_qv} query videos x {qf} frames vs {n_rv * rf} ref frames ({dim}-d) in {dt:.2f} s on "
+                  f"{threads} threads; rate scaled by {scale:.3f} (per-query cost is linear in ref rows)",
+    }
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (gfx950) GPU: the engine has no CPU fallback")
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+
+    from vsc2022_amd.engine import DeviceMatcher
+
+    n_qv, qf, n_rv, rf, dim = args.query_videos, args.query_frames, args.ref_videos, args.ref_frames, args.dim
+    refs = synth_on_device(torch, dev, args.seed, n_rv, rf, dim)
+    queries = synth_on_device(torch, dev, args.seed + 1000 + rank, n_qv, qf, dim)
+    plant_copies(torch, dev, args.seed + 2000 + rank, queries, n_qv, qf, refs, n_rv, rf)
+    r_off = np.arange(n_rv + 1, dtype=np.int64) * rf
+    q_off = np.arange(n_qv + 1, dtype=np.int64) * qf
+    matcher = DeviceMatcher(refs, r_off, local_rank)
+    matcher.set_queries(queries, q_off)
+    del refs
+    kw = {}
+    if world > 1:
+        kw = dict(n_qvid_global=n_qv * world, qvid_base=rank * n_qv, row_base=rank * n_qv * qf)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        res = matcher.match(**kw)
+    matcher.index.profile(True)
+    matcher.index.profile_read(reset=True)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        res = matcher.match(**kw)
+    barrier()
+    dt = time.perf_counter() - t0
+    prof = matcher.index.profile_read(reset=True)
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    if rank == 0:
+        total_videos = n_qv * world * args.steps
+        achieved = (prof["sim_flops"] / 1e12) / (prof["sim_ms"] / 1e3) if prof["sim_ms"] > 0 else 0.0
+        out = {
+            "metric": "query-videos localized/sec @ 512-d SSCD",
+            "value": total_videos / dt,
+            "unit": "query-videos/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": 1e3 * dt / args.steps,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "fp32",
+            "data": "synthetic",
+            "config": {
+                "workload": "BASELINE configs[1]: brute-force cosine search 200k query x 2M ref 512-d fp32 per GPU "
+                            "+ candidates + TN localization (full hot path)",
+                "query_videos_per_gpu": n_qv, "query_frames_per_gpu": n_qv * qf, "ref_frames": n_rv * rf,
+                "dim": dim, "global_k": 1200 * n_qv * world, "candidates": res.n_candidates,
+                "pairs_localized": res.n_localized, "matches": res.n_matches, "hits": res.n_hits,
+                "parallelism": f"query-sharded x{world}" if world > 1 else "single GPU",
+            },
+            "roofline": {
+                "kernel": "sim_thresh_kernel (fp32 MFMA similarity + fused threshold compaction)",
+                "bound": "mfma",
+                "achieved": achieved,
+                "peak": FP32_MFMA_PEAK_TFLOPS,
+                "unit": "TFLOP/s",
+                "frac": achieved / FP32_MFMA_PEAK_TFLOPS,
+                "traffic": None,
+                "launches": prof["sim_launches"],
+                "kernel_ms_per_step": prof["sim_ms"] / args.steps,
+            },
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -38,7 +38,7 @@
 #define ORC_METRIC_IP 0
 #define ORC_METRIC_L2 1
 
-#define JB 16 /* refs scored together; each lane keeps its own k-ordered chain */
+#define JB 64 /* refs scored together; each lane keeps its own k-ordered chain */
 
 /* ------------------------------------------------------------------ scoring */
 
@@ -200,7 +200,7 @@ static int range_search_rows(const float *q, int64_t i0, int64_t i1, const float
 /* A faster batch scorer used by the search below: parallel over ref panels so each packed
  * panel is reused by every row of the batch.  Produces the same hits in the same order. */
 static int range_search_batch(const float *q, int64_t i0, int64_t i1, const float *r, int64_t nr,
-                              int64_t d, int metric, float radius, hits_t *h) {
+                              int64_t d, int metric, float radius, hits_t *h, const float *rt_all) {
     const int64_t nrows = i1 - i0;
     if (nrows <= 0) return 0;
     const int64_t npanel = (nr + JB - 1) / JB;
@@ -227,13 +227,15 @@ static int range_search_batch(const float *q, int64_t i0, int64_t i1, const floa
 #endif
         /* static contiguous panel ranges: thread t owns refs in ascending blocks */
         const int64_t p0 = npanel * tid / nth, p1 = npanel * (tid + 1) / nth;
-        float *rt = (float *)malloc(sizeof(float) * (size_t)(d > 0 ? d : 1) * JB);
+        float *rt_own = (float *)malloc(sizeof(float) * (size_t)(d > 0 ? d : 1) * JB);
         float acc[JB];
         hits_t *L = &loc[tid];
         int64_t *rc = rowcnt + (size_t)tid * nrows;
         for (int64_t p = p0; p < p1; ++p) {
             const int64_t j0 = p * JB;
-            pack_panel(r, nr, d, j0, rt);
+            const float *rt = rt_own;
+            if (rt_all) rt = rt_all + (size_t)p * (size_t)d * JB;
+            else pack_panel(r, nr, d, j0, rt_own);
             for (int64_t t = 0; t < nrows; ++t) {
                 const float *qrow = q + (i0 + t) * d;
                 if (metric == ORC_METRIC_IP) ip_panel(qrow, rt, d, acc);
@@ -255,7 +257,7 @@ static int range_search_batch(const float *q, int64_t i0, int64_t i1, const floa
                 }
             }
         }
-        free(rt);
+        free(rt_own);
     }
     if (!err) {
         /* offsets: row-major over (row, thread) */
@@ -403,9 +405,17 @@ int orc_global_threshold_search(const float *q, int64_t nq, const float *r, int6
     memset(&h, 0, sizeof(h));
     int64_t bs = 32, i0 = 0, nre = 0;
     int err = 0;
+    /* transposed reference panels, packed once and shared by every batch (pure layout) */
+    const int64_t npanel_all = (nr + JB - 1) / JB;
+    float *rt_all = (float *)malloc(sizeof(float) * (size_t)(npanel_all > 0 ? npanel_all : 1) *
+                                    (size_t)(d > 0 ? d : 1) * JB);
+    if (rt_all) {
+#pragma omp parallel for schedule(static)
+        for (int64_t p = 0; p < npanel_all; ++p) pack_panel(r, nr, d, p * JB, rt_all + (size_t)p * (size_t)d * JB);
+    }
     while (i0 < nq && !err) {
         const int64_t i1 = (i0 + bs < nq) ? i0 + bs : nq;
-        if (range_search_batch(q, i0, i1, r, nr, d, metric, radius, &h)) {
+        if (range_search_batch(q, i0, i1, r, nr, d, metric, radius, &h, rt_all)) {
             err = -1;
             break;
         }
@@ -460,6 +470,7 @@ int orc_global_threshold_search(const float *q, int64_t nq, const float *r, int6
     if (final_radius) *final_radius = radius;
     if (n_rethreshold) *n_rethreshold = nre;
     hits_free(&h);
+    free(rt_all);
     return err;
 }
 

@@ -1,0 +1,176 @@
+"""Query-sharded multi-GPU matching: one process per GPU, `torch.distributed` (backend "nccl" is
+RCCL on ROCm; the CPU tests use "gloo").
+
+Sharding: every rank holds the whole reference set and a contiguous range
+of query videos.  Rows of the similarity matrix are independent and so are candidate pairs, so the
+only exchange steps are the ones forced by the GLOBAL cuts of the reference pipeline:
+
+  1. the K = 1200 * n_query_videos best frame hits over ALL queries (vsc/index.py:142-165):
+     exact distributed selection over the per-rank score-sorted hit lists -- two all-reduces of a
+     65536-bin histogram of the order-preserving fp32 key (512 KiB each) + one all-gather of tie
+     counts;
+  2. the 25 * n_query_videos best (query, ref) candidates (vsc/descriptor_eval_lib.py:45-49,
+     vsc/baseline/sscd_baseline.py:101-102): the same selection over the per-rank candidate
+     lists, then a variable-length all-gather of the surviving candidates (20 B each).
+
+Messages are KBs to a few MBs, i.e. latency-bound on the direct xGMI links; no ring-sized
+buckets are needed.  Everything here works on torch tensors of any device, so the same code runs
+under gloo on CPU tensors in the tests (with the per-rank search results supplied by the oracle)
+and under RCCL on HBM tensors in production.
+
+Result contract: identical to the single-GPU result whenever the reference's own batch schedule
+does not drop hits tied with a re-threshold radius (vsc/index.py semantics are schedule-dependent
+only in that case); i.e. the sharded search returns the exact global top-K under the
+total order (score desc, query row asc, ref row asc).
+"""
+from typing import List, Optional, Tuple
+
+import torch
+import torch.distributed as dist
+
+
+def score_keys(scores: torch.Tensor) -> torch.Tensor:
+    """Order-preserving fp32 -> integer key (int64 holding a uint32): larger score, larger key."""
+    bits = scores.contiguous().view(torch.int32).to(torch.int64) & 0xFFFFFFFF
+    neg = (bits & 0x80000000) != 0
+    return torch.where(neg, (~bits) & 0xFFFFFFFF, bits | 0x80000000)
+
+
+def key_to_score(key: int) -> float:
+    """Inverse of score_keys for one key."""
+    import numpy as np
+
+    bits = (key & 0x7FFFFFFF) if (key & 0x80000000) else ((~key) & 0xFFFFFFFF)
+    return float(np.array([bits], dtype=np.uint32).view(np.float32)[0])
+
+
+def _world(group):
+    if not dist.is_available() or not dist.is_initialized():
+        return 0, 1
+    return dist.get_rank(group), dist.get_world_size(group)
+
+
+def _all_reduce_sum(t: torch.Tensor, group) -> torch.Tensor:
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+    return t
+
+
+def _all_gather_scalar(v: int, device, group) -> List[int]:
+    rank, world = _world(group)
+    if world == 1:
+        return [int(v)]
+    mine = torch.tensor([int(v)], dtype=torch.int64, device=device)
+    out = [torch.zeros_like(mine) for _ in range(world)]
+    dist.all_gather(out, mine, group=group)
+    return [int(x.item()) for x in out]
+
+
+def distributed_prefix_select(sorted_scores: torch.Tensor, k_total: int, group=None) -> Tuple[int, float]:
+    """How many leading elements of this rank's score-DESCENDING list belong to the global top
+    `k_total` of the union of all ranks' lists, under the total order (score desc, rank asc,
+    local position asc).  Returns (n_take, tau) with tau the k_total-th best score (or -inf when
+    the union is shorter than k_total).
+    """
+    rank, world = _world(group)
+    device = sorted_scores.device
+    n_local = int(sorted_scores.numel())
+    total = sum(_all_gather_scalar(n_local, device, group))
+    if total <= k_total:
+        return n_local, float("-inf")
+    if k_total <= 0:
+        return 0, float("inf")
+    keys = score_keys(sorted_scores) if n_local else torch.zeros(0, dtype=torch.int64, device=device)
+    hi = keys >> 16
+    hist = torch.bincount(hi, minlength=65536).to(torch.int64) if n_local else torch.zeros(65536, dtype=torch.int64, device=device)
+    hist = _all_reduce_sum(hist, group)
+    # walk from the top bin: first bin whose cumulative count reaches k_total
+    cum = torch.cumsum(hist.flip(0), 0)
+    b1 = 65535 - int(torch.searchsorted(cum, torch.tensor([k_total], dtype=torch.int64, device=device)).item())
+    above1 = int(cum[65535 - b1 - 1].item()) if b1 < 65535 else 0
+    in_bin = hi == b1
+    lo = keys[in_bin] & 0xFFFF
+    hist2 = torch.bincount(lo, minlength=65536).to(torch.int64) if lo.numel() else torch.zeros(65536, dtype=torch.int64, device=device)
+    hist2 = _all_reduce_sum(hist2, group)
+    cum2 = torch.cumsum(hist2.flip(0), 0)
+    need = k_total - above1
+    b2 = 65535 - int(torch.searchsorted(cum2, torch.tensor([need], dtype=torch.int64, device=device)).item())
+    above2 = int(cum2[65535 - b2 - 1].item()) if b2 < 65535 else 0
+    tau_key = (b1 << 16) | b2
+    n_gt_global = above1 + above2
+    m = k_total - n_gt_global  # elements tied with tau that still fit
+    n_gt = int((keys > tau_key).sum().item()) if n_local else 0
+    n_eq = int((keys == tau_key).sum().item()) if n_local else 0
+    ties = _all_gather_scalar(n_eq, device, group)
+    before = sum(ties[:rank])
+    take_ties = max(0, min(n_eq, m - before))
+    tau = key_to_score(tau_key)
+    return n_gt + take_ties, float(tau)
+
+
+def all_gather_varlen(t: torch.Tensor, group=None) -> torch.Tensor:
+    """Concatenate every rank's 1-D/2-D tensor (different lengths along dim 0), rank order."""
+    rank, world = _world(group)
+    if world == 1:
+        return t
+    lens = _all_gather_scalar(int(t.shape[0]), t.device, group)
+    mx = max(lens)
+    pad_shape = (mx,) + tuple(t.shape[1:])
+    padded = torch.zeros(pad_shape, dtype=t.dtype, device=t.device)
+    padded[: t.shape[0]] = t
+    outs = [torch.empty_like(padded) for _ in range(world)]
+    dist.all_gather(outs, padded, group=group)
+    return torch.cat([o[:n] for o, n in zip(outs, lens)], dim=0)
+
+
+class ShardedCandidates:
+    """Globally ordered candidate table (every rank holds the same copy)."""
+
+    def __init__(self, q_vid, r_vid, score, first_i, first_j):
+        self.q_vid, self.r_vid, self.score = q_vid, r_vid, score
+        self.first_i, self.first_j = first_i, first_j
+
+    def __len__(self):
+        return int(self.score.numel())
+
+
+def merge_hits(local_scores_sorted: torch.Tensor, k_global: int, complete_above: float, group=None
+               ) -> Tuple[int, float, bool]:
+    """Step 1: prefix of the local hit list that survives the global K cut.
+
+    `complete_above`: every local hit with score > complete_above is present in the local list
+    (the local search's own cut).  Returns (n_take, tau, exact): exact is False on ranks whose
+    local cut is not strictly below the global one -- the caller must then rerun that rank's
+    local search with a larger local K (all ranks call merge_hits again).
+    """
+    n_take, tau = distributed_prefix_select(local_scores_sorted, k_global, group)
+    exact = (complete_above == float("-inf")) or (tau > complete_above)
+    return n_take, tau, exact
+
+
+def merge_candidates(q_vid: torch.Tensor, r_vid: torch.Tensor, score: torch.Tensor, first_i: torch.Tensor,
+                     first_j: torch.Tensor, m_global: int, group=None) -> ShardedCandidates:
+    """Step 2: global top-`m_global` candidates, ordered as the single-process pipeline orders them:
+    score descending, ties by the (global query row, ref row) of the pair's first hit.
+
+    Inputs are this rank's candidates in local order (score desc, first-appearance); q_vid and
+    first_i must already be GLOBAL ordinals/rows.  Ranks own ascending, disjoint query ranges, so
+    local order + rank order is the global tie order.
+    """
+    n_take, _ = distributed_prefix_select(score, m_global, group)
+    packed = torch.stack(
+        [q_vid[:n_take].to(torch.int64), r_vid[:n_take].to(torch.int64),
+         score[:n_take].contiguous().view(torch.int32).to(torch.int64),
+         first_i[:n_take].to(torch.int64), first_j[:n_take].to(torch.int64)], dim=1)
+    allp = all_gather_varlen(packed, group)
+    s = allp[:, 2].to(torch.int32).view(torch.float32)
+    # stable sort by score desc over (rank-ordered) concatenation == (score desc, first_i, first_j)
+    order = torch.sort(-s.to(torch.float64), stable=True).indices
+    allp = allp[order]
+    return ShardedCandidates(allp[:, 0].to(torch.int32), allp[:, 1].to(torch.int32),
+                             allp[:, 2].to(torch.int32).view(torch.float32), allp[:, 3], allp[:, 4])
+
+
+def shard_ranges(n_items: int, world: int) -> List[Tuple[int, int]]:
+    """Contiguous, balanced [begin, end) ranges (rank order)."""
+    return [((n_items * r) // world, (n_items * (r + 1)) // world) for r in range(world)]

@@ -1,0 +1,220 @@
+"""HBM-resident matching engine: search -> candidates -> Temporal-Network localisation with every
+intermediate kept on the device (torch tensors are only the memory/stream plumbing; all compute
+is libvscmi through the C ABI).
+
+This is the array-level API underneath the `vsc.index` / `vsc.candidates` / `vcsl.vta` mirrors; it
+is what bench.py times ("inputs already resident in HBM") and what the multi-GPU driver shards.
+The constants are the reference's (vsc/descriptor_eval_lib.py:23-24, vsc/baseline/sscd_baseline.py:
+93-94,111,121-124): 1200 hits, 25 candidates and 5 localised pairs per query video; TN with
+tn_max_step=5, min_length=4.
+"""
+import ctypes
+from dataclasses import dataclass
+from typing import Optional
+
+import numpy as np
+import torch
+
+from vsc2022_amd import _lib, dist as vdist
+from vsc2022_amd.vcsl.vta import tn_params
+from vsc2022_amd.vsc.index import FlatIndex
+
+RETRIEVE_PER_QUERY = 1200
+CANDIDATES_PER_QUERY = 25
+LOCALIZE_PER_QUERY = 5
+REFERENCE_TN = dict(tn_max_step=5, min_length=4)
+
+
+@dataclass
+class MatchResult:
+    n_hits: int
+    n_pairs: int
+    n_candidates: int
+    n_localized: int
+    n_matches: int
+    cand_q: torch.Tensor      # [n_candidates] int32 query video ordinal (global)
+    cand_r: torch.Tensor      # [n_candidates] int32 ref video ordinal
+    cand_score: torch.Tensor  # [n_candidates] fp32
+    loc_index: torch.Tensor   # [n_localized_here] indices into the candidate table localised by this rank
+    nbox: torch.Tensor        # [n_localized_here] int32
+    boxes: torch.Tensor       # [n_localized_here, 16, 4] int32
+    box_score: torch.Tensor   # [n_localized_here, 16] fp32 (MaxSim - bias)
+    radius: float
+
+
+def _dev_ptr(t: torch.Tensor) -> int:
+    assert t.is_cuda and t.is_contiguous()
+    return t.data_ptr()
+
+
+class DeviceMatcher:
+    """One GPU's share of the matching pipeline.
+
+    refs / queries: fp32 [rows, dim] torch tensors in HBM (or numpy arrays, uploaded once);
+    *_off: int64 numpy row offsets per video.
+    """
+
+    def __init__(self, ref_feats, r_off: np.ndarray, device: Optional[int] = None):
+        self.device = _lib.default_device() if device is None else int(device)
+        self.tdev = torch.device("cuda", self.device)
+        torch.cuda.set_device(self.tdev)
+        self.r_off = np.ascontiguousarray(r_off, dtype=np.int64)
+        self.n_rvid = len(self.r_off) - 1
+        self.ref_feats = self._as_dev(ref_feats)
+        self.dim = int(self.ref_feats.shape[1])
+        self.index = FlatIndex(self.dim, _lib.METRIC_INNER_PRODUCT, self.device)
+        torch.cuda.synchronize(self.tdev)
+        self.index.add(self.ref_feats)
+        lens = torch.from_numpy(np.diff(self.r_off)).to(self.tdev)
+        self.row2r = torch.repeat_interleave(torch.arange(self.n_rvid, dtype=torch.int32, device=self.tdev), lens)
+        self._tn = None
+        self._bufs = {}
+
+    def _as_dev(self, x):
+        if isinstance(x, torch.Tensor):
+            return x.to(self.tdev, torch.float32).contiguous()
+        return torch.from_numpy(np.ascontiguousarray(x, dtype=np.float32)).to(self.tdev)
+
+    def _buf(self, name, n, dtype, cols=None):
+        shape = (n,) if cols is None else (n,) + tuple(cols)
+        b = self._bufs.get(name)
+        if b is None or b.shape[0] < n or b.dtype != dtype or b.shape[1:] != shape[1:]:
+            b = torch.empty(shape, dtype=dtype, device=self.tdev)
+            self._bufs[name] = b
+        return b
+
+    # ---- queries
+    def set_queries(self, q_feats, q_off: np.ndarray):
+        self.q_off = np.ascontiguousarray(q_off, dtype=np.int64)
+        self.n_qvid = len(self.q_off) - 1
+        self.q_feats = self._as_dev(q_feats)
+        lens = torch.from_numpy(np.diff(self.q_off)).to(self.tdev)
+        self.row2q = torch.repeat_interleave(torch.arange(self.n_qvid, dtype=torch.int32, device=self.tdev), lens)
+        if self._tn is not None:
+            _lib.lib().vsc_tn_destroy(self._tn)
+            self._tn = None
+        torch.cuda.synchronize(self.tdev)
+        ctx = ctypes.c_void_p()
+        _lib.check(_lib.lib().vsc_tn_create(
+            _dev_ptr(self.q_feats), self.q_off.ctypes.data, self.n_qvid, _dev_ptr(self.ref_feats),
+            self.r_off.ctypes.data, self.n_rvid, self.dim, _lib.MEM_DEVICE, self.device, ctypes.byref(ctx)))
+        self._tn = ctx
+
+    def __del__(self):
+        tn = getattr(self, "_tn", None)
+        if tn is not None:
+            try:
+                _lib.lib().vsc_tn_destroy(tn)
+            except Exception:
+                pass
+            self._tn = None
+
+    # ---- stages (all tensors stay in HBM)
+    def search(self, K: int):
+        """vsc/index.py:142-165 over the resident queries: (i, j, s) sorted hits + final radius."""
+        cap = int(max(1, min(K, self.q_feats.shape[0] * max(self.index.ntotal, 1))))
+        oi = self._buf("hit_i", cap, torch.int32)
+        oj = self._buf("hit_j", cap, torch.int32)
+        os_ = self._buf("hit_s", cap, torch.float32)
+        n_out, radius = ctypes.c_int64(0), ctypes.c_float(0.0)
+        torch.cuda.synchronize(self.tdev)
+        _lib.check(_lib.lib().vsc_index_global_topk(
+            self.index.handle, _dev_ptr(self.q_feats), int(self.q_feats.shape[0]), _lib.MEM_DEVICE, int(K),
+            _dev_ptr(oi), _dev_ptr(oj), _dev_ptr(os_), cap, _lib.MEM_DEVICE, ctypes.byref(n_out),
+            ctypes.byref(radius)))
+        m = n_out.value
+        return oi[:m], oj[:m], os_[:m], radius.value
+
+    def pair_max(self, hi, hj, hs):
+        """vsc/index.py:121-140 + vsc/candidates.py:24-40 on device hits."""
+        n = int(hs.numel())
+        oq = self._buf("pair_q", max(n, 1), torch.int32)
+        orr = self._buf("pair_r", max(n, 1), torch.int32)
+        os_ = self._buf("pair_s", max(n, 1), torch.float32)
+        of = self._buf("pair_f", max(n, 1), torch.int64)
+        n_pairs = ctypes.c_int64(0)
+        if n:
+            hi, hj, hs = hi.contiguous(), hj.contiguous(), hs.contiguous()
+            torch.cuda.synchronize(self.tdev)
+            _lib.check(_lib.lib().vsc_pair_max(
+                _dev_ptr(hi), _dev_ptr(hj), _dev_ptr(hs), n, _lib.MEM_DEVICE, _dev_ptr(self.row2q),
+                int(self.row2q.numel()), _dev_ptr(self.row2r), int(self.row2r.numel()), _lib.MEM_DEVICE,
+                _dev_ptr(oq), _dev_ptr(orr), _dev_ptr(os_), _dev_ptr(of), n, _lib.MEM_DEVICE,
+                ctypes.byref(n_pairs), self.device))
+        m = n_pairs.value
+        return oq[:m], orr[:m], os_[:m], of[:m]
+
+    def localize(self, pair_q: torch.Tensor, pair_r: torch.Tensor, bias: float = 0.0, **tn_kwargs):
+        """vsc/baseline/localization.py:56-96 for device-resident pair lists (LOCAL query ordinals)."""
+        n = int(pair_q.numel())
+        nbox = self._buf("tn_nbox", max(n, 1), torch.int32)
+        boxes = self._buf("tn_boxes", max(n, 1), torch.int32, (_lib.TN_MAX_BOXES, 4))
+        bmax = self._buf("tn_bmax", max(n, 1), torch.float32, (_lib.TN_MAX_BOXES,))
+        if n:
+            prm = tn_params(**(tn_kwargs or REFERENCE_TN))
+            pq, pr = pair_q.to(torch.int32).contiguous(), pair_r.to(torch.int32).contiguous()
+            torch.cuda.synchronize(self.tdev)
+            _lib.check(_lib.lib().vsc_tn_localize(
+                self._tn, _dev_ptr(pq), _dev_ptr(pr), n, _lib.MEM_DEVICE, ctypes.byref(prm), float(bias),
+                _dev_ptr(nbox), _dev_ptr(boxes), _dev_ptr(bmax), _lib.MEM_DEVICE))
+        return nbox[:n], boxes[:n], bmax[:n]
+
+    # ---- the whole hot path
+    def match(self, n_qvid_global: Optional[int] = None, qvid_base: int = 0, row_base: int = 0, group=None,
+              bias: float = 0.0) -> MatchResult:
+        """search -> candidates -> localisation for the resident queries.
+
+        Single process: n_qvid_global is None.  Sharded (one process per GPU): this rank owns the
+        query videos [qvid_base, qvid_base + n_qvid) / rows [row_base, ...) of a global query set
+        of n_qvid_global videos; the two global cuts are resolved with vsc2022_amd.dist.
+        """
+        sharded = n_qvid_global is not None and torch.distributed.is_initialized() and \
+            torch.distributed.get_world_size(group) > 1
+        nq_glob = n_qvid_global if n_qvid_global is not None else self.n_qvid
+        K = int(RETRIEVE_PER_QUERY * nq_glob)
+        n_cand_cut = int(CANDIDATES_PER_QUERY * nq_glob)
+        n_loc_cut = int(LOCALIZE_PER_QUERY * nq_glob)
+        if not sharded:
+            hi, hj, hs, radius = self.search(K)
+            pq, pr, ps, pf = self.pair_max(hi, hj, hs)
+            n_cand = min(int(ps.numel()), n_cand_cut)
+            n_loc = min(n_cand, n_loc_cut)
+            nbox, boxes, bmax = self.localize(pq[:n_loc], pr[:n_loc], bias)
+            return MatchResult(int(hs.numel()), int(ps.numel()), n_cand, n_loc, int(nbox.sum().item()),
+                               pq[:n_cand], pr[:n_cand], ps[:n_cand],
+                               torch.arange(n_loc, device=self.tdev), nbox, boxes, bmax, radius)
+        world = torch.distributed.get_world_size(group)
+        total_rows_local = int(self.q_feats.shape[0])
+        k_local = max(1, min(K, 2 * K // world))
+        while True:
+            hi, hj, hs, radius = self.search(k_local)
+            n = int(hs.numel())
+            if n >= total_rows_local * self.index.ntotal:
+                complete_above = float("-inf")
+            elif n == k_local:
+                complete_above = float(hs[-1].item())
+            else:
+                complete_above = float(radius)
+            n_take, tau, exact = vdist.merge_hits(hs, K, complete_above, group)
+            flag = torch.tensor([0 if exact else 1], dtype=torch.int64, device=self.tdev)
+            torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MAX, group=group)
+            if int(flag.item()) == 0:
+                break
+            if not exact:
+                k_local = min(K, k_local * 2)
+        hi, hj, hs = hi[:n_take], hj[:n_take], hs[:n_take]
+        pq, pr, ps, pf = self.pair_max(hi, hj, hs)
+        first_i = hi[pf].to(torch.int64) + row_base if pf.numel() else pf
+        first_j = hj[pf].to(torch.int64) if pf.numel() else pf
+        cands = vdist.merge_candidates(pq + qvid_base, pr, ps, first_i, first_j, n_cand_cut, group)
+        n_cand = len(cands)
+        n_loc = min(n_cand, n_loc_cut)
+        mine = (cands.q_vid[:n_loc] >= qvid_base) & (cands.q_vid[:n_loc] < qvid_base + self.n_qvid)
+        loc_index = torch.nonzero(mine).flatten()
+        nbox, boxes, bmax = self.localize(cands.q_vid[loc_index] - qvid_base, cands.r_vid[loc_index], bias)
+        n_matches = torch.tensor([int(nbox.sum().item())], dtype=torch.int64, device=self.tdev)
+        torch.distributed.all_reduce(n_matches, group=group)
+        n_hits = torch.tensor([n_take], dtype=torch.int64, device=self.tdev)
+        torch.distributed.all_reduce(n_hits, group=group)
+        return MatchResult(int(n_hits.item()), int(ps.numel()), n_cand, n_loc, int(n_matches.item()),
+                           cands.q_vid, cands.r_vid, cands.score, loc_index, nbox, boxes, bmax, radius)
