@@ -148,6 +148,42 @@ def merge_hits(local_scores_sorted: torch.Tensor, k_global: int, complete_above:
     return n_take, tau, exact
 
 
+def sharded_hits(local_search, local_matrix_size: int, k_global: int, group=None, device=None,
+                 k_local_start: Optional[int] = None):
+    """Exact global top-`k_global` hits from per-rank searches.
+
+    local_search(k_local) -> (i, j, s, radius): this rank's global-threshold search with budget
+    k_local (hits sorted by (score desc, row asc, ref asc); radius = the search's final radius).
+    local_matrix_size = n_local_query_rows * n_ref_rows.  Starts from k_local = 2*K/world and doubles
+    the budget of any rank whose own cut is not strictly below the global cut (skewed shards), until
+    the result is exact everywhere.  Returns (i, j, s) = this rank's share of the global top-K.
+    """
+    rank, world = _world(group)
+    k_local = max(1, min(k_global, 2 * k_global // max(world, 1)))
+    if k_local_start is not None:
+        k_local = max(1, min(k_global, int(k_local_start)))
+    while True:
+        hi, hj, hs, radius = local_search(k_local)
+        n = int(hs.numel())
+        if n >= local_matrix_size:
+            complete_above = float("-inf")      # the whole local matrix was kept
+        elif n >= k_local:
+            complete_above = float(hs[-1].item())  # truncated at k_local: ties with the last may be missing
+        else:
+            complete_above = float(radius)      # hits <= radius were dropped by the schedule
+        n_take, tau, exact = merge_hits(hs, k_global, complete_above, group)
+        if world > 1:
+            flag = torch.tensor([0 if exact else 1], dtype=torch.int64, device=hs.device if device is None else device)
+            dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=group)
+            all_exact = int(flag.item()) == 0
+        else:
+            all_exact = exact
+        if all_exact or k_local >= k_global:
+            return hi[:n_take], hj[:n_take], hs[:n_take], tau
+        if not exact:
+            k_local = min(k_global, k_local * 2)
+
+
 def merge_candidates(q_vid: torch.Tensor, r_vid: torch.Tensor, score: torch.Tensor, first_i: torch.Tensor,
                      first_j: torch.Tensor, m_global: int, group=None) -> ShardedCandidates:
     """Step 2: global top-`m_global` candidates, ordered as the single-process pipeline orders them:

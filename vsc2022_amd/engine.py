@@ -183,26 +183,17 @@ class DeviceMatcher:
             return MatchResult(int(hs.numel()), int(ps.numel()), n_cand, n_loc, int(nbox.sum().item()),
                                pq[:n_cand], pr[:n_cand], ps[:n_cand],
                                torch.arange(n_loc, device=self.tdev), nbox, boxes, bmax, radius)
-        world = torch.distributed.get_world_size(group)
-        total_rows_local = int(self.q_feats.shape[0])
-        k_local = max(1, min(K, 2 * K // world))
-        while True:
-            hi, hj, hs, radius = self.search(k_local)
-            n = int(hs.numel())
-            if n >= total_rows_local * self.index.ntotal:
-                complete_above = float("-inf")
-            elif n == k_local:
-                complete_above = float(hs[-1].item())
-            else:
-                complete_above = float(radius)
-            n_take, tau, exact = vdist.merge_hits(hs, K, complete_above, group)
-            flag = torch.tensor([0 if exact else 1], dtype=torch.int64, device=self.tdev)
-            torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MAX, group=group)
-            if int(flag.item()) == 0:
-                break
-            if not exact:
-                k_local = min(K, k_local * 2)
-        hi, hj, hs = hi[:n_take], hj[:n_take], hs[:n_take]
+        radius_box = [float("nan")]
+
+        def local_search(k_local):
+            i, j, sc, rad = self.search(k_local)
+            radius_box[0] = rad
+            return i, j, sc, rad
+
+        hi, hj, hs, _tau = vdist.sharded_hits(local_search, int(self.q_feats.shape[0]) * self.index.ntotal, K,
+                                              group, self.tdev)
+        radius = radius_box[0]
+        n_take = int(hs.numel())
         pq, pr, ps, pf = self.pair_max(hi, hj, hs)
         first_i = hi[pf].to(torch.int64) + row_base if pf.numel() else pf
         first_j = hj[pf].to(torch.int64) if pf.numel() else pf
