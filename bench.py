@@ -90,7 +90,8 @@ def cpu_baseline(args):
 
     orc.build()
     rng = np.random.default_rng(args.seed)
-    n_qv, qf = 64, args.query_frames
+    # ~10-30 s of CPU work whatever the core count (0.2 s per query video per core at this size)
+    n_qv, qf = max(64, 6 * orc.num_threads()), args.query_frames
     n_rv, rf = max(1, args.ref_videos // 10), args.ref_frames
     dim = args.dim
 
@@ -178,6 +179,14 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     if rank == 0:
+        # HBM bytes per launch of the dominant kernel come from the committed PMC passes
+        # (FETCH_SIZE / WRITE_SIZE cannot be sampled from inside the process)
+        traffic = None
+        try:
+            with open(os.path.join(ROOT, "profiles", "r01_roofline.json")) as fh:
+                traffic = float(json.load(fh)["hbm_bytes_per_launch"])
+        except Exception:
+            traffic = None
         total_videos = n_qv * world * args.steps
         achieved = (prof["sim_flops"] / 1e12) / (prof["sim_ms"] / 1e3) if prof["sim_ms"] > 0 else 0.0
         out = {
@@ -208,7 +217,8 @@ def main():
                 "peak": FP32_MFMA_PEAK_TFLOPS,
                 "unit": "TFLOP/s",
                 "frac": achieved / FP32_MFMA_PEAK_TFLOPS,
-                "traffic": None,
+                "traffic": traffic,
+                "traffic_unit": "bytes/launch (PMC FETCH_SIZE x2 + WRITE_SIZE, profiles/r01_pmc_fetch_write.md)",
                 "launches": prof["sim_launches"],
                 "kernel_ms_per_step": prof["sim_ms"] / args.steps,
             },
