@@ -28,3 +28,18 @@ for k, cn, n, s in db.execute(q):
     if filt and filt not in k:
         continue
     print(f"| `{k[:80]}` | {cn} | {n} | {s:.6g} | {s / max(n, 1):.6g} |")
+
+# kernel durations (ns) for clock estimates
+try:
+    kc = cols("kernels")
+    nm = "name" if "name" in kc else "kernel_name"
+    st, en = ("start", "end") if "start" in kc else ("start_timestamp", "end_timestamp")
+    print()
+    print("| kernel | dispatches | total ms |")
+    print("|---|---|---|")
+    for k, n, t in db.execute(f"select {nm}, count(*), sum({en}-{st}) from kernels group by 1 order by 3 desc"):
+        if filt and filt not in k:
+            continue
+        print(f"| `{k[:80]}` | {n} | {t / 1e6:.3f} |")
+except Exception as e:  # noqa
+    print("no kernel table:", e)

@@ -1,0 +1,82 @@
+"""GPU, BASELINE configs[1] full size (200k query x 2M reference frames, 512-d fp32, K = 9.6M):
+size-independent properties of the hot path, with oracle spot checks on samples (the oracle cannot
+score 4e11 pairs)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def fullsize(gpu):
+    import torch
+    from bench import plant_copies, synth_on_device
+    from vsc2022_amd.engine import DeviceMatcher
+
+    dev = torch.device("cuda", 0)
+    n_qv, qf, n_rv, rf, dim = 8000, 25, 40000, 50, 512
+    refs = synth_on_device(torch, dev, 1, n_rv, rf, dim)
+    queries = synth_on_device(torch, dev, 1001, n_qv, qf, dim)
+    gt = plant_copies(torch, dev, 2001, queries, n_qv, qf, refs, n_rv, rf)
+    m = DeviceMatcher(refs, np.arange(n_rv + 1, dtype=np.int64) * rf, 0)
+    m.set_queries(queries, np.arange(n_qv + 1, dtype=np.int64) * qf)
+    return m, queries, refs, gt, (n_qv, qf, n_rv, rf, dim)
+
+
+def test_fullsize_search_properties(fullsize, orc):
+    import torch
+
+    m, queries, refs, gt, (n_qv, qf, n_rv, rf, dim) = fullsize
+    K = 1200 * n_qv
+    hi, hj, hs, radius = m.search(K)
+    assert hs.numel() == K
+    s = hs.cpu().numpy()
+    i = hi.cpu().numpy()
+    j = hj.cpu().numpy()
+    # ordering: score desc, then (row, ref) asc
+    assert np.all(s[:-1] >= s[1:])
+    same = s[:-1] == s[1:]
+    key = i.astype(np.int64) * (n_rv * rf) + j
+    assert np.all(key[:-1][same] < key[1:][same])
+    assert np.all(s > np.float32(radius))
+    assert len(np.unique(key)) == K
+    # spot check: 2000 hits recomputed by the oracle chain are bit-identical
+    rng = np.random.default_rng(0)
+    pick = rng.choice(K, 2000, replace=False)
+    q_rows = queries[torch.from_numpy(i[pick]).long().to(queries.device)].cpu().numpy()
+    r_rows = refs[torch.from_numpy(j[pick]).long().to(refs.device)].cpu().numpy()
+    exact = np.array([orc.scores(q_rows[k:k + 1], r_rows[k:k + 1])[0, 0] for k in range(len(pick))], dtype=np.float32)
+    assert np.array_equal(exact.view(np.uint32), s[pick].view(np.uint32))
+    # completeness on a sample of rows: every score above the K-th best hit of the search is a hit
+    rows = rng.choice(n_qv * qf, 24, replace=False)
+    sub = orc.scores(queries[torch.from_numpy(rows).long().to(queries.device)].cpu().numpy(),
+                     refs[: 200000].cpu().numpy())
+    cut = s[-1]
+    hits_set = set(zip(i.tolist(), j.tolist()))
+    rr, cc = np.nonzero(sub > cut)
+    assert len(rr) > 0
+    for a, b in zip(rr, cc):
+        assert (int(rows[a]), int(b)) in hits_set
+    # idempotence
+    hi2, hj2, hs2, radius2 = m.search(K)
+    assert radius2 == radius and torch.equal(hs2, hs) and torch.equal(hi2, hi) and torch.equal(hj2, hj)
+
+
+def test_fullsize_pipeline_finds_the_planted_copies(fullsize):
+    m, queries, refs, gt, (n_qv, qf, n_rv, rf, dim) = fullsize
+    res = m.match()
+    assert res.n_hits == 1200 * n_qv and res.n_candidates == 25 * n_qv and res.n_localized == 5 * n_qv
+    cand = set(zip(res.cand_q.cpu().tolist(), res.cand_r.cpu().tolist()))
+    planted = set(gt)
+    assert len(planted & cand) >= 0.99 * len(planted)
+    sc = res.cand_score.cpu().numpy()
+    assert np.all(sc[:-1] >= sc[1:])
+    nbox = res.nbox.cpu().numpy()
+    loc = set(zip(res.cand_q[: res.n_localized].cpu().numpy()[nbox > 0].tolist(),
+                  res.cand_r[: res.n_localized].cpu().numpy()[nbox > 0].tolist()))
+    assert len(planted & loc) >= 0.95 * len(planted)
+    boxes = res.boxes.cpu().numpy()
+    for p in np.nonzero(nbox > 0)[0][:200]:
+        for b in range(nbox[p]):
+            x1, y1, x2, y2 = boxes[p, b]
+            assert 0 <= x1 < x2 < qf and 0 <= y1 < y2 < rf

@@ -15,7 +15,7 @@ import threading
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libvscmi.so")
+LIB_PATH = os.environ.get("VSCMI_LIB") or os.path.join(_HERE, "libvscmi.so")  # VSCMI_LIB: kernel experiments only
 CSRC = os.path.join(_HERE, "csrc")
 
 VSC_OK = 0
@@ -77,6 +77,32 @@ def build(force: bool = False) -> str:
     return LIB_PATH
 
 
+def _preload_torch_hip_runtime():
+    """One HIP/HSA runtime per process.
+
+    PyTorch-ROCm wheels bundle their own libamdhip64 / libhsa-runtime64 (same SONAMEs as /opt/rocm).
+    If libvscmi pulled in the system copies first and torch its bundled ones later, two HSA runtimes
+    would fight over the device ("no ROCm-capable device is detected").  Loading torch's copies
+    first (without importing torch) makes both users share them, whatever the import order.
+    """
+    import importlib.util
+
+    try:
+        spec = importlib.util.find_spec("torch")
+    except Exception:
+        spec = None
+    if spec is None or not spec.origin:
+        return
+    libdir = os.path.join(os.path.dirname(spec.origin), "lib")
+    for name in ("libhsa-runtime64.so", "libamdhip64.so"):
+        path = os.path.join(libdir, name)
+        if os.path.exists(path):
+            try:
+                ctypes.CDLL(path, mode=ctypes.RTLD_GLOBAL)
+            except OSError:
+                pass
+
+
 def lib():
     global _lib
     with _lock:
@@ -87,6 +113,7 @@ def lib():
                 f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; "
                 "g.build()'` (hipcc --offload-arch=gfx950).  There is no CPU fallback."
             )
+        _preload_torch_hip_runtime()
         L = ctypes.CDLL(LIB_PATH)
         vp, i64, i32, f32 = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_float
         pi64 = ctypes.POINTER(ctypes.c_int64)

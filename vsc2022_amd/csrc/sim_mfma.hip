@@ -14,6 +14,7 @@
 // s = (row&1)<<3 | (chunk ^ (line&7)), which makes every ds_read_b128 lane group hit 16 distinct
 // slots (conflict-free) while the DMA destination stays lane-linear (swizzle on the source side).
 #include <cfloat>
+#include <cstdlib>
 
 #include "kernels.h"
 
@@ -29,14 +30,26 @@ constexpr int TILE_BYTES = BM * BK * 4;      // 16 KiB per operand per stage
 constexpr int STAGE_BYTES = 2 * TILE_BYTES;  // A + B
 constexpr int GEMM_LDS = 2 * STAGE_BYTES;    // 64 KiB
 
-__device__ __forceinline__ void glds16(const float* g, char* l) {
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
-                                     (__attribute__((address_space(3))) void*)l, 16, 0, 0);
+// LDS-DMA of one 16-byte piece per lane: buffer_load_dwordx4 ... lds.  The buffer descriptor is
+// wave-uniform (tile base), the per-lane part is a 32-bit byte offset, the K-tile advance rides in
+// the scalar offset: no 64-bit address arithmetic per issue.
+__device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rsrc, int voff, int soff, char* lds) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)lds, 16, voff,
+                                             soff, 0, 0);
+}
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t tile_rsrc(const float* base, int dpad) {
+    // make the (already wave-uniform) base provably uniform so the descriptor lives in SGPRs
+    const uint64_t p = reinterpret_cast<uint64_t>(base);
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)p);
+    const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(p >> 32));
+    void* up = reinterpret_cast<void*>(((uint64_t)hi << 32) | lo);
+    return __builtin_amdgcn_make_buffer_rsrc(up, 0, BM * dpad * 4, 0x00020000);
 }
 
 // Per-thread constants of the tile pipeline.
 struct TileThread {
-    int src_off[4];   // float offset (row*dpad + chunk*4) of the 4 DMA pieces this thread issues
+    int src_off[4];   // BYTE offset (row*dpad + chunk*4)*4 of the 4 DMA pieces this thread issues
     int dst_off[4];   // wave-uniform LDS byte offset of those pieces inside an operand tile
     int rdA[2][4];    // LDS byte offsets of the A fragments [tm][kk]
     int rdB[2][4];    // LDS byte offsets of the B fragments [tn][kk]
@@ -51,8 +64,8 @@ __device__ __forceinline__ void tile_thread_init(TileThread& t, int tid, int dpa
         const int line = p >> 4, s = p & 15;
         const int row = 2 * line + (s >> 3);
         const int chunk = (s & 7) ^ (line & 7);
-        t.src_off[n] = row * dpad + chunk * 4;
-        t.dst_off[n] = (n * 256 + wave * 64) * 16;
+        t.src_off[n] = (row * dpad + chunk * 4) * 4;
+        t.dst_off[n] = (n * 256 + __builtin_amdgcn_readfirstlane(wave) * 64) * 16;
     }
     const int hi = lane >> 5;
 #pragma unroll
@@ -69,55 +82,135 @@ __device__ __forceinline__ void tile_thread_init(TileThread& t, int tid, int dpa
     }
 }
 
-__device__ __forceinline__ void stage_tiles(const float* __restrict__ qrow0,
-                                            const float* __restrict__ rrow0, int kt, char* stage,
-                                            const TileThread& t) {
-#pragma unroll
-    for (int n = 0; n < 4; ++n) glds16(qrow0 + t.src_off[n] + kt * BK, stage + t.dst_off[n]);
-#pragma unroll
-    for (int n = 0; n < 4; ++n)
-        glds16(rrow0 + t.src_off[n] + kt * BK, stage + TILE_BYTES + t.dst_off[n]);
+struct Frags {
+    f32x4 a0, a1, b0, b1;
+};
+
+__device__ __forceinline__ Frags read_frags(const char* stage, const TileThread& t, int kk) {
+    Frags f;
+    f.a0 = *reinterpret_cast<const f32x4*>(stage + t.rdA[0][kk]);
+    f.a1 = *reinterpret_cast<const f32x4*>(stage + t.rdA[1][kk]);
+    f.b0 = *reinterpret_cast<const f32x4*>(stage + TILE_BYTES + t.rdB[0][kk]);
+    f.b1 = *reinterpret_cast<const f32x4*>(stage + TILE_BYTES + t.rdB[1][kk]);
+    return f;
 }
 
-// acc[tm][tn] += Q[q0.., :] . R[r0.., :]^T over the whole (padded) K.  All 256 threads.
-// On return every wave has finished its LDS reads of the last stage only after the caller syncs.
-__device__ __forceinline__ void gemm_tile(const float* __restrict__ qrow0,
-                                          const float* __restrict__ rrow0, int dpad, char* smem,
-                                          const TileThread& t, f32x16 (&acc)[2][2]) {
+__device__ __forceinline__ void mfma4(const Frags& f, int s, f32x16 (&acc)[2][2]) {
+    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a0[s], f.b0[s], acc[0][0], 0, 0, 0);
+    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a0[s], f.b1[s], acc[0][1], 0, 0, 0);
+    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a1[s], f.b0[s], acc[1][0], 0, 0, 0);
+    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a1[s], f.b1[s], acc[1][1], 0, 0, 0);
+}
+
+__device__ __forceinline__ void stage_tiles(__amdgpu_buffer_rsrc_t qrs, __amdgpu_buffer_rsrc_t rrs, int kt,
+                                            char* stage, const TileThread& t) {
+#pragma unroll
+    for (int n = 0; n < 4; ++n) dma16(qrs, t.src_off[n], kt * BK * 4, stage + t.dst_off[n]);
+#pragma unroll
+    for (int n = 0; n < 4; ++n) dma16(rrs, t.src_off[n], kt * BK * 4, stage + TILE_BYTES + t.dst_off[n]);
+}
+
+// ---- the tile stream -------------------------------------------------------------------------
+// A workgroup is persistent: it walks a list of output tiles and treats their K-tiles (32 floats each)
+// as ONE continuous stream through the 2-stage LDS ring, so there is no load prologue per output
+// tile: while the last K-tiles of tile T are multiplied, the first two K-tiles of tile T+1 are
+// already in flight.  Pipeline per K-tile (4 groups of 16 MFMAs per wave):
+//   * fragments are double-buffered in registers: the ds_read_b128 of group g+1 are issued before the
+//     MFMAs of group g;
+//   * the one barrier per K-tile sits BEFORE the last MFMA group of the K-tile (whose operands are
+//     already in registers), so the first fragment reads of the next K-tile and the 8 LDS-DMA issues
+//     of the one after it are covered by 16 MFMAs (1024 matrix-pipe cycles);
+//   * the DMA issues are interleaved one per two MFMAs (sched_group_barrier), never ahead of them.
+struct TileStream {
+    const float* q;   // operand panels of the current tile (wave-uniform)
+    const float* r;
+    Frags cur;        // fragments (K-tile 0, group 0) of the current tile
+    int sp;           // LDS stage holding K-tile 0 of the current tile
+};
+
+__device__ __forceinline__ void stream_begin(TileStream& st, const float* qrow0, const float* rrow0,
+                                             int dpad, char* smem, const TileThread& t) {
+    st.q = qrow0;
+    st.r = rrow0;
+    st.sp = 0;
+    const __amdgpu_buffer_rsrc_t qrs = tile_rsrc(qrow0, dpad), rrs = tile_rsrc(rrow0, dpad);
+    stage_tiles(qrs, rrs, 0, smem, t);
+    __syncthreads();  // K-tile 0 landed
+    stage_tiles(qrs, rrs, 1, smem + STAGE_BYTES, t);  // dpad >= 64: K-tile 1 always exists
+    st.cur = read_frags(smem, t, 0);
+}
+
+// acc += Q[tile rows, :] . R[tile rows, :]^T for the stream's current tile.  If has_next, the stream is
+// left positioned on the tile whose panels start at (nq, nr); otherwise pass the current panels.
+//
+// There is exactly ONE copy of every MFMA in this loop: the conditionals (is there a next K-tile to
+// wait for / a K-tile two ahead to fetch) only guard the barrier, the fragment reads and the DMA
+// issues.  Duplicating the MFMA groups across branches makes the register allocator copy the 64
+// accumulator VGPRs at the merge points (v_mov + MFMA-result hazard nops every K-tile).
+__device__ __forceinline__ void stream_tile(TileStream& st, bool has_next, const float* nq, const float* nr,
+                                            int dpad, char* smem, const TileThread& t,
+                                            f32x16 (&acc)[2][2]) {
     const int nkt = dpad / BK;
-    stage_tiles(qrow0, rrow0, 0, smem, t);
+    Frags cur = st.cur;
+    int sp = st.sp;
     for (int kt = 0; kt < nkt; ++kt) {
-        // tile kt has landed (the barrier's release waits for this wave's DMA), and every wave is
-        // done reading the other stage (it was consumed in iteration kt-1)
-        __syncthreads();
-        if (kt + 1 < nkt) stage_tiles(qrow0, rrow0, kt + 1, smem + ((kt + 1) & 1) * STAGE_BYTES, t);
-        const char* A = smem + (kt & 1) * STAGE_BYTES;
-        const char* B = A + TILE_BYTES;
+        const char* stage = smem + sp * STAGE_BYTES;
 #pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
-            const f32x4 a0 = *reinterpret_cast<const f32x4*>(A + t.rdA[0][kk]);
-            const f32x4 a1 = *reinterpret_cast<const f32x4*>(A + t.rdA[1][kk]);
-            const f32x4 b0 = *reinterpret_cast<const f32x4*>(B + t.rdB[0][kk]);
-            const f32x4 b1 = *reinterpret_cast<const f32x4*>(B + t.rdB[1][kk]);
+        for (int kk = 0; kk < 3; ++kk) {
+            const Frags nxt = read_frags(stage, t, kk + 1);
 #pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[s], b0[s], acc[0][0], 0, 0, 0);
-                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[s], b1[s], acc[0][1], 0, 0, 0);
-                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[s], b0[s], acc[1][0], 0, 0, 0);
-                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[s], b1[s], acc[1][1], 0, 0, 0);
-            }
+            for (int s = 0; s < 4; ++s) mfma4(cur, s, acc);
+            // pin the order: the 4 fragment reads of the NEXT group go out before this group's 16
+            // MFMAs (left alone, the scheduler sinks them to just before their use and exposes the
+            // LDS latency four times per K-tile)
+            __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);
+            cur = nxt;
         }
+        // Last group of this K-tile: its operands are in registers, so the stage is free.
+        const int k2 = kt + 2;
+        const bool in_cur = k2 < nkt;
+        const bool n1 = (kt + 1 < nkt) || has_next;  // a next K-tile exists in the stream
+        const bool n2 = in_cur || has_next;          // ... and one after it, to be fetched now
+        Frags nxt = cur;
+        if (n1) {
+            // the next K-tile (issued one K-tile ago) has landed once every wave's DMA count drains
+            __syncthreads();
+            nxt = read_frags(smem + (sp ^ 1) * STAGE_BYTES, t, 0);
+        }
+        const __amdgpu_buffer_rsrc_t q2 = tile_rsrc(in_cur ? st.q : nq, dpad);
+        const __amdgpu_buffer_rsrc_t r2 = tile_rsrc(in_cur ? st.r : nr, dpad);
+        const int soff = (in_cur ? k2 : k2 - nkt) * BK * 4;
+        char* wstage = smem + sp * STAGE_BYTES;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            // one DMA per two MFMAs: an LDS-DMA issue occupies the wave for ~60 cycles, one matrix
+            // instruction for 64 -- spaced like this the issue cost disappears behind the pipe
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.a0[s], cur.b0[s], acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.a0[s], cur.b1[s], acc[0][1], 0, 0, 0);
+            if (n2) dma16(q2, t.src_off[s], soff, wstage + t.dst_off[s]);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.a1[s], cur.b0[s], acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.a1[s], cur.b1[s], acc[1][1], 0, 0, 0);
+            if (n2) dma16(r2, t.src_off[s], soff, wstage + TILE_BYTES + t.dst_off[s]);
+        }
+        cur = nxt;
+        if (n1) sp ^= 1;
     }
+    st.cur = cur;
+    st.sp = sp;
+    st.q = nq;
+    st.r = nr;
 }
 
-// XCD-aware rasterisation.  The dispatcher places workgroup b on XCD b % 8; give every XCD a
-// contiguous run of tiles, and inside a run walk bands of GQ query tiles so that the ~64 tiles
-// resident on one XCD share GQ query panels and a short run of ref panels in its private L2.
-__device__ __forceinline__ bool raster(int bid, int tq, int64_t tr, int& tqi, int64_t& tri) {
+// XCD-aware rasterisation.  The dispatcher places workgroup b on XCD b % 8; every XCD owns a
+// contiguous run of tiles, and inside a run walks bands of GQ query tiles so that the ~64 tiles in
+// flight on one XCD share GQ query panels and a short run of ref panels in its private L2.
+// `local` = index inside the XCD's run.
+__device__ __forceinline__ bool raster(int xcd, int64_t local, int tq, int64_t tr, int& tqi, int64_t& tri) {
     const int64_t nblk = (int64_t)tq * tr;
     const int64_t per_xcd = (nblk + 7) / 8;
-    const int64_t logical = (int64_t)(bid & 7) * per_xcd + (bid >> 3);
-    if ((bid >> 3) >= per_xcd || logical >= nblk) return false;
+    const int64_t logical = (int64_t)xcd * per_xcd + local;
+    if (local >= per_xcd || logical >= nblk) return false;
     constexpr int GQ = 8;
     const int64_t band_sz = (int64_t)GQ * tr;
     const int64_t band = logical / band_sz, rem = logical % band_sz;
@@ -130,29 +223,9 @@ __device__ __forceinline__ bool raster(int bid, int tq, int64_t tr, int& tqi, in
 
 // ------------------------------------------------------------------ threshold compaction
 
-
-__global__ __launch_bounds__(256, 2) void sim_thresh_kernel(SimThreshArgs a) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    int tqi;
-    int64_t tri;
-    if (!raster(blockIdx.x, a.tq, a.tr, tqi, tri)) return;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wr = wave >> 1, wc = wave & 1;
-    TileThread t;
-    tile_thread_init(t, tid, a.dpad);
-    f32x16 acc[2][2];
-#pragma unroll
-    for (int m = 0; m < 2; ++m)
-#pragma unroll
-        for (int n = 0; n < 2; ++n)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.0f;
-
-    const int q0 = tqi * BM;
-    const int64_t r0 = tri * BN;
-    gemm_tile(a.Q + (int64_t)q0 * a.dpad, a.R + r0 * a.dpad, a.dpad, smem, t, acc);
-
-    const float radius = *a.radius;
+// append every accumulator > radius of one 128x128 tile to the hit list (one atomic per wave)
+__device__ __forceinline__ void emit_hits(const SimThreshArgs& a, float radius, int q0, int64_t r0,
+                                          const f32x16 (&acc)[2][2], int lane, int wr, int wc) {
     // C layout of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
     const int row_base = q0 + wr * 64 + 4 * (lane >> 5);
     const int col_base = (int)r0 + wc * 64 + (lane & 31);
@@ -168,6 +241,7 @@ __global__ __launch_bounds__(256, 2) void sim_thresh_kernel(SimThreshArgs a) {
                 const bool hit = (acc[m][n][r] > radius) && (i < a.nq) && (j < a.nr);
                 mask |= (unsigned long long)hit << ((m * 2 + n) * 16 + r);
             }
+    if (!__any(mask != 0ull)) return;
     const int cnt = __popcll(mask);
     int incl = cnt;
 #pragma unroll
@@ -176,7 +250,6 @@ __global__ __launch_bounds__(256, 2) void sim_thresh_kernel(SimThreshArgs a) {
         if (lane >= off) incl += v;
     }
     const int total = __shfl(incl, 63);
-    if (total == 0) return;
     unsigned long long base = 0;
     if (lane == 0) base = atomicAdd(a.counter, (unsigned long long)total);
     base = __shfl(base, 0);
@@ -200,14 +273,58 @@ __global__ __launch_bounds__(256, 2) void sim_thresh_kernel(SimThreshArgs a) {
             }
 }
 
+__global__ __launch_bounds__(256, 2) void sim_thresh_kernel(SimThreshArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int xcd = blockIdx.x & 7;
+    const int64_t lstride = gridDim.x >> 3;  // gridDim.x is a multiple of 8
+    int64_t local = blockIdx.x >> 3;
+    int tqi;
+    int64_t tri;
+    if (!raster(xcd, local, a.tq, a.tr, tqi, tri)) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave >> 1, wc = wave & 1;
+    TileThread t;
+    tile_thread_init(t, tid, a.dpad);
+    const float radius = *a.radius;
+    TileStream st;
+    stream_begin(st, a.Q + (int64_t)tqi * BM * a.dpad, a.R + tri * BN * a.dpad, a.dpad, smem, t);
+    for (;;) {
+        int ntq = 0;
+        int64_t ntr = 0;
+        const bool has_next = raster(xcd, local + lstride, a.tq, a.tr, ntq, ntr);
+        f32x16 acc[2][2];
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int n = 0; n < 2; ++n)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.0f;
+        stream_tile(st, has_next, has_next ? a.Q + (int64_t)ntq * BM * a.dpad : st.q,
+                    has_next ? a.R + ntr * BN * a.dpad : st.r, a.dpad, smem, t, acc);
+        emit_hits(a, radius, tqi * BM, tri * BN, acc, lane, wr, wc);
+        if (!has_next) break;
+        local += lstride;
+        tqi = ntq;
+        tri = ntr;
+    }
+}
+
+static int sim_grid_limit() {
+    static int g = 0;
+    if (g == 0) {
+        const char* e = getenv("VSC_SIM_GRID");
+        g = e ? atoi(e) : 512;  // 2 resident workgroups per CU (64 KiB of LDS each) x 256 CUs
+        if (g < 8) g = 8;
+        g = (g / 8) * 8;
+    }
+    return g;
+}
+
 int launch_sim_thresh(const SimThreshArgs& a, hipStream_t stream) {
     const int64_t nblk = (int64_t)a.tq * a.tr;
-    const int64_t grid = ((nblk + 7) / 8) * 8;
-    if (grid <= 0) return VSC_OK;
-    if (grid > 0x7fffffffLL) {
-        set_error("similarity grid too large (%lld tiles)", (long long)grid);
-        return VSC_ERR_INVALID;
-    }
+    if (nblk <= 0) return VSC_OK;
+    int64_t grid = ((nblk + 7) / 8) * 8;
+    if (grid > sim_grid_limit()) grid = sim_grid_limit();
     hipLaunchKernelGGL(sim_thresh_kernel, dim3((unsigned)grid), dim3(256), GEMM_LDS, stream, a);
     VSC_HIP(hipGetLastError());
     return VSC_OK;
@@ -258,6 +375,19 @@ __global__ __launch_bounds__(256, 1) void sim_knn_kernel(SimKnnArgs a) {
     tile_thread_init(t, tid, a.dpad);
     __syncthreads();
 
+    if (t_begin >= t_end) {
+        // nothing to scan (more runs than reference tiles cannot happen, but stay safe)
+        for (int x = tid; x < BM * k; x += 256) {
+            const int row = x / k, e = x % k;
+            const int64_t o = ((int64_t)(q0 + row) * a.nchunk + chunk) * k + e;
+            a.part_s[o] = -FLT_MAX;
+            a.part_j[o] = -1;
+        }
+        return;
+    }
+    const float* qpanel = a.Q + (int64_t)q0 * a.dpad;
+    TileStream st;
+    stream_begin(st, qpanel, a.R + (int64_t)t_begin * BN * a.dpad, a.dpad, smem, t);
     for (int tri = t_begin; tri < t_end; ++tri) {
         f32x16 acc[2][2];
 #pragma unroll
@@ -267,7 +397,8 @@ __global__ __launch_bounds__(256, 1) void sim_knn_kernel(SimKnnArgs a) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.0f;
         const int r0 = tri * BN;
-        gemm_tile(a.Q + (int64_t)q0 * a.dpad, a.R + (int64_t)r0 * a.dpad, a.dpad, smem, t, acc);
+        stream_tile(st, tri + 1 < t_end, qpanel, tri + 1 < t_end ? a.R + (int64_t)(tri + 1) * BN * a.dpad : st.r, a.dpad,
+                    smem, t, acc);
 
         // survivors of this tile against the thresholds as they stood before the tile
         const int rl_base = wr * 64 + 4 * (lane >> 5);

@@ -36,7 +36,7 @@ void set_error(const char* fmt, ...);
 // consecutive v_mfma_f32_32x32x2_f32 steps: the MFMA chain then runs in ascending k, which is
 // the arithmetic contract shared with the oracle (acc = fmaf(q[k], r[k], acc), k = 0..d-1).
 constexpr int ROW_PAD = 128;
-constexpr int K_PAD = 32;
+constexpr int K_PAD = 64;  // >= 2 K-tiles of 32 per row: the tile stream prefetches two K-tiles ahead
 
 __host__ __device__ inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
 __host__ __device__ inline int64_t round_up64(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
