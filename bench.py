@@ -137,11 +137,19 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (gfx950) GPU: the engine has no CPU fallback")
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+    # VSC_BENCH_SHARE_GPU=1: debugging aid for a 1-GPU box -- all ranks use cuda:0 and the collectives
+    # go over gloo (RCCL cannot place two ranks on one device).  The driver never sets it.
+    share_gpu = os.environ.get("VSC_BENCH_SHARE_GPU") == "1"
+    if share_gpu:
+        local_rank = 0
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if share_gpu:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     from vsc2022_amd.engine import DeviceMatcher
 
@@ -175,7 +183,7 @@ def main():
     dt = time.perf_counter() - t0
     prof = matcher.index.profile_read(reset=True)
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt], dtype=torch.float64, device="cpu" if share_gpu else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     if rank == 0:

@@ -97,6 +97,15 @@ int vsc_index_global_topk(vsc_index_t* idx, const float* q, int64_t nq, int q_me
                           int32_t* out_i, int32_t* out_j, float* out_s, int64_t cap, int out_mem,
                           int64_t* n_out, float* final_radius);
 
+/* Fused candidate generation: vsc_index_global_topk followed by vsc_pair_max without the hit list
+ * leaving HBM -- the whole of CandidateGeneration.query with MaxScoreAggregation
+ * (vsc/candidates.py:36-40 over vsc/index.py:96-165).  row2q[nq] / row2r[ntotal] (host) map frame
+ * rows to video ordinals.  Outputs (host, capacity cap; cap >= min(K, nq*ntotal) suffices): pairs in
+ * score-descending stable order.  *n_hits receives the number of frame hits found (<= K). */
+int vsc_index_candidates(vsc_index_t* idx, const float* q, int64_t nq, int q_mem, int64_t K,
+                         const int32_t* row2q, const int32_t* row2r, int32_t* out_q, int32_t* out_r,
+                         float* out_s, int64_t cap, int64_t* n_pairs, int64_t* n_hits);
+
 /* ------------------------------------------------------- candidate generation
  * Replaces the regroup loop of VideoIndex.search (vsc/index.py:121-140) fused with
  * MaxScoreAggregation + the stable descending sort of CandidateGeneration.query

@@ -88,6 +88,7 @@ struct vsc_index {
     int dim = 0, dpad = 0, metric = 0, device = 0;
     int64_t ntotal = 0, cap_rows = 0;
     DevBuf ref;
+    DevBuf cand[3];  // sorted hits of vsc_index_candidates
     hipStream_t stream = nullptr;
     Workspace ws;
     int64_t hit_cap_user = 0;
@@ -182,6 +183,7 @@ int vsc_index_destroy(vsc_index_t* idx) {
     (void)hipSetDevice(idx->device);
     (void)hipStreamSynchronize(idx->stream);
     idx->ref.release();
+    for (auto& b : idx->cand) b.release();
     idx->ws.release();
     for (auto& e : idx->ev_pool) {
         (void)hipEventDestroy(e.first);
@@ -396,6 +398,57 @@ int vsc_index_global_topk(vsc_index_t* idx, const float* q, int64_t nq, int q_me
     }
     VSC_HIP(hipStreamSynchronize(idx->stream));
     *n_out = mm;
+    return VSC_OK;
+}
+
+int vsc_index_candidates(vsc_index_t* idx, const float* q, int64_t nq, int q_mem, int64_t K,
+                         const int32_t* row2q, const int32_t* row2r, int32_t* out_q, int32_t* out_r,
+                         float* out_s, int64_t cap_out, int64_t* n_pairs, int64_t* n_hits) {
+    if (!idx || nq < 0 || K < 0 || !n_pairs || (nq > 0 && (!q || !row2q || !row2r))) {
+        set_error("vsc_index_candidates: invalid argument");
+        return VSC_ERR_INVALID;
+    }
+    *n_pairs = 0;
+    if (n_hits) *n_hits = 0;
+    if (idx->metric != VSC_METRIC_INNER_PRODUCT) {
+        set_error("vsc_index_candidates: max aggregation needs a larger-is-better metric (inner product)");
+        return VSC_ERR_INVALID;
+    }
+    if (nq == 0 || idx->ntotal == 0 || K == 0) return VSC_OK;
+    VSC_HIP(hipSetDevice(idx->device));
+    // 1. the score-sorted top-K hits stay in HBM
+    const int64_t hcap = std::max<int64_t>(1, std::min<int64_t>(K, nq * idx->ntotal));
+    for (int c = 0; c < 3; ++c) VSC_TRY(idx->cand[c].reserve((size_t)hcap * 4));
+    int64_t n = 0;
+    float radius = 0.0f;
+    VSC_TRY(vsc_index_global_topk(idx, q, nq, q_mem, K, idx->cand[0].as<int32_t>(), idx->cand[1].as<int32_t>(),
+                                  idx->cand[2].as<float>(), hcap, VSC_MEM_DEVICE, &n, &radius));
+    if (n_hits) *n_hits = n;
+    if (n == 0) return VSC_OK;
+    // 2. (query video, ref video) max aggregation on the device
+    Workspace& ws = idx->ws;
+    VSC_TRY(ws.maps0.reserve((size_t)nq * 4));
+    VSC_TRY(ws.maps1.reserve((size_t)idx->ntotal * 4));
+    VSC_HIP(hipMemcpyAsync(ws.maps0.p, row2q, (size_t)nq * 4, hipMemcpyHostToDevice, idx->stream));
+    VSC_HIP(hipMemcpyAsync(ws.maps1.p, row2r, (size_t)idx->ntotal * 4, hipMemcpyHostToDevice, idx->stream));
+    for (int c = 0; c < 3; ++c) VSC_TRY(ws.out[c].reserve((size_t)n * 4));
+    VSC_TRY(ws.out[3].reserve((size_t)n * 8));
+    int64_t np = 0;
+    VSC_TRY(pair_max_device(idx->cand[0].as<int32_t>(), idx->cand[1].as<int32_t>(), idx->cand[2].as<float>(), n,
+                            ws.maps0.as<int32_t>(), ws.maps1.as<int32_t>(), 0, ws.w0, ws.w1, ws.w2, ws.w3, ws.tmp,
+                            ws.cnt, ws.out[0].as<int32_t>(), ws.out[1].as<int32_t>(), ws.out[2].as<float>(),
+                            ws.out[3].as<int64_t>(), n, &np, idx->stream));
+    *n_pairs = np;
+    if (np > cap_out) {
+        set_error("vsc_index_candidates: output capacity %lld < %lld pairs", (long long)cap_out, (long long)np);
+        return VSC_ERR_CAPACITY;
+    }
+    if (np > 0) {
+        VSC_HIP(hipMemcpyAsync(out_q, ws.out[0].p, (size_t)np * 4, hipMemcpyDeviceToHost, idx->stream));
+        VSC_HIP(hipMemcpyAsync(out_r, ws.out[1].p, (size_t)np * 4, hipMemcpyDeviceToHost, idx->stream));
+        VSC_HIP(hipMemcpyAsync(out_s, ws.out[2].p, (size_t)np * 4, hipMemcpyDeviceToHost, idx->stream));
+    }
+    VSC_HIP(hipStreamSynchronize(idx->stream));
     return VSC_OK;
 }
 

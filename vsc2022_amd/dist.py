@@ -50,10 +50,43 @@ def _world(group):
     return dist.get_rank(group), dist.get_world_size(group)
 
 
+def _via_host(t: torch.Tensor, group) -> bool:
+    """gloo only implements a subset of the collectives for device tensors: stage through the host
+    (used by the tests and by single-GPU multi-process debugging; RCCL takes device tensors as is)."""
+    return t.is_cuda and dist.get_backend(group) == "gloo"
+
+
 def _all_reduce_sum(t: torch.Tensor, group) -> torch.Tensor:
     if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+        if _via_host(t, group):
+            h = t.cpu()
+            dist.all_reduce(h, op=dist.ReduceOp.SUM, group=group)
+            t.copy_(h)
+        else:
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
     return t
+
+
+def all_reduce_max_int(v: int, device, group=None) -> int:
+    rank, world = _world(group)
+    if world == 1:
+        return int(v)
+    t = torch.tensor([int(v)], dtype=torch.int64, device=device)
+    if _via_host(t, group):
+        t = t.cpu()
+    dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+    return int(t.item())
+
+
+def all_reduce_sum_int(v: int, device, group=None) -> int:
+    rank, world = _world(group)
+    if world == 1:
+        return int(v)
+    t = torch.tensor([int(v)], dtype=torch.int64, device=device)
+    if _via_host(t, group):
+        t = t.cpu()
+    dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+    return int(t.item())
 
 
 def _all_gather_scalar(v: int, device, group) -> List[int]:
@@ -61,6 +94,8 @@ def _all_gather_scalar(v: int, device, group) -> List[int]:
     if world == 1:
         return [int(v)]
     mine = torch.tensor([int(v)], dtype=torch.int64, device=device)
+    if _via_host(mine, group):
+        mine = mine.cpu()
     out = [torch.zeros_like(mine) for _ in range(world)]
     dist.all_gather(out, mine, group=group)
     return [int(x.item()) for x in out]
@@ -116,11 +151,12 @@ def all_gather_varlen(t: torch.Tensor, group=None) -> torch.Tensor:
     lens = _all_gather_scalar(int(t.shape[0]), t.device, group)
     mx = max(lens)
     pad_shape = (mx,) + tuple(t.shape[1:])
-    padded = torch.zeros(pad_shape, dtype=t.dtype, device=t.device)
+    host = _via_host(t, group)
+    padded = torch.zeros(pad_shape, dtype=t.dtype, device="cpu" if host else t.device)
     padded[: t.shape[0]] = t
     outs = [torch.empty_like(padded) for _ in range(world)]
     dist.all_gather(outs, padded, group=group)
-    return torch.cat([o[:n] for o, n in zip(outs, lens)], dim=0)
+    return torch.cat([o[:n] for o, n in zip(outs, lens)], dim=0).to(t.device)
 
 
 class ShardedCandidates:
@@ -172,12 +208,7 @@ def sharded_hits(local_search, local_matrix_size: int, k_global: int, group=None
         else:
             complete_above = float(radius)      # hits <= radius were dropped by the schedule
         n_take, tau, exact = merge_hits(hs, k_global, complete_above, group)
-        if world > 1:
-            flag = torch.tensor([0 if exact else 1], dtype=torch.int64, device=hs.device if device is None else device)
-            dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=group)
-            all_exact = int(flag.item()) == 0
-        else:
-            all_exact = exact
+        all_exact = all_reduce_max_int(0 if exact else 1, hs.device if device is None else device, group) == 0
         if all_exact or k_local >= k_global:
             return hi[:n_take], hj[:n_take], hs[:n_take], tau
         if not exact:

@@ -203,9 +203,7 @@ class DeviceMatcher:
         mine = (cands.q_vid[:n_loc] >= qvid_base) & (cands.q_vid[:n_loc] < qvid_base + self.n_qvid)
         loc_index = torch.nonzero(mine).flatten()
         nbox, boxes, bmax = self.localize(cands.q_vid[loc_index] - qvid_base, cands.r_vid[loc_index], bias)
-        n_matches = torch.tensor([int(nbox.sum().item())], dtype=torch.int64, device=self.tdev)
-        torch.distributed.all_reduce(n_matches, group=group)
-        n_hits = torch.tensor([n_take], dtype=torch.int64, device=self.tdev)
-        torch.distributed.all_reduce(n_hits, group=group)
-        return MatchResult(int(n_hits.item()), int(ps.numel()), n_cand, n_loc, int(n_matches.item()),
+        n_matches = vdist.all_reduce_sum_int(int(nbox.sum().item()), self.tdev, group)
+        n_hits = vdist.all_reduce_sum_int(n_take, self.tdev, group)
+        return MatchResult(n_hits, int(ps.numel()), n_cand, n_loc, n_matches,
                            cands.q_vid, cands.r_vid, cands.score, loc_index, nbox, boxes, bmax, radius)

@@ -14,7 +14,7 @@ from typing import List
 import numpy as np
 
 from vsc2022_amd import _lib
-from vsc2022_amd.vsc.index import PairMatches, VideoFeature, VideoIndex
+from vsc2022_amd.vsc.index import PairMatches, VideoFeature, VideoIndex, VideoLayout
 from vsc2022_amd.vsc.metrics import CandidatePair
 
 
@@ -96,24 +96,26 @@ class CandidateGeneration:
         return candidates
 
     def _query_max(self, queries: List[VideoFeature], global_k: int) -> CandidateList:
-        hits = self.index.search_hits(queries, global_k)
-        n = len(hits)
-        q_ids, r_ids = hits.q_layout.video_ids, self.index._video_ids
-        if n == 0:
-            e = np.zeros(0, dtype=np.int32)
-            return CandidateList(e, e, np.zeros(0, dtype=np.float32), q_ids, r_ids)
-        row2q = np.ascontiguousarray(hits.q_layout.row2vid, dtype=np.int32)
+        """One call into libvscmi: search + regroup + max + sort, the hit list never leaves HBM."""
+        layout = VideoLayout(queries)
+        feats = VideoLayout.features(queries)
+        q_ids, r_ids = layout.video_ids, self.index._video_ids
+        nq, nr = feats.shape[0], self.index.index.ntotal
+        empty = np.zeros(0, dtype=np.int32)
+        if nq == 0 or nr == 0 or global_k == 0:
+            return CandidateList(empty, empty, np.zeros(0, dtype=np.float32), q_ids, r_ids)
+        if feats.shape[1] != self.index.dim:
+            raise ValueError(f"expected [n, {self.index.dim}] features, got {feats.shape}")
+        row2q = np.ascontiguousarray(layout.row2vid, dtype=np.int32)
         row2r = np.ascontiguousarray(self.index._row2vid, dtype=np.int32)
-        oq = np.empty(n, dtype=np.int32)
-        orr = np.empty(n, dtype=np.int32)
-        os_ = np.empty(n, dtype=np.float32)
-        first = np.empty(n, dtype=np.int64)
-        n_pairs = ctypes.c_int64(0)
-        hi, hj, hs = (np.ascontiguousarray(a) for a in (hits.i, hits.j, hits.s))
-        _lib.check(_lib.lib().vsc_pair_max(
-            hi.ctypes.data, hj.ctypes.data, hs.ctypes.data, n, _lib.MEM_HOST,
-            row2q.ctypes.data, len(row2q), row2r.ctypes.data, len(row2r), _lib.MEM_HOST,
-            oq.ctypes.data, orr.ctypes.data, os_.ctypes.data, first.ctypes.data, n, _lib.MEM_HOST,
-            ctypes.byref(n_pairs), self.index.index.device))
+        cap = int(max(1, min(int(global_k), nq * nr)))
+        oq = np.empty(cap, dtype=np.int32)
+        orr = np.empty(cap, dtype=np.int32)
+        os_ = np.empty(cap, dtype=np.float32)
+        n_pairs, n_hits = ctypes.c_int64(0), ctypes.c_int64(0)
+        _lib.check(_lib.lib().vsc_index_candidates(
+            self.index.index.handle, feats.ctypes.data, nq, _lib.MEM_HOST, int(global_k), row2q.ctypes.data,
+            row2r.ctypes.data, oq.ctypes.data, orr.ctypes.data, os_.ctypes.data, cap, ctypes.byref(n_pairs),
+            ctypes.byref(n_hits)))
         m = n_pairs.value
-        return CandidateList(oq[:m], orr[:m], os_[:m], q_ids, r_ids)
+        return CandidateList(oq[:m].copy(), orr[:m].copy(), os_[:m].copy(), q_ids, r_ids)
