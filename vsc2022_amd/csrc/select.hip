@@ -69,27 +69,52 @@ __global__ __launch_bounds__(256) void select_compact_kernel(SelectCtl* c, const
                                                              const int32_t* aj, const float* as,
                                                              int32_t* bi, int32_t* bj, float* bs) {
     if (!c->active) return;
+    // One global atomic per 2048-element chunk (not per wavefront): with tens of millions of kept
+    // hits the single counter would otherwise serialise the whole pass.
+    constexpr int PER_THREAD = 8, CHUNK = 256 * PER_THREAD;
+    __shared__ unsigned int wave_cnt[4];
+    __shared__ unsigned long long chunk_base;
     const unsigned long long n = c->n;
     const float radius = c->radius;
-    const int lane = threadIdx.x & 63;
-    const unsigned long long stride = (unsigned long long)gridDim.x * 256;
-    const unsigned long long n_round = (n + 255) / 256 * 256;
-    for (unsigned long long x = (unsigned long long)blockIdx.x * 256 + threadIdx.x; x < n_round;
-         x += stride) {
-        const bool in = x < n;
-        const float s = in ? as[x] : 0.0f;
-        const bool keep = in && (s > radius);
-        const unsigned long long m = __ballot(keep);
-        if (!m) continue;
-        unsigned long long base = 0;
-        if (lane == 0) base = atomicAdd(&c->n_tmp, (unsigned long long)__popcll(m));
-        base = __shfl(base, 0);
-        if (keep) {
-            const unsigned long long pos = base + __popcll(m & ((1ull << lane) - 1));
-            bi[pos] = ai[x];
-            bj[pos] = aj[x];
-            bs[pos] = s;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const unsigned long long n_chunks = (n + CHUNK - 1) / CHUNK;
+    for (unsigned long long ch = blockIdx.x; ch < n_chunks; ch += gridDim.x) {
+        const unsigned long long x0 = ch * CHUNK + threadIdx.x;
+        float s[PER_THREAD];
+        unsigned int keep_bits = 0;
+#pragma unroll
+        for (int e = 0; e < PER_THREAD; ++e) {
+            const unsigned long long x = x0 + (unsigned long long)e * 256;
+            s[e] = x < n ? as[x] : 0.0f;
+            keep_bits |= (unsigned int)((x < n) && (s[e] > radius)) << e;
         }
+        // order inside the chunk: element-slot major, then thread -- any order is fine (sorted later)
+        unsigned int mine = __popc(keep_bits), incl = mine;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const unsigned int v = __shfl_up(incl, off);
+            if (lane >= off) incl += v;
+        }
+        if (lane == 63) wave_cnt[wave] = incl;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const unsigned int tot = wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
+            chunk_base = tot ? atomicAdd(&c->n_tmp, (unsigned long long)tot) : 0ull;
+        }
+        __syncthreads();
+        unsigned long long pos = chunk_base + (incl - mine);
+        for (int w = 0; w < wave; ++w) pos += wave_cnt[w];
+#pragma unroll
+        for (int e = 0; e < PER_THREAD; ++e) {
+            if ((keep_bits >> e) & 1u) {
+                const unsigned long long x = x0 + (unsigned long long)e * 256;
+                bi[pos] = ai[x];
+                bj[pos] = aj[x];
+                bs[pos] = s[e];
+                ++pos;
+            }
+        }
+        __syncthreads();  // wave_cnt / chunk_base are reused by the next chunk
     }
 }
 
