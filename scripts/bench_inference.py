@@ -1,0 +1,38 @@
+#!/usr/bin/env python3
+"""BASELINE config 3: SSCD-shaped ResNet-50 @1fps frame inference on synthetic videos, PyTorch-ROCm,
+one GPU.  Reports frames/s and videos/s for fp32 and bf16/fp16 autocast (channels-last), per-video
+batches (the reference's batching) and packed batches."""
+import argparse
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+
+from vsc2022_amd.vsc.baseline.inference import (SyntheticVideos, build_sscd_model, run_inference,
+                                                run_inference_packed)
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--videos", type=int, default=512)
+ap.add_argument("--frames", type=int, default=25)
+ap.add_argument("--batch", type=int, default=32)
+ap.add_argument("--packed-batch", type=int, default=128)
+args = ap.parse_args()
+dev = torch.device("cuda", 0)
+model = build_sscd_model(device=dev)
+src = SyntheticVideos(n_videos=args.videos, frames=(args.frames, args.frames), size=320)
+warm = SyntheticVideos(n_videos=16, frames=(args.frames, args.frames), size=320)
+for name, dt in (("fp32", None), ("bf16-autocast", torch.bfloat16), ("fp16-autocast", torch.float16)):
+    for mode, fn, bs in (("per-video", run_inference, args.batch), ("packed", run_inference_packed, args.packed_batch)):
+        for _ in fn(model, warm, dev, bs, dt):
+            pass
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        n = 0
+        for _, d in fn(model, src, dev, bs, dt):
+            n += d.shape[0]
+        torch.cuda.synchronize()
+        dtm = time.perf_counter() - t0
+        print(f"{name:14s} {mode:9s} batch<={bs:4d}: {n} frames in {dtm:.2f} s = {n / dtm:8.1f} frames/s "
+              f"{args.videos / dtm:7.1f} videos/s")

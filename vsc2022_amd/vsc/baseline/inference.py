@@ -1,0 +1,225 @@
+"""Frame-descriptor inference on PyTorch-ROCm (BASELINE config 3).
+
+Mirror of the *contract* of the reference's `vsc/baseline/inference.py` / `inference_impl.py`
+(paths relative to /root/reference): frames at 1 fps -> [B, 3, 320, 320] normalised tensors
+(`inference_impl.py:39-69`) -> model -> one [n_frames, 512] descriptor block per video with
+`(i/fps, (i+1)/fps)` timestamps (`video_reader/ffmpeg_video_reader.py:54`), videos partitioned over
+ranks by `video_idx % world_size == rank` (`inference_impl.py:105-109`), batches of <= 32 frames of
+a single video (`inference.py:58,65`, `inference_impl.py:210-239`).
+
+What differs, deliberately:
+  * no ffmpeg / TorchScript file: there is neither a decoder nor SSCD weights in this environment
+    (no network), so frames come from a seeded synthetic source and the model is a random-init
+    network of the SSCD architecture (ResNet-50 trunk + GeM + Linear(2048 -> 512), the trailing
+    L2-norm removed as `adapt_sscd_model.py:54-77` does);
+  * this is stock PyTorch-ROCm (MIOpen convolutions): the north-star keeps frame inference off
+    the hand-written-kernel path;
+  * descriptors can be handed to the matching engine as device tensors (no `.npz` round trip,
+    no `.cpu()` per batch as in `inference_impl.py:228-229`).
+"""
+from dataclasses import dataclass
+from typing import Iterator, List, Optional, Tuple
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from vsc2022_amd.vsc.index import VideoFeature
+
+IMAGENET_MEAN = (0.485, 0.456, 0.406)
+IMAGENET_STD = (0.229, 0.224, 0.225)
+
+
+class Bottleneck(nn.Module):
+    expansion = 4
+
+    def __init__(self, inplanes: int, planes: int, stride: int = 1):
+        super().__init__()
+        self.conv1 = nn.Conv2d(inplanes, planes, 1, bias=False)
+        self.bn1 = nn.BatchNorm2d(planes)
+        self.conv2 = nn.Conv2d(planes, planes, 3, stride=stride, padding=1, bias=False)
+        self.bn2 = nn.BatchNorm2d(planes)
+        self.conv3 = nn.Conv2d(planes, planes * 4, 1, bias=False)
+        self.bn3 = nn.BatchNorm2d(planes * 4)
+        self.down = None
+        if stride != 1 or inplanes != planes * 4:
+            self.down = nn.Sequential(nn.Conv2d(inplanes, planes * 4, 1, stride=stride, bias=False),
+                                      nn.BatchNorm2d(planes * 4))
+
+    def forward(self, x):
+        idt = x if self.down is None else self.down(x)
+        x = F.relu(self.bn1(self.conv1(x)), inplace=True)
+        x = F.relu(self.bn2(self.conv2(x)), inplace=True)
+        x = self.bn3(self.conv3(x))
+        return F.relu(x + idt, inplace=True)
+
+
+class SSCDModel(nn.Module):
+    """ResNet-50 trunk -> GeM(p=3) -> Linear(2048 -> dims); no final L2 normalisation."""
+
+    def __init__(self, dims: int = 512, gem_p: float = 3.0):
+        super().__init__()
+        self.stem = nn.Sequential(nn.Conv2d(3, 64, 7, stride=2, padding=3, bias=False), nn.BatchNorm2d(64),
+                                  nn.ReLU(inplace=True), nn.MaxPool2d(3, stride=2, padding=1))
+        layers, inplanes = [], 64
+        for planes, blocks, stride in ((64, 3, 1), (128, 4, 2), (256, 6, 2), (512, 3, 2)):
+            for b in range(blocks):
+                layers.append(Bottleneck(inplanes, planes, stride if b == 0 else 1))
+                inplanes = planes * 4
+        self.trunk = nn.Sequential(*layers)
+        self.gem_p = gem_p
+        self.embed = nn.Linear(2048, dims)
+
+    def forward(self, x):
+        x = self.trunk(self.stem(x))
+        x = x.float().clamp(min=1e-6).pow(self.gem_p).mean(dim=(2, 3)).pow(1.0 / self.gem_p)
+        return self.embed(x)
+
+
+def build_sscd_model(dims: int = 512, seed: int = 0, device="cpu", channels_last: bool = True) -> SSCDModel:
+    torch.manual_seed(seed)
+    model = SSCDModel(dims).eval().to(device)
+    if channels_last:
+        model = model.to(memory_format=torch.channels_last)
+    for p in model.parameters():
+        p.requires_grad_(False)
+    return model
+
+
+@dataclass
+class SyntheticVideos:
+    """Seeded stand-in for the ffmpeg reader: `n_videos` videos of `frames` (min, max) uint8 frames."""
+
+    n_videos: int
+    frames: Tuple[int, int] = (25, 25)
+    size: int = 320
+    fps: float = 1.0
+    seed: int = 2
+    prefix: str = "Q"
+
+    def lengths(self) -> np.ndarray:
+        rng = np.random.default_rng(self.seed)
+        lo, hi = self.frames
+        return rng.integers(lo, hi + 1, self.n_videos) if hi > lo else np.full(self.n_videos, lo)
+
+    def video(self, idx: int, n_frames: int, device) -> torch.Tensor:
+        g = torch.Generator(device=device)
+        g.manual_seed(self.seed * 1000003 + idx)
+        return torch.randint(0, 256, (n_frames, 3, self.size, self.size), generator=g, device=device,
+                             dtype=torch.uint8)
+
+    def timestamps(self, n_frames: int) -> np.ndarray:
+        i = np.arange(n_frames, dtype=np.float32)
+        return np.stack([i / self.fps, (i + 1) / self.fps], axis=1).astype(np.float32)
+
+
+def preprocess(frames_u8: torch.Tensor, channels_last: bool = True) -> torch.Tensor:
+    """ToTensor + Normalize of `inference_impl.py:50-58` on the device (frames already 320x320)."""
+    x = frames_u8.float().div_(255.0)
+    mean = torch.tensor(IMAGENET_MEAN, device=x.device).view(1, 3, 1, 1)
+    std = torch.tensor(IMAGENET_STD, device=x.device).view(1, 3, 1, 1)
+    x = (x - mean) / std
+    return x.contiguous(memory_format=torch.channels_last) if channels_last else x
+
+
+@torch.no_grad()
+def run_inference(model: nn.Module, source: SyntheticVideos, device, batch_size: int = 32,
+                  autocast_dtype: Optional[torch.dtype] = None, rank: int = 0, world_size: int = 1,
+                  channels_last: bool = True) -> Iterator[Tuple[int, torch.Tensor]]:
+    """Yields (video index, [n_frames, dims] fp32 descriptors on `device`) for this rank's videos."""
+    assert rank < world_size
+    lengths = source.lengths()
+    use_amp = autocast_dtype is not None and torch.device(device).type == "cuda"
+    for idx in range(source.n_videos):
+        if idx % world_size != rank:
+            continue
+        frames = source.video(idx, int(lengths[idx]), device)
+        outs = []
+        for b0 in range(0, frames.shape[0], batch_size):  # batches never mix videos (inference.py:58)
+            x = preprocess(frames[b0 : b0 + batch_size], channels_last)
+            if use_amp:
+                with torch.autocast("cuda", dtype=autocast_dtype):
+                    y = model(x)
+            else:
+                y = model(x)
+            outs.append(y.float())
+        yield idx, torch.cat(outs, dim=0)
+
+
+@torch.no_grad()
+def run_inference_packed(model: nn.Module, source: SyntheticVideos, device, batch_size: int = 128,
+                         autocast_dtype: Optional[torch.dtype] = None, rank: int = 0, world_size: int = 1,
+                         channels_last: bool = True) -> Iterator[Tuple[int, torch.Tensor]]:
+    """Same results as run_inference, but frames of consecutive videos share a batch.
+
+    The reference never mixes videos in a batch (an artefact of its per-video DataLoader); in eval
+    mode the network treats every frame independently, so packing 25-frame videos into batches of
+    128 only changes MIOpen's efficiency (measured on MI355X, bf16: 5.4 k -> 9.0 k frames/s).
+    """
+    assert rank < world_size
+    lengths = source.lengths()
+    use_amp = autocast_dtype is not None and torch.device(device).type == "cuda"
+    pending: List[Tuple[int, int]] = []   # (video idx, n_frames) in batch order
+    frames: List[torch.Tensor] = []
+    done: List[torch.Tensor] = []         # descriptor blocks not yet assigned to a video
+
+    def flush(n_take):
+        batch = torch.cat(frames, dim=0)
+        x = preprocess(batch[:n_take], channels_last)
+        if use_amp:
+            with torch.autocast("cuda", dtype=autocast_dtype):
+                y = model(x)
+        else:
+            y = model(x)
+        rest = batch[n_take:]
+        frames.clear()
+        if rest.shape[0]:
+            frames.append(rest)
+        done.append(y.float())
+
+    def drain():
+        have = sum(d.shape[0] for d in done)
+        while pending and pending[0][1] <= have:
+            idx, n = pending.pop(0)
+            buf = torch.cat(done, dim=0)
+            done.clear()
+            if buf.shape[0] > n:
+                done.append(buf[n:])
+            have -= n
+            yield idx, buf[:n]
+
+    for idx in range(source.n_videos):
+        if idx % world_size != rank:
+            continue
+        n = int(lengths[idx])
+        frames.append(source.video(idx, n, device))
+        pending.append((idx, n))
+        while sum(f.shape[0] for f in frames) >= batch_size:
+            flush(batch_size)
+            yield from drain()
+    if frames and sum(f.shape[0] for f in frames):
+        flush(sum(f.shape[0] for f in frames))
+    yield from drain()
+
+
+def to_video_features(results, source: SyntheticVideos) -> List[VideoFeature]:
+    """Host-side VideoFeature list (what `store_features` / the `.npz` route expects)."""
+    out = []
+    for idx, desc in results:
+        out.append(VideoFeature(video_id=f"{source.prefix}{idx:06d}", timestamps=source.timestamps(desc.shape[0]),
+                                feature=desc.cpu().numpy()))
+    return out
+
+
+def to_flat(results) -> Tuple[torch.Tensor, np.ndarray, List[int]]:
+    """Device-resident hand-off into the matching engine: (features [rows, dims], row offsets, video idx)."""
+    idxs, blocks = [], []
+    for idx, desc in results:
+        idxs.append(idx)
+        blocks.append(desc)
+    lens = np.array([b.shape[0] for b in blocks], dtype=np.int64)
+    off = np.zeros(len(blocks) + 1, dtype=np.int64)
+    np.cumsum(lens, out=off[1:])
+    feats = torch.cat(blocks, dim=0) if blocks else torch.zeros((0, 0))
+    return feats, off, idxs
