@@ -116,3 +116,41 @@ def test_prefix_select_single_process_properties():
         assert n_take == min(n, k)
         if 0 < k < n:
             assert tau == x[k - 1]
+
+
+def _knn_worker(rank, world, port, out_path):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        sys.path[:0] = [ROOT, os.path.join(ROOT, "oracle")]
+        import oracle as orc
+        from vsc2022_amd import dist as vdist
+
+        rng = np.random.default_rng(3)
+        q = rng.standard_normal((40, 16)).astype(np.float32)
+        r = rng.standard_normal((90, 16)).astype(np.float32)
+        r[50:60] = r[10:20]  # exact duplicates across the shard boundary -> ties resolved by global id
+        lo, hi = vdist.shard_ranges(len(r), world)[rank]
+        D, I = orc.knn(q, r[lo:hi], 7)
+        I = np.where(I >= 0, I + lo, -1)
+        gD, gI = vdist.ref_sharded_knn(torch.from_numpy(D), torch.from_numpy(I), 7)
+        if rank == 0:
+            np.savez(out_path, D=gD.numpy(), I=gI.numpy())
+    finally:
+        dist.destroy_process_group()
+
+
+def test_ref_sharded_knn_merge_equals_single_index(tmp_path):
+    sys.path[:0] = [ROOT, os.path.join(ROOT, "oracle")]
+    import oracle as orc
+
+    out = str(tmp_path / "knn.npz")
+    mp.spawn(_knn_worker, args=(3, 29900 + os.getpid() % 1000, out), nprocs=3, join=True)
+    got = np.load(out)
+    rng = np.random.default_rng(3)
+    q = rng.standard_normal((40, 16)).astype(np.float32)
+    r = rng.standard_normal((90, 16)).astype(np.float32)
+    r[50:60] = r[10:20]
+    D, I = orc.knn(q, r, 7)
+    assert np.array_equal(got["I"], I) and np.array_equal(got["D"].view(np.uint32), D.view(np.uint32))
