@@ -1,36 +1,36 @@
-"""Descriptor-track evaluation on the MI355X engine.
+"""Descriptor-track evaluation from the command line, on the MI355X engine.
 
-Same flags and outputs as the reference's `descriptor_eval.py` (:16-58):
+Accepts the flags of the reference's `descriptor_eval.py` (:16-35):
+
     python -m vsc2022_amd.cli.descriptor_eval --query_features q.npz --ref_features r.npz \
         [--ground_truth gt.csv] [--candidates_output candidates.csv]
 """
 import argparse
 import logging
 
-from vsc2022_amd.vsc.descriptor_eval_lib import evaluate_descriptor_track
-from vsc2022_amd.vsc.metrics import CandidatePair
+from vsc2022_amd.vsc import descriptor_eval_lib, metrics
 
-log = logging.getLogger("descriptor_eval_lib.py")
-
-
-def build_parser() -> argparse.ArgumentParser:
-    p = argparse.ArgumentParser(description=__doc__.splitlines()[0])
-    p.add_argument("--query_features", required=True, type=str, help="Path containing query features")
-    p.add_argument("--ref_features", required=True, type=str, help="Path containing reference features")
-    p.add_argument("--candidates_output", type=str, help="Path to write candidates (optional)")
-    p.add_argument("--ground_truth", type=str, help="Path containing Groundtruth")
-    return p
+FLAGS = (
+    # name, required, help
+    ("--query_features", True, "query descriptors (.npz)"),
+    ("--ref_features", True, "reference descriptors (.npz)"),
+    ("--candidates_output", False, "where to write the candidate pairs (CSV, optional)"),
+    ("--ground_truth", False, "ground-truth CSV; enables the micro-AP report"),
+)
 
 
 def main(argv=None):
-    args = build_parser().parse_args(argv)
-    logging.basicConfig(format="%(asctime)s %(levelname)-8s %(message)s", level=logging.INFO,
-                        datefmt="%Y-%m-%d %H:%M:%S")
-    log.setLevel(logging.INFO)
-    ap, candidates = evaluate_descriptor_track(args.query_features, args.ref_features, args.ground_truth)
+    parser = argparse.ArgumentParser(description="descriptor track: search + candidate micro-AP")
+    for name, required, text in FLAGS:
+        parser.add_argument(name, required=required, type=str, help=text)
+    args = parser.parse_args(argv)
+    logging.basicConfig(level=logging.INFO, datefmt="%Y-%m-%d %H:%M:%S",
+                        format="%(asctime)s %(levelname)-8s %(message)s")
+    ap, candidates = descriptor_eval_lib.evaluate_descriptor_track(args.query_features, args.ref_features,
+                                                                   args.ground_truth)
     if args.candidates_output:
-        log.info(f"Storing candidates to {args.candidates_output}")
-        CandidatePair.write_csv(candidates, args.candidates_output)
+        metrics.CandidatePair.write_csv(candidates, args.candidates_output)
+        logging.getLogger("descriptor_eval").info("wrote %d candidates to %s", len(candidates), args.candidates_output)
     return ap, candidates
 
 

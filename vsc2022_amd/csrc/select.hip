@@ -17,7 +17,10 @@ __global__ void select_begin_kernel(SelectCtl* c, unsigned long long max_results
                                     unsigned long long min_results) {
     if (threadIdx.x < 256) c->hist[threadIdx.x] = 0;
     if (threadIdx.x == 0) {
-        const bool act = c->n > max_results;
+        // After an overflow c->n counts hits that were never stored (it may exceed the buffer):
+        // the host reruns the whole schedule with a larger buffer, so every later round is a no-op
+        // instead of walking past the end of the hit arrays.
+        const bool act = !c->overflow && c->n > max_results;
         c->active = act ? 1 : 0;
         c->prefix = 0;
         c->prefix_mask = 0;

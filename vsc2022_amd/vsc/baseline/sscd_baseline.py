@@ -1,7 +1,9 @@
-"""End-to-end matching baseline on SSCD descriptors: mirror of the reference's
-`vsc/baseline/sscd_baseline.py` (same functions, flags, constants and output files; paths relative
-to /root/reference), running search, candidate generation, score normalisation and Temporal-Network
-localisation on the MI355X engine.
+"""SSCD matching baseline on the MI355X engine: search -> candidates -> (score normalisation) ->
+Temporal-Network localisation -> CSV files -> metrics.
+
+Drop-in for `python -m vsc.baseline.sscd_baseline` of the reference (same flags, same output files
+`candidates.csv` / `matches.csv` / `sn_*.npz`, same module-level functions `search`,
+`localize_and_verify`, `match`, `main`; /root/reference/vsc/baseline/sscd_baseline.py:54-231).
 
     python -m vsc2022_amd.vsc.baseline.sscd_baseline --query_features q.npz --ref_features r.npz \
         --output_path out/ [--score_norm_features noise.npz] [--ground_truth gt.csv] [--overwrite]
@@ -9,85 +11,87 @@ localisation on the MI355X engine.
 import argparse
 import logging
 import os
-from typing import List, Tuple
+from dataclasses import dataclass
+from typing import List, Optional, Sequence, Tuple
 
-from vsc2022_amd.vsc.baseline.localization import VCSLLocalizationCandidateScore, VCSLLocalizationMaxSim
+from vsc2022_amd.vsc import metrics as M
+from vsc2022_amd.vsc import storage
+from vsc2022_amd.vsc.baseline import localization as loc
 from vsc2022_amd.vsc.baseline.score_normalization import _normalize_videos, score_normalize
 from vsc2022_amd.vsc.candidates import CandidateGeneration, MaxScoreAggregation
 from vsc2022_amd.vsc.index import VideoFeature
-from vsc2022_amd.vsc.metrics import (AveragePrecision, CandidatePair, Dataset, Match, average_precision,
-                                     evaluate_matching_track)
-from vsc2022_amd.vsc.storage import load_features, store_features
 
 logger = logging.getLogger("sscd_baseline.py")
 logger.setLevel(logging.INFO)
 
-# pipeline constants of the reference (sscd_baseline.py:93-94,111,139,118-135,198)
-RETRIEVE_PER_QUERY = 1200.0
-CANDIDATES_PER_QUERY = 25.0
-LOCALIZE_PER_QUERY = 5.0
-BATCH_SIZE = 512
-TN_ARGS = dict(model_type="TN", tn_max_step=5, min_length=4, concurrency=16)
-SCORE_NORM_BIAS = 0.5
-SCORE_NORM_BETA = 1.2
+
+@dataclass(frozen=True)
+class PipelineConstants:
+    """The reference's hard-coded tuning (sscd_baseline.py:93-94,111,121-125,139,198)."""
+
+    retrieve_per_query: float = 1200.0   # frame hits searched for, per query video
+    candidates_per_query: float = 25.0   # (query, ref) pairs kept
+    localize_per_query: float = 5.0      # pairs handed to the aligner
+    batch_size: int = 512                # pairs per localize_all call
+    tn_max_step: int = 5
+    tn_min_length: int = 4
+    tn_concurrency: int = 16             # accepted for compatibility; the GPU aligns a whole batch at once
+    score_norm_bias: float = 0.5
+    score_norm_beta: float = 1.2
 
 
-def build_parser() -> argparse.ArgumentParser:
-    p = argparse.ArgumentParser()
-    p.add_argument("--query_features", help="Path to query descriptors", type=str, required=True)
-    p.add_argument("--ref_features", help="Path to reference descriptors", type=str, required=True)
-    p.add_argument("--score_norm_features", help="Path to score normalization descriptors", type=str)
-    p.add_argument("--output_path", help="The path to write match predictions.", type=str, required=True)
-    p.add_argument("--ground_truth", help="Path to the ground truth (labels) CSV file.", type=str)
-    p.add_argument("--overwrite", help="Overwrite prediction files, if found.", action="store_true")
-    return p
+CONSTANTS = PipelineConstants()
 
 
-def search(queries: List[VideoFeature], refs: List[VideoFeature], retrieve_per_query: float = RETRIEVE_PER_QUERY,
-           candidates_per_query: float = CANDIDATES_PER_QUERY) -> List[CandidatePair]:
-    """sscd_baseline.py:90-104"""
-    logger.info("Searching")
-    cg = CandidateGeneration(refs, MaxScoreAggregation())
-    candidates = cg.query(queries, global_k=int(retrieve_per_query * len(queries)))
-    candidates = candidates[: int(candidates_per_query * len(queries))]
-    logger.info("Got %d candidates", len(candidates))
-    return candidates
+def search(queries: List[VideoFeature], refs: List[VideoFeature],
+           retrieve_per_query: float = CONSTANTS.retrieve_per_query,
+           candidates_per_query: float = CONSTANTS.candidates_per_query) -> List[M.CandidatePair]:
+    """Best `candidates_per_query * len(queries)` video pairs by max frame similarity."""
+    n_hits = int(retrieve_per_query * len(queries))
+    n_keep = int(candidates_per_query * len(queries))
+    pairs = CandidateGeneration(refs, MaxScoreAggregation()).query(queries, global_k=n_hits)[:n_keep]
+    logger.info("search: %d candidate pairs from the %d best frame hits", len(pairs), n_hits)
+    return pairs
 
 
-def localize_and_verify(queries: List[VideoFeature], refs: List[VideoFeature], candidates: List[CandidatePair],
-                        localize_per_query: float = LOCALIZE_PER_QUERY, score_normalization: bool = False
-                        ) -> List[Match]:
-    """sscd_baseline.py:107-152"""
-    candidates = candidates[: int(len(queries) * localize_per_query)]
+def _aligner(queries, refs, score_normalization: bool) -> loc.VCSLLocalization:
+    tn = dict(model_type="TN", tn_max_step=CONSTANTS.tn_max_step, min_length=CONSTANTS.tn_min_length,
+              concurrency=CONSTANTS.tn_concurrency)
     if score_normalization:
-        alignment = VCSLLocalizationMaxSim(queries, refs, similarity_bias=SCORE_NORM_BIAS, **TN_ARGS)
-    else:
-        alignment = VCSLLocalizationCandidateScore(_normalize_videos(queries), _normalize_videos(refs), **TN_ARGS)
-    matches: List[Match] = []
-    logger.info("Aligning %s candidate pairs", len(candidates))
-    done = 0
-    while done < len(candidates):
-        batch = candidates[done : done + BATCH_SIZE]
-        matches.extend(alignment.localize_all(batch))
-        done += len(batch)
-        logger.info("Aligned %d pairs of %d; %d predictions so far", done, len(candidates), len(matches))
-    return matches
+        # score-normalised similarities live around zero: shift them for the aligner, score boxes by
+        # their best frame similarity
+        return loc.VCSLLocalizationMaxSim(queries, refs, similarity_bias=CONSTANTS.score_norm_bias, **tn)
+    # plain descriptors: align on cosine similarity, score boxes with the candidate's retrieval score
+    return loc.VCSLLocalizationCandidateScore(_normalize_videos(queries), _normalize_videos(refs), **tn)
+
+
+def localize_and_verify(queries: List[VideoFeature], refs: List[VideoFeature], candidates: Sequence[M.CandidatePair],
+                        localize_per_query: float = CONSTANTS.localize_per_query,
+                        score_normalization: bool = False) -> List[M.Match]:
+    """Temporal-Network boxes for the best `localize_per_query * len(queries)` candidates."""
+    todo = candidates[: int(len(queries) * localize_per_query)]
+    aligner = _aligner(queries, refs, score_normalization)
+    found: List[M.Match] = []
+    for start in range(0, len(todo), CONSTANTS.batch_size):
+        found += aligner.localize_all(todo[start : start + CONSTANTS.batch_size])
+        logger.info("localised %d / %d pairs, %d segments so far", min(start + CONSTANTS.batch_size, len(todo)),
+                    len(todo), len(found))
+    return found
 
 
 def match(queries: List[VideoFeature], refs: List[VideoFeature], output_path: str,
           score_normalization: bool = False) -> Tuple[str, str]:
-    """sscd_baseline.py:155-176: writes candidates.csv and matches.csv."""
-    candidates = search(queries, refs)
+    """Runs the matching pipeline; returns the paths of candidates.csv and matches.csv."""
     os.makedirs(output_path, exist_ok=True)
     candidate_file = os.path.join(output_path, "candidates.csv")
-    CandidatePair.write_csv(candidates, candidate_file)
-    matches = localize_and_verify(queries, refs, candidates, score_normalization=score_normalization)
     matches_file = os.path.join(output_path, "matches.csv")
-    Match.write_csv(matches, matches_file)
+    pairs = search(queries, refs)
+    M.CandidatePair.write_csv(pairs, candidate_file)
+    M.Match.write_csv(localize_and_verify(queries, refs, pairs, score_normalization=score_normalization), matches_file)
     return candidate_file, matches_file
 
 
-def create_pr_plot(ap: AveragePrecision, filename: str):
+def create_pr_plot(ap: M.AveragePrecision, filename: str):
     import matplotlib.pyplot as plt
 
     ap.pr_curve.plot(linewidth=1)
@@ -95,36 +99,47 @@ def create_pr_plot(ap: AveragePrecision, filename: str):
     plt.show()
 
 
+def _report(output_path: str, ground_truth: str, candidate_file: str, match_file: str):
+    truth = M.CandidatePair.from_matches(M.Match.read_csv(ground_truth, is_gt=True))
+    uap = M.average_precision(truth, M.CandidatePair.read_csv(candidate_file))
+    tracks = M.evaluate_matching_track(ground_truth, match_file)
+    logger.info("Candidate uAP: %.4f", uap.ap)
+    logger.info("Matching track metric: %.4f", tracks.segment_ap.ap)
+    for curve, name in ((uap, "candidate_precision_recall.pdf"), (tracks.segment_ap, "precision_recall.pdf")):
+        target = os.path.join(output_path, name)
+        create_pr_plot(curve, target)
+        logger.info("PR plot: %s", target)
+    logger.info("Candidates: %s", candidate_file)
+    logger.info("Matches: %s", match_file)
+
+
+def build_parser() -> argparse.ArgumentParser:
+    p = argparse.ArgumentParser(description="SSCD matching baseline on MI355X")
+    for flag, text, required in (("--query_features", "Path to query descriptors", True),
+                                 ("--ref_features", "Path to reference descriptors", True),
+                                 ("--score_norm_features", "Path to score normalization descriptors", False),
+                                 ("--output_path", "The path to write match predictions.", True),
+                                 ("--ground_truth", "Path to the ground truth (labels) CSV file.", False)):
+        p.add_argument(flag, help=text, type=str, required=required)
+    p.add_argument("--overwrite", help="Overwrite prediction files, if found.", action="store_true")
+    return p
+
+
 def main(args):
-    """sscd_baseline.py:185-231"""
     if os.path.exists(args.output_path) and not args.overwrite:
         raise Exception(f"Output path already exists: {args.output_path}. Do you want to --overwrite?")
-    queries = load_features(args.query_features, Dataset.QUERIES)
-    refs = load_features(args.ref_features, Dataset.REFS)
-    score_normalization = False
-    if args.score_norm_features:
-        queries, refs = score_normalize(queries, refs, load_features(args.score_norm_features, Dataset.REFS),
-                                        beta=SCORE_NORM_BETA)
-        score_normalization = True
+    queries = storage.load_features(args.query_features, M.Dataset.QUERIES)
+    refs = storage.load_features(args.ref_features, M.Dataset.REFS)
+    normalised = bool(args.score_norm_features)
+    if normalised:
+        noise = storage.load_features(args.score_norm_features, M.Dataset.REFS)
+        queries, refs = score_normalize(queries, refs, noise, beta=CONSTANTS.score_norm_beta)
         os.makedirs(args.output_path, exist_ok=True)
-        store_features(os.path.join(args.output_path, "sn_queries.npz"), queries)
-        store_features(os.path.join(args.output_path, "sn_refs.npz"), refs)
-    candidate_file, match_file = match(queries, refs, args.output_path, score_normalization=score_normalization)
-    if not args.ground_truth:
-        return
-    gt_pairs = CandidatePair.from_matches(Match.read_csv(args.ground_truth, is_gt=True))
-    candidate_uap = average_precision(gt_pairs, CandidatePair.read_csv(candidate_file))
-    logger.info(f"Candidate uAP: {candidate_uap.ap:.4f}")
-    candidate_pr_file = os.path.join(args.output_path, "candidate_precision_recall.pdf")
-    create_pr_plot(candidate_uap, candidate_pr_file)
-    match_metrics = evaluate_matching_track(args.ground_truth, match_file)
-    logger.info(f"Matching track metric: {match_metrics.segment_ap.ap:.4f}")
-    matching_pr_file = os.path.join(args.output_path, "precision_recall.pdf")
-    create_pr_plot(match_metrics.segment_ap, matching_pr_file)
-    logger.info(f"Candidates: {candidate_file}")
-    logger.info(f"Matches: {match_file}")
-    logger.info(f"Candidate PR plot: {candidate_pr_file}")
-    logger.info(f"Match PR plot: {matching_pr_file}")
+        storage.store_features(os.path.join(args.output_path, "sn_queries.npz"), queries)
+        storage.store_features(os.path.join(args.output_path, "sn_refs.npz"), refs)
+    candidate_file, match_file = match(queries, refs, args.output_path, score_normalization=normalised)
+    if args.ground_truth:
+        _report(args.output_path, args.ground_truth, candidate_file, match_file)
 
 
 if __name__ == "__main__":

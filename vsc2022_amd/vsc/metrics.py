@@ -1,48 +1,61 @@
-"""Record types, CSV formats and evaluation metrics of the matching pipeline.
+"""Records, CSV formats and the two challenge metrics (candidate micro-AP, segment-level AP).
 
-Host-side mirror of the reference's `vsc/metrics.py` (same public names and semantics, cited per
-symbol below; paths relative to /root/reference).  Nothing here is GPU work: these are the
-O(n log n) judges (micro-AP, segment AP) that run once per evaluation.  They are written
-array-first so that 10^5..10^6 predictions do not spend minutes in Python loops.
+Public names and semantics follow the reference's `vsc/metrics.py` (cited per symbol; paths relative
+to /root/reference) so that files and scores are interchangeable; the implementation is array-first
+(10^5..10^6 predictions must not spend minutes in per-object Python).  Values are pinned against the
+reference by fixture `tests/golden/g7_metrics.npz`.
 """
-import collections
+import bisect
 import dataclasses
 import enum
 import math
-from typing import Collection, Dict, Iterable, List, NamedTuple, Optional, Sequence, TextIO, Tuple, Union
+from typing import Collection, Dict, Iterable, List, NamedTuple, Optional, TextIO, Tuple, Union
 
 import numpy as np
 
 
 class Dataset(enum.Enum):
-    """vsc/metrics.py:21-23"""
+    """Which side of the challenge a video id belongs to; the value is the id prefix (metrics.py:21-23)."""
 
     QUERIES = "Q"
     REFS = "R"
 
 
 def format_video_id(video_id: Union[str, int], dataset: Optional[Dataset]) -> str:
-    """vsc/metrics.py:26-40: ints become e.g. Q000123; strings are checked against the dataset."""
+    """Canonical string id: integers become `<prefix>%06d`, strings are checked against the prefix
+    (metrics.py:26-40)."""
     if isinstance(video_id, (int, np.integer)):
         if dataset is None:
             raise ValueError("Unable to convert integer video_id without a Dataset enum")
         return "%s%06d" % (dataset.value, int(video_id))
     if not isinstance(video_id, str):
         raise AssertionError(f"unexpected video_id: {video_id} of type {type(video_id)}")
-    if dataset is not None and video_id[0] != dataset.value:
+    if dataset is not None and not video_id.startswith(dataset.value):
         raise AssertionError(f"dataset mismatch? got {video_id} for dataset {dataset}")
     return video_id
 
 
-def _pd():
-    import pandas as pd  # deferred: keeps `import vsc2022_amd` light
+def _pandas():
+    import pandas  # deferred: `import vsc2022_amd` stays light
 
-    return pd
+    return pandas
+
+
+def _pair_columns(pairs) -> Tuple[list, list, np.ndarray]:
+    """(query ids, ref ids, scores) of a collection of CandidatePair (array-backed lists expose
+    `columns()` and are never expanded into objects)."""
+    columns = getattr(pairs, "columns", None)
+    if columns is not None:
+        q, r, s = columns()
+        return list(q), list(r), np.asarray(s, dtype=np.float64)
+    pairs = list(pairs)
+    return ([p.query_id for p in pairs], [p.ref_id for p in pairs],
+            np.fromiter((p.score for p in pairs), dtype=np.float64, count=len(pairs)))
 
 
 @dataclasses.dataclass
 class CandidatePair:
-    """vsc/metrics.py:43-93"""
+    """A (query video, reference video) pair with a confidence (metrics.py:43-93)."""
 
     query_id: str
     ref_id: str
@@ -50,23 +63,16 @@ class CandidatePair:
 
     @classmethod
     def to_dataframe(cls, candidates: Collection["CandidatePair"]):
-        cols = getattr(candidates, "columns", None)
-        if cols is not None:  # array-backed CandidateList: no per-object work
-            qids, rids, scores = cols()
-        else:
-            qids = [c.query_id for c in candidates]
-            rids = [c.ref_id for c in candidates]
-            scores = [c.score for c in candidates]
-        frame = _pd().DataFrame(
-            {
-                "query_id": [format_video_id(q, Dataset.QUERIES) for q in qids],
-                "ref_id": [format_video_id(r, Dataset.REFS) for r in rids],
-                "score": scores,
-            }
-        )
-        if len(frame) == 0:  # the reference builds an empty, column-less frame from []
-            frame = _pd().DataFrame([])
-        return frame
+        q, r, _ = _pair_columns(candidates)
+        if not q:  # the reference builds a column-less frame from an empty list
+            return _pandas().DataFrame([])
+        # scores keep their own dtype (fp32 from the engine) so that the CSV text matches the reference's
+        raw_scores = candidates.columns()[2] if hasattr(candidates, "columns") else [c.score for c in candidates]
+        return _pandas().DataFrame({
+            "query_id": [format_video_id(x, Dataset.QUERIES) for x in q],
+            "ref_id": [format_video_id(x, Dataset.REFS) for x in r],
+            "score": raw_scores,
+        })
 
     @classmethod
     def write_csv(cls, candidates: Collection["CandidatePair"], file: Union[str, TextIO]):
@@ -74,29 +80,24 @@ class CandidatePair:
 
     @classmethod
     def read_csv(cls, file: Union[str, TextIO]) -> List["CandidatePair"]:
-        frame = _pd().read_csv(file)
-        return [
-            CandidatePair(
-                query_id=format_video_id(q, Dataset.QUERIES),
-                ref_id=format_video_id(r, Dataset.REFS),
-                score=s,
-            )
-            for q, r, s in zip(frame["query_id"], frame["ref_id"], frame["score"])
-        ]
+        table = _pandas().read_csv(file)
+        rows = zip(table["query_id"], table["ref_id"], table["score"])
+        return [cls(format_video_id(q, Dataset.QUERIES), format_video_id(r, Dataset.REFS), s) for q, r, s in rows]
 
     @classmethod
     def from_matches(cls, matches: Collection["Match"]) -> List["CandidatePair"]:
-        """Best score per (query, ref); starts from 0.0 like defaultdict(float) (metrics.py:84-93)."""
+        """One pair per (query, ref) with the best segment score, floored at 0 as the reference's
+        defaultdict(float) does (metrics.py:84-93)."""
         best: Dict[Tuple[str, str], float] = {}
         for m in matches:
             key = (m.query_id, m.ref_id)
             best[key] = max(m.score, best.get(key, 0.0))
-        return [CandidatePair(query_id=q, ref_id=r, score=s) for (q, r), s in best.items()]
+        return [cls(q, r, s) for (q, r), s in best.items()]
 
 
 @dataclasses.dataclass
 class PrecisionRecallCurve:
-    """vsc/metrics.py:96-111"""
+    """metrics.py:96-111"""
 
     precisions: np.ndarray
     recalls: np.ndarray
@@ -106,63 +107,74 @@ class PrecisionRecallCurve:
         if ax is None:
             import matplotlib.pyplot as plt
 
-            _, ax = plt.subplots()
-            ax.set_xlabel("recall")
-            ax.set_ylabel("precision")
-            ax.set_xlim(0, 1.05)
-            ax.set_ylim(0, 1.05)
+            ax = plt.subplots()[1]
+            ax.set(xlabel="recall", ylabel="precision", xlim=(0, 1.05), ylim=(0, 1.05))
         ax.plot(self.recalls, self.precisions, **kwargs)
         return ax
 
 
 @dataclasses.dataclass
 class AveragePrecision:
-    """vsc/metrics.py:114-118"""
+    """metrics.py:114-118"""
 
     ap: float
     pr_curve: PrecisionRecallCurve
     simple_ap: Optional[float] = None
 
 
-def _merge_intervals(intervals: Iterable[Tuple[float, float]]) -> List[Tuple[float, float]]:
-    out: List[Tuple[float, float]] = []
-    for start, end in sorted(intervals):
-        if out and start <= out[-1][1]:
-            if end > out[-1][1]:
-                out[-1] = (out[-1][0], end)
+# ------------------------------------------------------------------------------------ intervals
+
+def _coalesce(intervals: Iterable[Tuple[float, float]]) -> List[Tuple[float, float]]:
+    """Union of closed intervals as a sorted list of disjoint ones (touching intervals merge)."""
+    merged: List[Tuple[float, float]] = []
+    for lo, hi in sorted(intervals):
+        if merged and lo <= merged[-1][1]:
+            if hi > merged[-1][1]:
+                merged[-1] = (merged[-1][0], hi)
         else:
-            out.append((start, end))
-    return out
+            merged.append((lo, hi))
+    return merged
 
 
 class Intervals:
-    """Set of non-overlapping intervals ordered by start (vsc/metrics.py:120-174)."""
+    """A union of intervals on one time axis (metrics.py:120-174)."""
 
     intervals: List[Tuple[float, float]]
 
     def __init__(self, intervals: Optional[List[Tuple[float, float]]] = None):
-        self.intervals = _merge_intervals(intervals or [])
+        self.intervals = _coalesce(intervals or [])
 
     def add(self, interval: Tuple[float, float]):
-        self.intervals = _merge_intervals(self.intervals + [interval])
+        """Insert one interval, keeping the list sorted and disjoint (O(log n + merged))."""
+        lo, hi = interval
+        items = self.intervals
+        k = bisect.bisect_left(items, (lo, hi))
+        if k > 0 and items[k - 1][1] >= lo:  # overlaps its left neighbour
+            k -= 1
+            lo, hi = items[k][0], max(items[k][1], hi)
+        end = k
+        while end < len(items) and items[end][0] <= hi:
+            hi = max(hi, items[end][1])
+            end += 1
+        items[k:end] = [(lo, hi)]
 
     def union(self, intervals: "Intervals") -> "Intervals":
         return Intervals(self.intervals + intervals.intervals)
 
     def total_length(self) -> float:
-        length = 0.0
-        for start, end in self.intervals:
-            length += end - start
-        return length
+        total = 0.0
+        for lo, hi in self.intervals:
+            total += hi - lo
+        return total
 
     def intersect_length(self, intervals: "Intervals") -> float:
-        """|A n B| = |A| + |B| - |A U B|"""
+        """|A n B| = |A| + |B| - |A u B|."""
         return self.total_length() + intervals.total_length() - self.union(intervals).total_length()
 
-    def __str__(self):
+    def __repr__(self):
         return str(self.intervals)
 
-    __repr__ = __str__
+    __str__ = __repr__
 
 
 class Axis(enum.Enum):
@@ -171,7 +183,7 @@ class Axis(enum.Enum):
 
 
 class Match(NamedTuple):
-    """A ground-truth or predicted copied segment (vsc/metrics.py:182-235)."""
+    """A copied segment: ground truth or prediction (metrics.py:182-235)."""
 
     query_id: str
     ref_id: str
@@ -185,221 +197,188 @@ class Match(NamedTuple):
         return (self.query_id, self.ref_id)
 
     def interval(self, axis: Axis) -> Tuple[float, float]:
-        if axis == Axis.QUERY:
-            return (self.query_start, self.query_end)
-        return (self.ref_start, self.ref_end)
+        return (self.query_start, self.query_end) if axis == Axis.QUERY else (self.ref_start, self.ref_end)
 
     def intersection_area(self, bbox: "Match") -> float:
-        dq = min(self.query_end, bbox.query_end) - max(self.query_start, bbox.query_start)
-        dr = min(self.ref_end, bbox.ref_end) - max(self.ref_start, bbox.ref_start)
-        return abs(max(dq, 0) * max(dr, 0))
+        width = min(self.query_end, bbox.query_end) - max(self.query_start, bbox.query_start)
+        height = min(self.ref_end, bbox.ref_end) - max(self.ref_start, bbox.ref_start)
+        return abs(max(width, 0) * max(height, 0))
 
     def overlaps(self, bbox: "Match") -> bool:
         return self.intersection_area(bbox) > 0.0
 
     @classmethod
     def write_csv(cls, matches: Collection["Match"], file: Union[str, TextIO]):
-        frame = _pd().DataFrame([m._asdict() for m in matches], columns=cls._fields)
-        frame.to_csv(file, index=False)
+        _pandas().DataFrame([m._asdict() for m in matches], columns=cls._fields).to_csv(file, index=False)
 
     @classmethod
     def read_csv(cls, file: Union[str, TextIO], is_gt=False, check=True) -> List["Match"]:
-        frame = _pd().read_csv(file)
-        frame["query_id"] = frame.query_id.map(lambda x: format_video_id(x, Dataset.QUERIES))
-        frame["ref_id"] = frame.ref_id.map(lambda x: format_video_id(x, Dataset.REFS))
+        table = _pandas().read_csv(file)
+        table["query_id"] = [format_video_id(x, Dataset.QUERIES) for x in table["query_id"]]
+        table["ref_id"] = [format_video_id(x, Dataset.REFS) for x in table["ref_id"]]
         if is_gt:
-            frame["score"] = 1.0
+            table["score"] = 1.0
         if check:
             for field in cls._fields:
-                assert not frame[field].isna().any()
-        return [Match(**record) for record in frame.to_dict("records")]
+                assert not table[field].isna().any()
+        return [cls(**row) for row in table.to_dict("records")]
 
 
 class VideoPair:
-    """Per (query, ref) accumulator of predictions against ground truth (vsc/metrics.py:238-301).
+    """Running overlap statistics of one (query, ref) pair (metrics.py:238-301).
 
-    Ground-truth boxes only count towards the intersection once at least one prediction overlaps
-    them (area overlap), exactly as the reference; the bookkeeping is incremental: the set of
-    overlapped GT boxes and the merged prediction intervals are carried between calls instead of
-    being rebuilt from every past prediction.
+    A ground-truth segment counts towards the intersection only once some prediction overlaps it in
+    area (both axes), as in the reference; the state is incremental -- which ground-truth segments
+    are "awake" and the merged prediction intervals are carried from call to call instead of being
+    rebuilt from every earlier prediction.
     """
 
     gts: List[Match]
     preds: List[Match]
 
     def __init__(self):
+        self.gts, self.preds = [], []
         self.intersections = {axis: 0.0 for axis in Axis}
         self.totals = {axis: 0.0 for axis in Axis}
-        self.gts = []
-        self.preds = []
-        self._gt_hit: List[bool] = []
-        self._pred_ints = {axis: Intervals() for axis in Axis}
+        self._awake: List[bool] = []
+        self._covered = {axis: Intervals() for axis in Axis}
 
     def total_gt_length(self, axis: Axis) -> float:
-        return Intervals([gt.interval(axis) for gt in self.gts]).total_length()
+        return Intervals([g.interval(axis) for g in self.gts]).total_length()
 
     def total_pred_length(self, axis: Axis) -> float:
-        return Intervals([pred.interval(axis) for pred in self.preds]).total_length()
+        return Intervals([p.interval(axis) for p in self.preds]).total_length()
 
     def gt_overlaps(self, gt: Match) -> bool:
-        return any(gt.overlaps(pred) for pred in self.preds)
+        return any(gt.overlaps(p) for p in self.preds)
 
     def add_gt(self, bbox: Match):
         self.gts.append(bbox)
-        self._gt_hit.append(self.gt_overlaps(bbox))
+        self._awake.append(self.gt_overlaps(bbox))
 
     def add_prediction(self, bbox: Match) -> Tuple[Dict[Axis, float], Dict[Axis, float]]:
+        """Returns the change of (intersection with ground truth, covered length) per axis."""
         self.preds.append(bbox)
         for k, gt in enumerate(self.gts):
-            if not self._gt_hit[k] and gt.overlaps(bbox):
-                self._gt_hit[k] = True
-        considered = [gt for gt, hit in zip(self.gts, self._gt_hit) if hit]
-        intersect_deltas, total_deltas = {}, {}
+            if not self._awake[k] and gt.overlaps(bbox):
+                self._awake[k] = True
+        d_inter, d_total = {}, {}
         for axis in Axis:
-            self._pred_ints[axis].add(bbox.interval(axis))
-            pred_ints = self._pred_ints[axis]
-            gt_ints = Intervals([gt.interval(axis) for gt in considered])
-            intersect_length = pred_ints.intersect_length(gt_ints)
-            prediction_length = pred_ints.total_length()
-            intersect_deltas[axis] = intersect_length - self.intersections[axis]
-            total_deltas[axis] = prediction_length - self.totals[axis]
-            self.intersections[axis] = intersect_length
-            self.totals[axis] = prediction_length
-        return intersect_deltas, total_deltas
+            covered = self._covered[axis]
+            covered.add(bbox.interval(axis))
+            truth = Intervals([g.interval(axis) for g, on in zip(self.gts, self._awake) if on])
+            inter, total = covered.intersect_length(truth), covered.total_length()
+            d_inter[axis], d_total[axis] = inter - self.intersections[axis], total - self.totals[axis]
+            self.intersections[axis], self.totals[axis] = inter, total
+        return d_inter, d_total
 
 
 def match_metric(gts: Collection[Match], predictions: Collection[Match]) -> AveragePrecision:
-    """Segment-level AP of the matching track (vsc/metrics.py:304-378).
-
-    AP = sum_i P(i) dR(i) with P = sqrt(P_query * P_ref), R = sqrt(R_query * R_ref); predictions
-    sharing a score are applied as one group before the curve is sampled.
-    """
-    ordered = sorted(predictions, key=lambda m: m.score, reverse=True)
-    pairs: Dict[Tuple[str, str], VideoPair] = collections.defaultdict(VideoPair)
+    """Segment-level AP of the matching track (metrics.py:304-378): AP = sum_i P(i) * dR(i) with
+    P = sqrt(P_query * P_ref) and R = sqrt(R_query * R_ref); predictions with equal scores enter as
+    one group before the curve is sampled."""
+    ranked = sorted(predictions, key=lambda m: m.score, reverse=True)
+    per_pair: Dict[Tuple[str, str], VideoPair] = {}
     for gt in gts:
-        pairs[gt.pair_id()].add_gt(gt)
-    gt_total = {axis: 0.0 for axis in Axis}
-    for pair in pairs.values():
+        per_pair.setdefault(gt.pair_id(), VideoPair()).add_gt(gt)
+    # per-axis ground-truth length, accumulated pair by pair (the reference's summation order)
+    truth_length = {axis: 0.0 for axis in Axis}
+    for pair in per_pair.values():
         for axis in Axis:
-            gt_total[axis] += pair.total_gt_length(axis)
+            truth_length[axis] += pair.total_gt_length(axis)
 
     inter = {axis: 0.0 for axis in Axis}
-    total = {axis: 0.0 for axis in Axis}
-    recall = 0.0
-    metric = 0.0
-    curve_r, curve_p, curve_s = [], [], []
-    pos, n = 0, len(ordered)
-    while pos < n:
-        score = ordered[pos].score
-        while pos < n and ordered[pos].score == score:
-            d_inter, d_total = pairs[ordered[pos].pair_id()].add_prediction(ordered[pos])
+    covered = {axis: 0.0 for axis in Axis}
+    ap, recall = 0.0, 0.0
+    points = []  # (recall, precision, score)
+    cursor = 0
+    while cursor < len(ranked):
+        score = ranked[cursor].score
+        while cursor < len(ranked) and ranked[cursor].score == score:
+            pred = ranked[cursor]
+            d_inter, d_total = per_pair.setdefault(pred.pair_id(), VideoPair()).add_prediction(pred)
             for axis in Axis:
                 inter[axis] += d_inter[axis]
-                total[axis] += d_total[axis]
-            pos += 1
-        rec = {axis: inter[axis] / gt_total[axis] for axis in Axis}
-        prec = {axis: inter[axis] / total[axis] for axis in Axis}
-        new_recall = math.sqrt(rec[Axis.QUERY] * rec[Axis.REF])
-        precision = math.sqrt(prec[Axis.QUERY] * prec[Axis.REF])
-        delta = new_recall - recall
-        metric += precision * delta
-        recall = new_recall
-        if delta > 0:
-            curve_r.append(recall)
-            curve_p.append(precision)
-            curve_s.append(score)
-    return AveragePrecision(
-        metric, PrecisionRecallCurve(np.array(curve_p), np.array(curve_r), np.array(curve_s))
-    )
+                covered[axis] += d_total[axis]
+            cursor += 1
+        r_now = math.sqrt((inter[Axis.QUERY] / truth_length[Axis.QUERY]) * (inter[Axis.REF] / truth_length[Axis.REF]))
+        p_now = math.sqrt((inter[Axis.QUERY] / covered[Axis.QUERY]) * (inter[Axis.REF] / covered[Axis.REF]))
+        gain = r_now - recall
+        ap += p_now * gain
+        recall = r_now
+        if gain > 0:
+            points.append((recall, p_now, score))
+    curve = PrecisionRecallCurve(np.array([p[1] for p in points]), np.array([p[0] for p in points]),
+                                 np.array([p[2] for p in points]))
+    return AveragePrecision(ap, curve)
 
 
 @dataclasses.dataclass
 class MatchingTrackMetrics:
-    """vsc/metrics.py:381-386"""
+    """metrics.py:381-386"""
 
-    segment_ap: AveragePrecision
-    pairwise_micro_ap: AveragePrecision
+    segment_ap: AveragePrecision      # the matching-track metric
+    pairwise_micro_ap: AveragePrecision  # pair retrieval only, no localisation
 
 
 def evaluate_matching_track(ground_truth_filename: str, predictions_filename: str) -> MatchingTrackMetrics:
-    """vsc/metrics.py:389-415"""
-    gt = Match.read_csv(ground_truth_filename, is_gt=True)
-    predictions = Match.read_csv(predictions_filename)
-    metric = match_metric(gt, predictions)
-    pair_ap = average_precision(CandidatePair.from_matches(gt), CandidatePair.from_matches(predictions))
-    return MatchingTrackMetrics(segment_ap=metric, pairwise_micro_ap=pair_ap)
+    """Both metrics from two CSV files with the `Match` columns in any order (metrics.py:389-415)."""
+    truth = Match.read_csv(ground_truth_filename, is_gt=True)
+    predicted = Match.read_csv(predictions_filename)
+    pair_ap = average_precision(CandidatePair.from_matches(truth), CandidatePair.from_matches(predicted))
+    return MatchingTrackMetrics(segment_ap=match_metric(truth, predicted), pairwise_micro_ap=pair_ap)
 
 
-def _columns(pairs: Collection[CandidatePair]):
-    cols = getattr(pairs, "columns", None)
-    if cols is not None:
-        q, r, s = cols()
-        return list(q), list(r), np.asarray(s, dtype=np.float64)
-    return ([p.query_id for p in pairs], [p.ref_id for p in pairs],
-            np.asarray([p.score for p in pairs], dtype=np.float64))
-
-
-def average_precision(
-    ground_truth: Collection[CandidatePair], predictions: Collection[CandidatePair]
-) -> AveragePrecision:
-    """Micro-AP over (query, ref) pairs (vsc/metrics.py:418-450).
-
-    `ap` is the DrivenData-style value (threshold-grouped AP scaled by the fraction of ground
-    truth that was predicted at all), `simple_ap` the rank-based one.
-    """
-    gq, gr, _ = _columns(ground_truth)
-    gt_pairs = set(zip(gq, gr))
-    if len(gt_pairs) != len(gq):
+def average_precision(ground_truth: Collection[CandidatePair], predictions: Collection[CandidatePair]
+                      ) -> AveragePrecision:
+    """Micro-AP over (query, ref) pairs (metrics.py:418-450): `ap` is the DrivenData value
+    (threshold-grouped AP scaled by the share of the ground truth that was predicted at all),
+    `simple_ap` the rank-based one."""
+    gq, gr, _ = _pair_columns(ground_truth)
+    wanted = set(zip(gq, gr))
+    if len(wanted) != len(gq):
         raise AssertionError("Duplicates detected in ground truth")
-    pq, pr, scores = _columns(predictions)
+    pq, pr, scores = _pair_columns(predictions)
     if len(set(zip(pq, pr))) != len(pq):
         raise AssertionError("Duplicates detected in predictions")
-    canonical = drivendata_average_precision(
-        predicted=CandidatePair.to_dataframe(predictions),
-        ground_truth=CandidatePair.to_dataframe(ground_truth),
-    )
+    canonical = drivendata_average_precision(predicted=CandidatePair.to_dataframe(predictions),
+                                             ground_truth=CandidatePair.to_dataframe(ground_truth))
     order = np.argsort(-scores, kind="stable")
-    scores = scores[order]
-    correct = np.fromiter(((pq[k], pr[k]) in gt_pairs for k in order), dtype=bool, count=len(order))
-    total_pairs = len(gt_pairs)
-    cum_correct = np.cumsum(correct)
-    recall = cum_correct / total_pairs
-    precision = cum_correct / (np.arange(len(correct)) + 1)
-    simple_ap = np.sum(precision * correct) / total_pairs
-    hit = np.nonzero(correct)[0]
-    curve = PrecisionRecallCurve(precision[hit], recall[hit], scores[hit])
-    return AveragePrecision(ap=canonical, pr_curve=curve, simple_ap=simple_ap)
+    hit = np.fromiter(((pq[k], pr[k]) in wanted for k in order), dtype=bool, count=len(order))
+    found = np.cumsum(hit)
+    precision = found / (np.arange(len(hit)) + 1)
+    recall = found / len(wanted)
+    simple_ap = np.sum(precision * hit) / len(wanted)
+    at = np.flatnonzero(hit)
+    return AveragePrecision(ap=canonical, pr_curve=PrecisionRecallCurve(precision[at], recall[at], scores[order][at]),
+                            simple_ap=simple_ap)
 
 
 def _threshold_ap(labels: np.ndarray, scores: np.ndarray) -> float:
-    """sklearn.metrics.average_precision_score for binary labels: sum over distinct score
-    thresholds (descending) of (R_k - R_{k-1}) * P_k."""
+    """Binary average precision as sklearn.metrics.average_precision_score defines it: over the
+    distinct score thresholds, descending, sum (R_k - R_{k-1}) * P_k."""
     order = np.argsort(-scores, kind="stable")
-    labels = labels[order]
-    scores = scores[order]
-    last_of_group = np.r_[np.nonzero(np.diff(scores))[0], len(scores) - 1]
-    tp = np.cumsum(labels)[last_of_group]
-    seen = last_of_group + 1
-    precision = tp / seen
+    labels, scores = labels[order], scores[order]
+    group_end = np.r_[np.flatnonzero(np.diff(scores)), len(scores) - 1]
+    tp = np.cumsum(labels)[group_end]
+    precision = tp / (group_end + 1)
     recall = tp / tp[-1]
     return float(np.sum(np.diff(np.r_[0.0, recall]) * precision))
 
 
 def drivendata_average_precision(predicted, ground_truth) -> float:
-    """Canonical challenge AP (vsc/metrics.py:453-489).  Frames carry query_id / ref_id / score."""
+    """The challenge backend's AP (metrics.py:453-489); both arguments are frames with query_id /
+    ref_id (/ score) columns."""
     if len(predicted) == 0:
         return 0.0
     scores = np.asarray(predicted["score"], dtype=np.float64)
     if not np.isfinite(scores).all():
         raise ValueError("Scores must be finite.")
-    actual = set(zip(ground_truth["query_id"], ground_truth["ref_id"])) if len(ground_truth) else set()
-    labels = np.fromiter(
-        (pair in actual for pair in zip(predicted["query_id"], predicted["ref_id"])),
-        dtype=np.float64,
-        count=len(scores),
-    )
-    predicted_n_pos = int(labels.sum())
-    if predicted_n_pos == 0:
+    truth = set(zip(ground_truth["query_id"], ground_truth["ref_id"])) if len(ground_truth) else set()
+    labels = np.fromiter((pair in truth for pair in zip(predicted["query_id"], predicted["ref_id"])),
+                         dtype=np.float64, count=len(scores))
+    n_found = int(labels.sum())
+    if n_found == 0:
         return 0.0
-    actual_n_pos = int(_pd().notna(ground_truth["ref_id"]).sum())
-    return _threshold_ap(labels, scores) * (predicted_n_pos / actual_n_pos)
+    n_truth = int(_pandas().notna(ground_truth["ref_id"]).sum())
+    return _threshold_ap(labels, scores) * (n_found / n_truth)
