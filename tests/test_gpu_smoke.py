@@ -22,6 +22,18 @@ def test_smoke_in_fresh_process():
 
 
 @pytest.mark.gpu
+def test_parity_suites_with_poisoned_allocations():
+    """VSC_POISON_ALLOC=1 fills every fresh device buffer with 0xFF (NaN scores, -1 indices): a kernel
+    that consumes memory nobody wrote fails the bit-exact parity tests instead of passing on the
+    zero-filled pages a fresh allocation usually has."""
+    env = dict(os.environ, VSC_POISON_ALLOC="1")
+    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", "tests/test_gpu_search.py",
+                        "tests/test_gpu_tn.py", "tests/test_gpu_edge_cases.py", "tests/test_gpu_golden.py"],
+                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=1200)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+
+
+@pytest.mark.gpu
 def test_overflow_retry_in_fresh_process():
     """First search of the process overflows the default kept-hit buffer and is rerun with a larger
     one: results must still be the exact top-K prefix."""

@@ -24,6 +24,15 @@ void set_error(const char* fmt, ...) {
     g_err = buf;
 }
 
+// ---- debug aid (see vscmi_common.h)
+bool poison_mode() {
+    static const bool on = [] {
+        const char* e = getenv("VSC_POISON_ALLOC");
+        return e && e[0] == '1';
+    }();
+    return on;
+}
+
 static int check_device(int device) {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) {

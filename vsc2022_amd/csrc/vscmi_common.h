@@ -66,6 +66,11 @@ __host__ __device__ inline float key2f(uint32_t k) {
 #endif
 }
 
+// Debug aid: with VSC_POISON_ALLOC=1 every fresh device buffer is filled with 0xFF bytes (NaN as
+// fp32, -1 as an index), so a kernel that consumes memory nobody wrote shows up as a parity failure
+// instead of passing on zero-filled fresh pages (tests/test_gpu_smoke.py).  Defined in api.hip.
+bool poison_mode();
+
 // growable device buffer
 struct DevBuf {
     void* p = nullptr;
@@ -86,6 +91,7 @@ struct DevBuf {
             return VSC_ERR_NOMEM;
         }
         bytes = want;
+        if (poison_mode()) (void)hipMemset(p, 0xFF, bytes);
         return VSC_OK;
     }
     void release() {
