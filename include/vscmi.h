@@ -179,6 +179,14 @@ int vsc_tn_similarity(vsc_tn_ctx_t* ctx, int32_t q_vid, int32_t r_vid, float bia
 int vsc_index_profile(vsc_index_t* idx, int enable);
 int vsc_index_profile_read(vsc_index_t* idx, double* sim_ms, int64_t* sim_launches, double* sim_flops,
                            int reset);
+/* Same accounting per kernel class: 0 = exact fp32 similarity kernels (what vsc_index_profile_read
+ * reports), 1 = fp16 pre-filter GEMM (work = algorithmic flops 2*nq*nr*dim), 2 = exact re-scoring of
+ * the pre-filter's candidates (work unused). */
+int vsc_index_profile_read_class(vsc_index_t* idx, int cls, double* ms, int64_t* launches, double* work,
+                                 int reset);
+/* Counters of the last thresholded search on this handle: pairs the fp16 pre-filter passed on to
+ * the exact stage, and (reserved) hits. */
+int vsc_index_search_stats(vsc_index_t* idx, int64_t* candidates, int64_t* hits);
 
 #ifdef __cplusplus
 }

@@ -39,4 +39,6 @@ dt = time.perf_counter() - t0
 p = m.index.profile_read(True)
 print(f"nq={args.nq} nr={args.nr} d={args.dim} hits={hs.numel()} wall/search={dt/args.reps*1e3:.1f} ms "
       f"sim_kernel={p['sim_ms']/args.reps:.1f} ms launches={p['sim_launches']//args.reps} "
-      f"TFLOP/s={p['sim_flops']/1e12/(p['sim_ms']/1e3):.1f}")
+      f"TFLOP/s={p['sim_flops']/1e12/max(p['sim_ms'],1e-9)*1e3:.1f} | f16 {p['f16_ms']/args.reps:.1f} ms "
+      f"launches={p['f16_launches']//args.reps} TFLOP/s={p['f16_flops']/1e12/max(p['f16_ms'],1e-9)*1e3:.1f} | "
+      f"rescore {p['rescore_ms']/args.reps:.1f} ms candidates={p['candidates']}")

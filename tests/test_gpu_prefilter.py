@@ -1,0 +1,163 @@
+"""fp16 pre-filter + exact re-scoring (csrc/sim_f16.hip) must be INVISIBLE in the results.
+
+The thresholded searches evaluate the bulk of the score matrix in fp16 and hand to the exact fp32
+stage every pair whose fp16 score plus a rigorous error bound exceeds the radius.  The candidate set is
+a superset of the exact hit set, so hits, order and fp32 bit patterns must equal the CPU oracle's
+(vsc/index.py:142-165 semantics) -- with the pre-filter chosen by the density rule, forced onto every
+batch (VSC_PREFILTER=2) or switched off (VSC_PREFILTER=0).
+"""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def unit(rng, n, d):
+    x = rng.standard_normal((n, d)).astype(np.float32)
+    return x / np.linalg.norm(x, axis=1, keepdims=True)
+
+
+def bits(x):
+    return np.ascontiguousarray(x, dtype=np.float32).view(np.uint32)
+
+
+class prefilter_mode:
+    """VSC_PREFILTER is read when an index handle is created."""
+
+    def __init__(self, mode):
+        self.mode = mode
+
+    def __enter__(self):
+        self.old = os.environ.get("VSC_PREFILTER")
+        if self.mode is None:
+            os.environ.pop("VSC_PREFILTER", None)
+        else:
+            os.environ["VSC_PREFILTER"] = self.mode
+
+    def __exit__(self, *exc):
+        if self.old is None:
+            os.environ.pop("VSC_PREFILTER", None)
+        else:
+            os.environ["VSC_PREFILTER"] = self.old
+
+
+def search_stats(idx):
+    import ctypes
+
+    from vsc2022_amd import _lib
+
+    c, h = ctypes.c_int64(0), ctypes.c_int64(0)
+    _lib.check(_lib.lib().vsc_index_search_stats(idx._h, ctypes.byref(c), ctypes.byref(h)))
+    return c.value
+
+
+def run_topk(q, r, K, mode):
+    from vsc2022_amd.vsc.index import FlatIndex
+
+    with prefilter_mode(mode):
+        idx = FlatIndex(q.shape[1])
+    idx.add(r)
+    i, j, s, radius = idx.global_topk(q, K)
+    return i, j, s, radius, search_stats(idx)
+
+
+def assert_same(a, b):
+    assert len(a[2]) == len(b[2]), (len(a[2]), len(b[2]))
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+    assert np.array_equal(bits(a[2]), bits(b[2]))
+
+
+@pytest.mark.parametrize("mode", [None, "2"])
+@pytest.mark.parametrize("nq,nr,d,K", [(700, 3000, 128, 900), (300, 1000, 512, 200), (1100, 5000, 40, 3000),
+                                        (64, 257, 100, 50)])
+def test_topk_with_prefilter_matches_oracle(gpu, orc, mode, nq, nr, d, K):
+    rng = np.random.default_rng(nq + nr + d)
+    q, r = unit(rng, nq, d), unit(rng, nr, d)
+    got = run_topk(q, r, K, mode)
+    oi, oj, os_, info = orc.global_threshold_search(q, r, K, 0, return_info=True)
+    assert_same(got, (oi, oj, os_))
+    assert np.float32(got[3]) == np.float32(info["radius"])
+    if mode == "2":
+        assert got[4] >= len(os_)  # the pre-filter really ran: candidates are a superset of the hits
+
+
+def test_prefilter_with_ties_and_duplicates(gpu, orc):
+    """Static videos: many identical rows => exact score ties sit on the re-threshold values."""
+    rng = np.random.default_rng(11)
+    r = unit(rng, 2000, 64)
+    r[100:400] = r[100]  # 300 identical reference rows
+    q = unit(rng, 600, 64)
+    q[50:120] = q[50]
+    q[300:330] = r[100]  # exact copies of the repeated reference row
+    for mode in (None, "2", "0"):
+        got = run_topk(q, r, 1500, mode)
+        oi, oj, os_ = orc.global_threshold_search(q, r, 1500)
+        assert_same(got, (oi, oj, os_))
+
+
+def test_prefilter_unnormalised_and_extreme_rows(gpu, orc):
+    """Rows of very different norms, rows fp16 cannot represent (|x| > 65504, inf, NaN), tiny rows."""
+    rng = np.random.default_rng(12)
+    q = rng.standard_normal((400, 96)).astype(np.float32) * rng.uniform(0.01, 30.0, (400, 1)).astype(np.float32)
+    r = rng.standard_normal((1500, 96)).astype(np.float32) * rng.uniform(0.01, 30.0, (1500, 1)).astype(np.float32)
+    r[7] *= 1e-6  # far below the fp16 subnormal range
+    r[8, 3] = 1e6  # overflows fp16
+    q[9, 0] = 7e4
+    r[10, 5] = np.inf
+    q[11, 2] = np.nan
+    r[12] = 0.0
+    for mode in (None, "2"):
+        got = run_topk(q, r, 2500, mode)
+        oi, oj, os_ = orc.global_threshold_search(q, r, 2500)
+        assert_same(got, (oi, oj, os_))
+
+
+def test_range_search_with_prefilter(gpu, orc):
+    from vsc2022_amd.vsc.index import FlatIndex
+
+    rng = np.random.default_rng(13)
+    q, r = unit(rng, 500, 128), unit(rng, 2100, 128)
+    for mode in (None, "0"):
+        with prefilter_mode(mode):
+            idx = FlatIndex(128)
+        idx.add(r[:900])
+        idx.add(r[900:])
+        lims, D, I = idx.range_search(q, 0.25)
+        olims, oD, oI = orc.range_search(q, r, 0.25)
+        assert np.array_equal(lims, olims) and np.array_equal(I, oI)
+        assert np.array_equal(bits(D), bits(oD))
+
+
+def test_fp16_error_bound_holds(gpu, orc):
+    """Empirical check of the analytic bound the pre-filter relies on: |fp16 score - exact score| stays far
+    below c1 * |q| * |r| (c1 ~ 1.1e-3 at D = 512) on descriptor-like data."""
+    rng = np.random.default_rng(14)
+    q, r = unit(rng, 256, 512), unit(rng, 1024, 512)
+    exact = orc.scores(q, r).astype(np.float64)
+    approx = q.astype(np.float16).astype(np.float64) @ r.astype(np.float16).astype(np.float64).T
+    assert np.abs(approx - exact).max() < 0.25 * 1.1e-3
+
+
+def test_prefilter_equals_fp32_path_at_scale(gpu):
+    """Larger than the oracle can check quickly: the two device routes must agree bit for bit."""
+    rng = np.random.default_rng(15)
+    q, r = unit(rng, 6000, 256), unit(rng, 60000, 256)
+    a = run_topk(q, r, 40000, None)
+    b = run_topk(q, r, 40000, "0")
+    assert_same(a, b)
+    assert a[3] == b[3]
+    assert a[4] > 0 and b[4] == 0  # the default route used the pre-filter, the fp32 route did not
+
+
+def test_parity_suites_with_forced_prefilter():
+    """All search/candidate parity suites again with the pre-filter on every batch."""
+    env = dict(os.environ, VSC_PREFILTER="2")
+    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", "tests/test_gpu_search.py",
+                        "tests/test_gpu_edge_cases.py", "tests/test_gpu_golden.py", "tests/test_gpu_sharded.py"],
+                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=1200)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]

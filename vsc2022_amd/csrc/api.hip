@@ -61,8 +61,11 @@ struct Workspace {
     DevBuf w0, w1, w2, w3, tmp, cnt;  // sort scratch
     DevBuf out[4];  // device-side outputs when the caller wants host results
     DevBuf parts, partj, mat, maps0, maps1;
+    DevBuf qh, qn;  // fp16 image + norm bounds of the query rows (pre-filter)
+    DevBuf ci, cj, segcnt;  // pre-filter candidates of one batch (per-wave segments + their fill levels)
     void release() {
         stage.release(); qbuf.release();
+        qh.release(); qn.release(); ci.release(); cj.release(); segcnt.release();
         for (auto& b : hA) b.release();
         for (auto& b : hB) b.release();
         ctl.release(); w0.release(); w1.release(); w2.release(); w3.release(); tmp.release(); cnt.release();
@@ -73,9 +76,21 @@ struct Workspace {
 
 // Bring raw fp32 rows (host or device) into the packed engine layout at dst (rows_out rows are
 // written, rows >= n zero).  Host sources are staged in chunks.
+// Optional second image for the fp16 pre-filter: rows_out_h rows of dpadh halves + one norm per row.
+struct HalfImage {
+    _Float16* rows = nullptr;
+    float* norms = nullptr;
+    int64_t rows_out = 0;
+    int dpadh = 0;
+};
+
 static int pack_into(const float* x, int64_t n, int dim, int mem, float* dst, int64_t rows_out, int dpad,
-                     Workspace& ws, hipStream_t stream) {
-    if (mem == VSC_MEM_DEVICE || n == 0) return launch_pack_rows(x, n, dim, dst, rows_out, dpad, stream);
+                     Workspace& ws, hipStream_t stream, const HalfImage& h = HalfImage()) {
+    if (mem == VSC_MEM_DEVICE || n == 0) {
+        VSC_TRY(launch_pack_rows(x, n, dim, dst, rows_out, dpad, stream));
+        if (h.rows) VSC_TRY(launch_pack_half(x, n, dim, h.rows, h.norms, h.rows_out, h.dpadh, stream));
+        return VSC_OK;
+    }
     const int64_t chunk_rows = std::max<int64_t>(1, (int64_t)(256ll << 20) / ((int64_t)dim * 4));
     VSC_TRY(ws.stage.reserve((size_t)std::min(chunk_rows, n) * dim * 4));
     for (int64_t r0 = 0; r0 < n; r0 += chunk_rows) {
@@ -84,6 +99,9 @@ static int pack_into(const float* x, int64_t n, int dim, int mem, float* dst, in
         const bool last = (r0 + rows == n);
         const int64_t out_rows = last ? rows_out - r0 : rows;
         VSC_TRY(launch_pack_rows(ws.stage.as<float>(), rows, dim, dst + r0 * dpad, out_rows, dpad, stream));
+        if (h.rows)
+            VSC_TRY(launch_pack_half(ws.stage.as<float>(), rows, dim, h.rows + r0 * h.dpadh, h.norms + r0,
+                                     last ? h.rows_out - r0 : rows, h.dpadh, stream));
         VSC_HIP(hipStreamSynchronize(stream));  // staging buffer is reused
     }
     return VSC_OK;
@@ -97,19 +115,27 @@ struct vsc_index {
     int dim = 0, dpad = 0, metric = 0, device = 0;
     int64_t ntotal = 0, cap_rows = 0;
     DevBuf ref;
+    // fp16 image (dpadh halves per row) and row-norm bounds of the references: the pre-filter of the
+    // thresholded inner-product searches (sim_f16.hip).  Not kept for L2 indexes.
+    DevBuf refh, refn;
+    int dpadh = 0;
+    bool prefilter = false, prefilter_force = false;
+    unsigned long long stat_candidates = 0, stat_hits = 0;  // last search (vsc_index_profile_read)
     DevBuf cand[3];  // sorted hits of vsc_index_candidates
     hipStream_t stream = nullptr;
     Workspace ws;
     int64_t hit_cap_user = 0;
-    // profiling of the dominant similarity kernel
+    // kernel-time accounting (HIP events on the handle's stream), per kernel class:
+    // 0 = exact fp32 similarity kernels, 1 = fp16 pre-filter, 2 = exact re-scoring of candidates
     bool prof = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
+    std::vector<int> ev_class;
     size_t ev_used = 0;
-    double prof_ms = 0.0, prof_flops = 0.0, pending_flops = 0.0;
-    int64_t prof_launches = 0;
+    double prof_ms[3] = {0, 0, 0}, prof_work[3] = {0, 0, 0}, pending_work[3] = {0, 0, 0};
+    int64_t prof_launches[3] = {0, 0, 0};
 };
 
-static int prof_begin(vsc_index* idx, hipEvent_t* stop_out) {
+static int prof_begin(vsc_index* idx, hipEvent_t* stop_out, int cls = 0) {
     *stop_out = nullptr;
     if (!idx->prof) return VSC_OK;
     if (idx->ev_used == idx->ev_pool.size()) {
@@ -117,16 +143,19 @@ static int prof_begin(vsc_index* idx, hipEvent_t* stop_out) {
         VSC_HIP(hipEventCreate(&a));
         VSC_HIP(hipEventCreate(&b));
         idx->ev_pool.emplace_back(a, b);
+        idx->ev_class.push_back(0);
     }
+    idx->ev_class[idx->ev_used] = cls;
     auto& e = idx->ev_pool[idx->ev_used++];
     VSC_HIP(hipEventRecord(e.first, idx->stream));
     *stop_out = e.second;
     return VSC_OK;
 }
-static int prof_end(vsc_index* idx, hipEvent_t stop, double flops) {
+// `work`: algorithmic flops (classes 0, 1) or bytes (class 2) of the launch
+static int prof_end(vsc_index* idx, hipEvent_t stop, double work, int cls = 0) {
     if (!stop) return VSC_OK;
     VSC_HIP(hipEventRecord(stop, idx->stream));
-    idx->pending_flops += flops;
+    idx->pending_work[cls] += work;
     return VSC_OK;
 }
 // call after a stream sync
@@ -134,11 +163,13 @@ static int prof_collect(vsc_index* idx) {
     for (size_t e = 0; e < idx->ev_used; ++e) {
         float ms = 0.0f;
         VSC_HIP(hipEventElapsedTime(&ms, idx->ev_pool[e].first, idx->ev_pool[e].second));
-        idx->prof_ms += ms;
-        idx->prof_launches += 1;
+        idx->prof_ms[idx->ev_class[e]] += ms;
+        idx->prof_launches[idx->ev_class[e]] += 1;
     }
-    idx->prof_flops += idx->pending_flops;
-    idx->pending_flops = 0.0;
+    for (int c = 0; c < 3; ++c) {
+        idx->prof_work[c] += idx->pending_work[c];
+        idx->pending_work[c] = 0.0;
+    }
     idx->ev_used = 0;
     return VSC_OK;
 }
@@ -169,7 +200,15 @@ int vsc_index_create(int dim, int metric, int device, vsc_index_t** out) {
     vsc_index* idx = new vsc_index();
     idx->dim = dim;
     idx->dpad = round_up(dim, K_PAD);
+    idx->dpadh = round_up(dim, 128);
     idx->metric = metric;
+    {
+        // VSC_PREFILTER=0 keeps every search on the all-fp32 kernel (A/B and debugging);
+        // VSC_PREFILTER=2 sends EVERY batch through the pre-filter, whatever its hit density (tests)
+        const char* e = getenv("VSC_PREFILTER");
+        idx->prefilter = metric == VSC_METRIC_INNER_PRODUCT && !(e && e[0] == '0');
+        idx->prefilter_force = idx->prefilter && e && e[0] == '2';
+    }
     idx->device = device;
     hipError_t e = hipStreamCreateWithFlags(&idx->stream, hipStreamNonBlocking);
     if (e != hipSuccess) {
@@ -192,6 +231,8 @@ int vsc_index_destroy(vsc_index_t* idx) {
     (void)hipSetDevice(idx->device);
     (void)hipStreamSynchronize(idx->stream);
     idx->ref.release();
+    idx->refh.release();
+    idx->refn.release();
     for (auto& b : idx->cand) b.release();
     idx->ws.release();
     for (auto& e : idx->ev_pool) {
@@ -234,34 +275,66 @@ int vsc_index_add(vsc_index_t* idx, const float* x, int64_t n, int x_mem) {
         return VSC_ERR_INVALID;
     }
     VSC_HIP(hipSetDevice(idx->device));
-    const int64_t need_rows = round_up64(idx->ntotal + n, ROW_PAD);
+    const int64_t need_rows = round_up64(idx->ntotal + n, ROW_PAD_H);
     if (need_rows > idx->cap_rows) {
         // grow geometrically; keep the old rows
         int64_t cap = std::max<int64_t>(need_rows, idx->cap_rows + idx->cap_rows / 2);
-        cap = round_up64(cap, ROW_PAD);
-        DevBuf nb;
+        cap = round_up64(cap, ROW_PAD_H);
+        DevBuf nb, nh, nn;
         VSC_TRY(nb.reserve((size_t)cap * idx->dpad * 4));
+        if (idx->prefilter) {
+            VSC_TRY(nh.reserve((size_t)cap * idx->dpadh * 2));
+            VSC_TRY(nn.reserve((size_t)cap * 4));
+        }
         if (idx->ntotal > 0) {
             VSC_HIP(hipMemcpyAsync(nb.p, idx->ref.p, (size_t)idx->ntotal * idx->dpad * 4,
                                    hipMemcpyDeviceToDevice, idx->stream));
+            if (idx->prefilter) {
+                VSC_HIP(hipMemcpyAsync(nh.p, idx->refh.p, (size_t)idx->ntotal * idx->dpadh * 2,
+                                       hipMemcpyDeviceToDevice, idx->stream));
+                VSC_HIP(hipMemcpyAsync(nn.p, idx->refn.p, (size_t)idx->ntotal * 4, hipMemcpyDeviceToDevice,
+                                       idx->stream));
+            }
             VSC_HIP(hipStreamSynchronize(idx->stream));
         }
         idx->ref.release();
+        idx->refh.release();
+        idx->refn.release();
         idx->ref = nb;
+        idx->refh = nh;
+        idx->refn = nn;
         idx->cap_rows = cap;
     }
     float* dst = idx->ref.as<float>() + idx->ntotal * idx->dpad;
-    VSC_TRY(pack_into(x, n, idx->dim, x_mem, dst, need_rows - idx->ntotal, idx->dpad, idx->ws, idx->stream));
+    HalfImage h;
+    if (idx->prefilter) {
+        h.rows = idx->refh.as<_Float16>() + idx->ntotal * idx->dpadh;
+        h.norms = idx->refn.as<float>() + idx->ntotal;
+        h.rows_out = need_rows - idx->ntotal;
+        h.dpadh = idx->dpadh;
+    }
+    VSC_TRY(pack_into(x, n, idx->dim, x_mem, dst, need_rows - idx->ntotal, idx->dpad, idx->ws, idx->stream, h));
     VSC_HIP(hipStreamSynchronize(idx->stream));
     idx->ntotal += n;
     return VSC_OK;
 }
 
 // Pack the query rows: returns device pointer; buffer holds round_up(nq,128)+128 zero-padded rows.
-static int pack_queries(vsc_index* idx, const float* q, int64_t nq, int q_mem, float** out) {
+static int pack_queries(vsc_index* idx, const float* q, int64_t nq, int q_mem, float** out,
+                        bool with_half = false) {
     const int64_t rows = round_up64(nq, ROW_PAD) + ROW_PAD;
     VSC_TRY(idx->ws.qbuf.reserve((size_t)rows * idx->dpad * 4));
-    VSC_TRY(pack_into(q, nq, idx->dim, q_mem, idx->ws.qbuf.as<float>(), rows, idx->dpad, idx->ws, idx->stream));
+    HalfImage h;
+    if (with_half) {
+        // a batch starts at any multiple of 32 rows and reads whole 256-row tiles from there
+        h.rows_out = round_up64(nq, ROW_PAD_H) + ROW_PAD_H;
+        h.dpadh = idx->dpadh;
+        VSC_TRY(idx->ws.qh.reserve((size_t)h.rows_out * idx->dpadh * 2));
+        VSC_TRY(idx->ws.qn.reserve((size_t)h.rows_out * 4));
+        h.rows = idx->ws.qh.as<_Float16>();
+        h.norms = idx->ws.qn.as<float>();
+    }
+    VSC_TRY(pack_into(q, nq, idx->dim, q_mem, idx->ws.qbuf.as<float>(), rows, idx->dpad, idx->ws, idx->stream, h));
     *out = idx->ws.qbuf.as<float>();
     return VSC_OK;
 }
@@ -271,15 +344,85 @@ static int ensure_hit_buffers(vsc_index* idx, int64_t cap) {
         VSC_TRY(idx->ws.hA[c].reserve((size_t)cap * 4));
         VSC_TRY(idx->ws.hB[c].reserve((size_t)cap * 4));
     }
+    if (idx->prefilter) {
+        // candidate list: `cap` entries in per-wave segments + a shared tail of `cap` entries, so any
+        // distribution of <= cap candidates over the waves fits
+        VSC_TRY(idx->ws.ci.reserve((size_t)cap * 8));
+        VSC_TRY(idx->ws.cj.reserve((size_t)cap * 8));
+        VSC_TRY(idx->ws.segcnt.reserve(2048 * sizeof(int)));
+    }
     VSC_TRY(idx->ws.ctl.reserve(sizeof(SelectCtl)));
     return VSC_OK;
 }
 
 // Append every (row, ref) of query rows [i0, i1) with score > *radius (score space: IP as is, L2
 // negated) to the hit buffer A.
-static int enqueue_batch(vsc_index* idx, const float* qpacked, int64_t i0, int64_t i1, int64_t cap) {
+static int enqueue_batch(vsc_index* idx, const float* qpacked, int64_t i0, int64_t i1, int64_t cap,
+                         bool use_f16 = false) {
     SelectCtl* ctl = idx->ws.ctl.as<SelectCtl>();
     const int nqb = (int)(i1 - i0);
+    if (use_f16) {
+        // 1. fp16 pre-filter: candidates = pairs whose fp16 score + error bound exceeds the radius
+        const double D = (double)idx->dpadh;
+        SimF16Args f;
+        f.Q = idx->ws.qh.as<_Float16>() + i0 * idx->dpadh;
+        f.R = idx->refh.as<_Float16>();
+        f.qn = idx->ws.qn.as<float>() + i0;
+        f.rn = idx->refn.as<float>();
+        f.dpadh = idx->dpadh;
+        f.nq = nqb;
+        f.i0 = (int)i0;
+        f.nr = (int)idx->ntotal;
+        f.tq = (nqb + 255) / 256;
+        f.tr = (int)((idx->ntotal + 255) / 256);
+        // |fp16 score - exact score| <= c1 |q||r| + c2 (|q| + |r|) + c3   (|x| = L2 norm):
+        //   rounding to fp16: |x - h(x)| <= 2^-11 |x| + 2^-25 per element (normal / subnormal range)
+        //     => sum |q r - h(q) h(r)| <= (2^-10 + 2^-22) |q||r| + 2^-25 * 1.001 * sqrt(D) (|q|+|r|) + D 2^-50
+        //   accumulation: the exact fp32 fma chain (D roundings) and the MFMA's fp32 accumulation
+        //     (D/16 instructions of 16 products + addend) each stay within 2^-23 |q||r| per operation
+        f.c1 = (float)(ldexp(1.0, -10) + ldexp(1.0, -22) + (2.0 * D + D / 16.0 + 16.0) * ldexp(1.0, -23));
+        f.c2 = (float)(ldexp(1.0, -25) * 1.001 * sqrt(D));
+        f.c3 = (float)(D * ldexp(1.0, -50));
+        f.radius = &ctl->radius;
+        f.out_i = idx->ws.ci.as<int32_t>();
+        f.out_j = idx->ws.cj.as<int32_t>();
+        const int grid = sim_f16_grid(f.tq, f.tr);
+        f.seg_cap = (int)std::min<int64_t>(cap / (grid * 8), 0x7fffffff);
+        f.seg_count = idx->ws.segcnt.as<int>();
+        f.tail_base = (int64_t)f.seg_cap * grid * 8;
+        f.tail_cap = 2 * cap - f.tail_base;
+        f.tail_count = &ctl->n_tail;
+        f.overflow = &ctl->overflow;
+        hipEvent_t stop;
+        VSC_TRY(prof_begin(idx, &stop, 1));
+        VSC_TRY(launch_sim_f16(f, idx->stream));
+        VSC_TRY(prof_end(idx, stop, 2.0 * (double)nqb * (double)idx->ntotal * (double)idx->dim, 1));
+        // 2. exact scores of the candidates; those above the radius join the kept hits
+        RescoreArgs r;
+        r.Q = qpacked;
+        r.R = idx->ref.as<float>();
+        r.dpad = idx->dpad;
+        r.cand_i = f.out_i;
+        r.cand_j = f.out_j;
+        r.n_seg = grid * 8;
+        r.seg_cap = f.seg_cap;
+        r.seg_count = f.seg_count;
+        r.tail_base = f.tail_base;
+        r.tail_cap = f.tail_cap;
+        r.tail_count = f.tail_count;
+        r.n_cand_total = &ctl->n_cand_total;
+        r.radius = &ctl->radius;
+        r.out_i = idx->ws.hA[0].as<int32_t>();
+        r.out_j = idx->ws.hA[1].as<int32_t>();
+        r.out_s = idx->ws.hA[2].as<float>();
+        r.counter = &ctl->n;
+        r.cap = cap;
+        r.overflow = &ctl->overflow;
+        VSC_TRY(prof_begin(idx, &stop, 2));
+        VSC_TRY(launch_rescore(r, idx->stream));
+        VSC_TRY(prof_end(idx, stop, 0.0, 2));
+        return VSC_OK;
+    }
     if (idx->metric == VSC_METRIC_INNER_PRODUCT) {
         SimThreshArgs a;
         a.Q = qpacked + i0 * idx->dpad;
@@ -342,7 +485,7 @@ int vsc_index_global_topk(vsc_index_t* idx, const float* q, int64_t nq, int q_me
     if (nq == 0 || idx->ntotal == 0) return VSC_OK;
     VSC_HIP(hipSetDevice(idx->device));
     float* qp = nullptr;
-    VSC_TRY(pack_queries(idx, q, nq, q_mem, &qp));
+    VSC_TRY(pack_queries(idx, q, nq, q_mem, &qp, idx->prefilter));
     const int64_t cap_max = nq * idx->ntotal + 1024;  // the whole score matrix always fits
     int64_t cap = idx->hit_cap_user;
     if (cap <= 0) cap = std::max<int64_t>(32 * idx->ntotal, 2 * K) + 2 * K + 1024;
@@ -357,7 +500,13 @@ int vsc_index_global_topk(vsc_index_t* idx, const float* q, int64_t nq, int q_me
         int64_t bs = 32, i0 = 0;
         while (i0 < nq) {
             const int64_t i1 = std::min(nq, i0 + bs);
-            VSC_TRY(enqueue_batch(idx, qp, i0, i1, cap));
+            // After i0 rows the radius sits near the K-th best of i0 * ntotal scores, so about
+            // K / (i0 * ntotal) of this batch's pairs are hits.  While that density is high the
+            // exact kernel is cheaper than pre-filtering and re-scoring nearly everything
+            // (exact: ~7.5 ps per pair; re-scoring: ~1 ns per candidate => break-even near 0.5 %).
+            const bool f16 = idx->prefilter_force ||
+                             (idx->prefilter && i0 > 0 && (double)K < 0.005 * (double)i0 * (double)idx->ntotal);
+            VSC_TRY(enqueue_batch(idx, qp, i0, i1, cap, f16));
             VSC_TRY(enqueue_rethreshold(ctl, idx->ws.hA[0].as<int32_t>(), idx->ws.hA[1].as<int32_t>(),
                                         idx->ws.hA[2].as<float>(), idx->ws.hB[0].as<int32_t>(),
                                         idx->ws.hB[1].as<int32_t>(), idx->ws.hB[2].as<float>(),
@@ -368,6 +517,7 @@ int vsc_index_global_topk(vsc_index_t* idx, const float* q, int64_t nq, int q_me
         VSC_HIP(hipMemcpyAsync(&h, ctl, sizeof(h), hipMemcpyDeviceToHost, idx->stream));
         VSC_HIP(hipStreamSynchronize(idx->stream));
         VSC_TRY(prof_collect(idx));
+        idx->stat_candidates = h.n_cand_total;
         if (!h.overflow) break;
         // A batch emitted more hits than the buffer holds (heavy score ties keep the radius low).
         // The schedule is deterministic, so simply rerun it with a larger buffer.
@@ -473,14 +623,17 @@ int vsc_index_range_search(vsc_index_t* idx, const float* q, int64_t nq, int q_m
     const bool ip = idx->metric == VSC_METRIC_INNER_PRODUCT;
     VSC_HIP(hipSetDevice(idx->device));
     float* qp = nullptr;
-    VSC_TRY(pack_queries(idx, q, nq, q_mem, &qp));
+    VSC_TRY(pack_queries(idx, q, nq, q_mem, &qp, idx->prefilter));
     int64_t cap = idx->hit_cap_user > 0 ? idx->hit_cap_user : std::min<int64_t>(nq * idx->ntotal, (int64_t)1 << 28);
     cap = std::max<int64_t>(cap, 1024);
     VSC_TRY(ensure_hit_buffers(idx, cap));
     VSC_TRY(init_ctl(idx, ip ? radius : -radius));
     SelectCtl* ctl = idx->ws.ctl.as<SelectCtl>();
     const int64_t step = 32768;
-    for (int64_t i0 = 0; i0 < nq; i0 += step) VSC_TRY(enqueue_batch(idx, qp, i0, std::min(nq, i0 + step), cap));
+    // fixed radius: the pre-filter is used throughout (a radius so low that most pairs pass would
+    // overflow the hit capacity on either route)
+    for (int64_t i0 = 0; i0 < nq; i0 += step)
+        VSC_TRY(enqueue_batch(idx, qp, i0, std::min(nq, i0 + step), cap, idx->prefilter));
     SelectCtl h;
     VSC_HIP(hipMemcpyAsync(&h, ctl, sizeof(h), hipMemcpyDeviceToHost, idx->stream));
     VSC_HIP(hipStreamSynchronize(idx->stream));
@@ -590,17 +743,29 @@ int vsc_index_profile(vsc_index_t* idx, int enable) {
     return VSC_OK;
 }
 
+int vsc_index_profile_read_class(vsc_index_t* idx, int cls, double* ms, int64_t* launches, double* work,
+                                 int reset) {
+    if (!idx || cls < 0 || cls > 2) return VSC_ERR_INVALID;
+    if (ms) *ms = idx->prof_ms[cls];
+    if (launches) *launches = idx->prof_launches[cls];
+    if (work) *work = idx->prof_work[cls];
+    if (reset) {
+        idx->prof_ms[cls] = 0.0;
+        idx->prof_work[cls] = 0.0;
+        idx->prof_launches[cls] = 0;
+    }
+    return VSC_OK;
+}
+
 int vsc_index_profile_read(vsc_index_t* idx, double* sim_ms, int64_t* sim_launches, double* sim_flops,
                            int reset) {
+    return vsc_index_profile_read_class(idx, 0, sim_ms, sim_launches, sim_flops, reset);
+}
+
+int vsc_index_search_stats(vsc_index_t* idx, int64_t* candidates, int64_t* hits) {
     if (!idx) return VSC_ERR_INVALID;
-    if (sim_ms) *sim_ms = idx->prof_ms;
-    if (sim_launches) *sim_launches = idx->prof_launches;
-    if (sim_flops) *sim_flops = idx->prof_flops;
-    if (reset) {
-        idx->prof_ms = 0.0;
-        idx->prof_flops = 0.0;
-        idx->prof_launches = 0;
-    }
+    if (candidates) *candidates = (int64_t)idx->stat_candidates;
+    if (hits) *hits = (int64_t)idx->stat_hits;
     return VSC_OK;
 }
 

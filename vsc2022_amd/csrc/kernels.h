@@ -10,6 +10,27 @@ struct SimThreshArgs {
     const float* radius; int32_t* out_i; int32_t* out_j; float* out_s;
     unsigned long long* counter; long long cap; int* overflow;
 };
+// fp16 pre-filter (sim_f16.hip): emits every (row, ref) whose fp16 score PLUS the tile's error bound
+// exceeds *radius -- a superset of the exact hits; rescore_candidates then applies the exact test.
+struct SimF16Args {
+    const _Float16* Q; const _Float16* R;  // fp16 images [rows pad 256][dpadh], natural k order
+    const float* qn; const float* rn;      // per-row upper bounds of the L2 norm (+inf: row not representable)
+    int dpadh; int nq; int i0; int nr; int tq; int tr;
+    float c1, c2, c3;                      // |fp16 score - exact score| <= c1*nq*nr + c2*(nq+nr) + c3
+    const float* radius; int32_t* out_i; int32_t* out_j;
+    // candidate list = one private segment of seg_cap entries per wave of the launch (8 per workgroup)
+    // + a shared tail (atomic counter) for waves whose segment is full
+    int seg_cap; int* seg_count; int64_t tail_base; long long tail_cap; unsigned long long* tail_count;
+    int* overflow;
+};
+struct RescoreArgs {
+    const float* Q; const float* R; int dpad;  // packed fp32 images (exact arithmetic contract)
+    const int32_t* cand_i; const int32_t* cand_j; int n_seg; int seg_cap; const int* seg_count;
+    int64_t tail_base; long long tail_cap; unsigned long long* tail_count;  // reset to 0 after the pass
+    unsigned long long* n_cand_total;      // statistics
+    const float* radius; int32_t* out_i; int32_t* out_j; float* out_s;
+    unsigned long long* counter; long long cap; int* overflow;
+};
 struct SimKnnArgs {
     const float* Q; const float* R; int dpad; int nq; int nr; int tq; int tr; int nchunk; int k;
     float* part_s; int32_t* part_j;
@@ -27,6 +48,8 @@ struct SelectCtl {
     unsigned long long n; unsigned long long n_tmp; float radius; int overflow; int active;
     unsigned int prefix; unsigned int prefix_mask; unsigned long long rank; unsigned int hist[256];
     unsigned long long n_rethreshold;
+    unsigned long long n_cand_total;  // pre-filter candidates of the whole search (statistics)
+    unsigned long long n_tail;        // fill level of the candidate list's shared tail (current batch)
 };
 struct TnPairArgs {
     const float* qfeat; const float* rfeat; const int64_t* q_off; const int64_t* r_off; int dpad;
@@ -39,6 +62,10 @@ struct TnPairArgs {
 struct TnSimsArgs { const float* qfeat; const float* rfeat; int64_t qrow0, rrow0; int lq, lr, dpad; float bias; float* out; };
 
 int launch_sim_thresh(const SimThreshArgs&, hipStream_t);
+int launch_sim_f16(const SimF16Args&, hipStream_t);
+int sim_f16_grid(int tq, int tr);
+int launch_rescore(const RescoreArgs&, hipStream_t);
+int launch_pack_half(const float*, int64_t, int, _Float16*, float*, int64_t, int, hipStream_t);
 int launch_sim_knn(const SimKnnArgs&, hipStream_t);
 int launch_knn_merge(const KnnMergeArgs&, hipStream_t);
 int launch_score_matrix(const ScoreMatArgs&, hipStream_t);

@@ -37,6 +37,49 @@ int launch_pack_rows(const float* src, int64_t n, int dim, float* dst, int64_t r
     return VSC_OK;
 }
 
+// fp16 image for the pre-filter GEMM (natural k order, rows zero-padded to dpadh) and, per row, an
+// UPPER bound of its L2 norm (the pre-filter's error bound is built from these).  A row with an
+// element fp16 cannot hold (NaN, inf, |x| > 65504) gets norm +inf: the pre-filter then passes every
+// pair of that row to the exact stage.  One wave per row; HBM-bound (4 B read + 2 B written per element).
+__global__ __launch_bounds__(256) void pack_half_kernel(const float* __restrict__ src, int64_t n, int dim,
+                                                        _Float16* __restrict__ dst, float* __restrict__ norms,
+                                                        int64_t rows_pad, int dpadh) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows_pad) return;
+    typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
+    half2_t* o = reinterpret_cast<half2_t*>(dst + row * dpadh);
+    const float* r = src + row * dim;
+    float ss = 0.0f;
+    bool bad = false;
+    for (int k = 2 * lane; k < dpadh; k += 128) {
+        const float x0 = (row < n && k < dim) ? r[k] : 0.0f;
+        const float x1 = (row < n && k + 1 < dim) ? r[k + 1] : 0.0f;
+        bad |= !(fabsf(x0) <= 65504.0f) || !(fabsf(x1) <= 65504.0f);
+        ss = __fmaf_rn(x0, x0, ss);
+        ss = __fmaf_rn(x1, x1, ss);
+        half2_t h;
+        h.x = (_Float16)x0;  // round to nearest even
+        h.y = (_Float16)x1;
+        o[k >> 1] = h;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) ss += __shfl_xor(ss, off);
+    const bool any_bad = __any(bad);
+    // fp32 summation error is <= dim * 2^-24 relative (all terms positive): 1.0005 covers dim <= 8192;
+    // larger rows use the +inf route
+    if (lane == 0) norms[row] = (any_bad || dim > 8192) ? INFINITY : sqrtf(ss) * 1.0005f;
+}
+
+int launch_pack_half(const float* src, int64_t n, int dim, _Float16* dst, float* norms, int64_t rows_pad,
+                     int dpadh, hipStream_t stream) {
+    if (rows_pad <= 0) return VSC_OK;
+    hipLaunchKernelGGL(pack_half_kernel, dim3((unsigned)((rows_pad + 3) / 4)), dim3(256), 0, stream, src, n,
+                       dim, dst, norms, rows_pad, dpadh);
+    VSC_HIP(hipGetLastError());
+    return VSC_OK;
+}
+
 // One wave per row.  The squared norm is the ascending-k fp32 fma chain (the oracle's order), so a
 // single lane walks the row for the norm; the division is done by all lanes.  Rows are short
 // (<= a few KB) and the kernel is bandwidth-trivial next to the search.

@@ -1,0 +1,389 @@
+// fp16 pre-filter of the thresholded search + exact re-scoring of its candidates (gfx950).
+//
+// The exact similarity (fp32 fma chain, sim_mfma.hip) runs at the fp32 matrix rate, 1/16 of the fp16
+// rate.  Almost every (query row, ref row) pair is far below the search radius, so the bulk of the
+// score matrix is first evaluated in fp16 with fp32 accumulation (v_mfma_f32_32x32x16_f16) and a pair
+// goes on to the exact stage only if its fp16 score PLUS a rigorous error bound exceeds the radius:
+//
+//     |fp16 score - exact score| <= c1 * |q| * |r| + c2 * (|q| + |r|)            (api.hip derives c1, c2)
+//
+// so the candidate set is a superset of the exact hit set and the final result is bit-identical to
+// the all-fp32 path (vsc/index.py:142-165 semantics unchanged; tests/test_gpu_prefilter.py).
+//
+//   sim_f16_kernel   : 256x256 output tile per workgroup step, 8 waves (2 x 4), wave tile 128x64 =
+//                      4x2 blocks of 32x32x16 MFMAs; operands by LDS-DMA into an XOR-swizzled image
+//                      (2 stages x 64 KiB); persistent workgroups (1 per CU) walk an XCD-aware raster.
+//                      MFMA-bound: 2*256*256*dpadh flop per tile.
+//   rescore_kernel   : one lane per candidate runs the exact ascending-k fp32 fma chain on the packed
+//                      fp32 rows; rows are brought in coalesced 256-byte pieces by LDS-DMA into a
+//                      swizzled per-wave LDS image.  HBM/L2-bound: 8*dpad bytes per candidate.
+#include "kernels.h"
+
+namespace vscmi {
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+namespace f16 {
+
+constexpr int BM = 256, BN = 256;
+constexpr int BK = 64;                       // fp16 elements per K-tile
+constexpr int ROWB = BK * 2;                 // bytes per row per K-tile (128)
+constexpr int TILE_BYTES = BM * ROWB;        // 32 KiB per operand
+constexpr int STAGE_BYTES = 2 * TILE_BYTES;  // A + B
+constexpr int LDS_BYTES = 2 * STAGE_BYTES;   // 128 KiB
+
+__device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rsrc, int voff, int soff, char* lds) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)lds, 16, voff,
+                                             soff, 0, 0);
+}
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t tile_rsrc(const void* base, int row_bytes) {
+    const uint64_t p = reinterpret_cast<uint64_t>(base);
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)p);
+    const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(p >> 32));
+    void* up = reinterpret_cast<void*>(((uint64_t)hi << 32) | lo);
+    return __builtin_amdgcn_make_buffer_rsrc(up, 0, BM * row_bytes, 0x00020000);
+}
+
+// Per-thread constants.  LDS image of one operand K-tile: 128 lines of 256 B; line l holds rows 2l
+// and 2l+1 (128 B each = 8 pieces of 16 B); piece c of a row sits at slot c ^ (l & 7) of its half
+// line, so the 16 lanes of one ds_read_b128 phase (16 consecutive rows, same piece) cover all 64 banks.
+struct TileThread {
+    int src_off[4];  // byte offset (inside the tile's rows) of the 4 DMA pieces per operand
+    int dst_off[4];  // wave-uniform LDS byte offset of those pieces
+    int rdA[4];      // LDS byte offset of A block m at k-step 0 (k-step ks: ^ (ks << 5))
+    int rdB[2];
+};
+
+__device__ __forceinline__ void tile_thread_init(TileThread& t, int tid, int row_bytes) {
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wr = wave >> 2, wc = wave & 3;
+#pragma unroll
+    for (int n = 0; n < 4; ++n) {
+        const int p = n * 512 + tid;
+        const int line = p >> 4, s = p & 15;
+        const int row = 2 * line + (s >> 3);
+        const int chunk = (s & 7) ^ (line & 7);
+        t.src_off[n] = row * row_bytes + chunk * 16;
+        t.dst_off[n] = (n * 512 + __builtin_amdgcn_readfirstlane(wave) * 64) * 16;
+    }
+    const int hi = lane >> 5;
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+        const int row = wr * 128 + m * 32 + (lane & 31);
+        const int line = row >> 1;
+        t.rdA[m] = line * 256 + ((((row & 1) << 3) | (hi ^ (line & 7))) << 4);
+    }
+#pragma unroll
+    for (int n = 0; n < 2; ++n) {
+        const int row = wc * 64 + n * 32 + (lane & 31);
+        const int line = row >> 1;
+        t.rdB[n] = line * 256 + ((((row & 1) << 3) | (hi ^ (line & 7))) << 4);
+    }
+}
+
+struct Frags {
+    f16x8 a[4], b[2];
+};
+
+__device__ __forceinline__ Frags read_frags(const char* stage, const TileThread& t, int ks) {
+    Frags f;
+#pragma unroll
+    for (int m = 0; m < 4; ++m) f.a[m] = *reinterpret_cast<const f16x8*>(stage + (t.rdA[m] ^ (ks << 5)));
+#pragma unroll
+    for (int n = 0; n < 2; ++n)
+        f.b[n] = *reinterpret_cast<const f16x8*>(stage + TILE_BYTES + (t.rdB[n] ^ (ks << 5)));
+    return f;
+}
+
+__device__ __forceinline__ void mfma8(const Frags& f, f32x16 (&acc)[4][2]) {
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.a[m], f.b[n], acc[m][n], 0, 0, 0);
+}
+
+__device__ __forceinline__ void stage_tiles(__amdgpu_buffer_rsrc_t ars, __amdgpu_buffer_rsrc_t brs, int kt,
+                                            char* stage, const TileThread& t) {
+#pragma unroll
+    for (int n = 0; n < 4; ++n) dma16(ars, t.src_off[n], kt * ROWB, stage + t.dst_off[n]);
+#pragma unroll
+    for (int n = 0; n < 4; ++n) dma16(brs, t.src_off[n], kt * ROWB, stage + TILE_BYTES + t.dst_off[n]);
+}
+
+// acc = Q[256 rows] . R[256 rows]^T over the whole (padded) dimension.  2-stage ring: K-tile kt lives
+// in stage kt & 1; the barrier of a K-tile sits before its last MFMA group (whose operands are
+// already in registers), after it the stage is free and the DMA of K-tile kt+2 goes out interleaved
+// with that group.
+__device__ __forceinline__ void tile_gemm(const _Float16* qrows, const _Float16* rrows, int dpadh, char* smem,
+                                          const TileThread& t, f32x16 (&acc)[4][2]) {
+    const __amdgpu_buffer_rsrc_t ars = tile_rsrc(qrows, dpadh * 2), brs = tile_rsrc(rrows, dpadh * 2);
+    const int nkt = dpadh / BK;  // >= 2 (dpadh is a multiple of 128)
+    stage_tiles(ars, brs, 0, smem, t);
+    __syncthreads();
+    stage_tiles(ars, brs, 1, smem + STAGE_BYTES, t);
+    Frags cur = read_frags(smem, t, 0);
+    int sp = 0;
+    // Register budget: 2 waves per SIMD => 256 VGPRs per lane, 128 of them accumulators.  The A fragment
+    // of the NEXT k-step is therefore read right after the two MFMAs that consumed the current one (it
+    // can reuse the same registers); only the two B fragments are double-buffered.
+    for (int kt = 0; kt < nkt; ++kt) {
+        const char* stage = smem + sp * STAGE_BYTES;
+#pragma unroll
+        for (int ks = 0; ks < 3; ++ks) {
+            f16x8 nb[2];
+#pragma unroll
+            for (int n = 0; n < 2; ++n)
+                nb[n] = *reinterpret_cast<const f16x8*>(stage + TILE_BYTES + (t.rdB[n] ^ ((ks + 1) << 5)));
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                acc[m][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur.a[m], cur.b[0], acc[m][0], 0, 0, 0);
+                acc[m][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur.a[m], cur.b[1], acc[m][1], 0, 0, 0);
+                cur.a[m] = *reinterpret_cast<const f16x8*>(stage + (t.rdA[m] ^ ((ks + 1) << 5)));
+            }
+            cur.b[0] = nb[0];
+            cur.b[1] = nb[1];
+        }
+        // last k-step of the K-tile: every fragment of this stage is in registers
+        const bool n1 = kt + 1 < nkt, n2 = kt + 2 < nkt;
+        const char* nstage = smem + (sp ^ 1) * STAGE_BYTES;
+        char* wstage = smem + sp * STAGE_BYTES;
+        const int soff = (kt + 2) * ROWB;
+        f16x8 nb[2] = {cur.b[0], cur.b[1]};
+        if (n1) {
+            __syncthreads();  // K-tile kt+1 has landed; nobody reads this stage any more
+#pragma unroll
+            for (int n = 0; n < 2; ++n) nb[n] = *reinterpret_cast<const f16x8*>(nstage + TILE_BYTES + t.rdB[n]);
+        }
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            acc[m][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur.a[m], cur.b[0], acc[m][0], 0, 0, 0);
+            if (n2) dma16(ars, t.src_off[m], soff, wstage + t.dst_off[m]);
+            acc[m][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur.a[m], cur.b[1], acc[m][1], 0, 0, 0);
+            if (n2) dma16(brs, t.src_off[m], soff, wstage + TILE_BYTES + t.dst_off[m]);
+            if (n1) cur.a[m] = *reinterpret_cast<const f16x8*>(nstage + t.rdA[m]);
+        }
+        cur.b[0] = nb[0];
+        cur.b[1] = nb[1];
+        sp ^= 1;
+    }
+}
+
+// XCD-aware raster (workgroup b runs on XCD b % 8): every XCD owns a contiguous run of tiles and walks
+// it in bands of GQ query tiles, ref tile fastest inside... query tile fastest inside a band column, so
+// the tiles in flight on one XCD share GQ query panels and a short run of ref panels in its L2.
+__device__ __forceinline__ bool raster(int xcd, int64_t local, int tq, int64_t tr, int& tqi, int64_t& tri) {
+    const int64_t nblk = (int64_t)tq * tr;
+    const int64_t per_xcd = (nblk + 7) / 8;
+    const int64_t logical = (int64_t)xcd * per_xcd + local;
+    if (local >= per_xcd || logical >= nblk) return false;
+    constexpr int GQ = 4;
+    const int64_t band_sz = (int64_t)GQ * tr;
+    const int64_t band = logical / band_sz, rem = logical % band_sz;
+    const int q0 = (int)band * GQ;
+    const int gq = (tq - q0) < GQ ? (tq - q0) : GQ;
+    tri = rem / gq;
+    tqi = q0 + (int)(rem % gq);
+    return true;
+}
+
+// Candidates of one wave tile -> the wave's PRIVATE segment of the candidate list: no atomics, no
+// scans.  Per accumulator register one ballot; the (rare) non-empty ones are ranked with mbcnt.
+// `count` is the wave-uniform fill level of the segment.
+__device__ __forceinline__ void emit_candidates(const SimF16Args& a, bool all, float thr, int row0, int64_t col0,
+                                                const f32x16 (&acc)[4][2], int lane, int64_t seg_base,
+                                                int seg_cap, int& count) {
+    // C layout of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
+    const int row_base = row0 + 4 * (lane >> 5);
+    const int col_base = (int)col0 + (lane & 31);
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const unsigned long long hits = __ballot(all || acc[m][n][r] > thr);
+                if (hits == 0ull) continue;
+                const int i = row_base + m * 32 + (r & 3) + 8 * (r >> 2);
+                const int j = col_base + n * 32;
+                const unsigned long long ok = __ballot(((hits >> lane) & 1ull) && i < a.nq && j < a.nr);
+                if (ok == 0ull) continue;
+                const int total = __popcll(ok);
+                int64_t pos;
+                if (count + total <= seg_cap) {
+                    pos = seg_base + count;
+                    count += total;
+                } else {
+                    // segment full (candidates are not spread evenly): shared tail behind the segments
+                    unsigned long long base = 0;
+                    if (lane == 0) base = atomicAdd(a.tail_count, (unsigned long long)total);
+                    base = __shfl(base, 0);
+                    if ((long long)(base + total) > a.tail_cap) {
+                        if (lane == 0) atomicOr(a.overflow, 1);
+                        continue;
+                    }
+                    pos = a.tail_base + (int64_t)base;
+                }
+                if ((ok >> lane) & 1ull) {
+                    pos += __popcll(ok & ((1ull << lane) - 1));
+                    a.out_i[pos] = a.i0 + i;
+                    a.out_j[pos] = j;
+                }
+            }
+}
+
+}  // namespace f16
+
+__global__ __launch_bounds__(512, 1) void sim_f16_kernel(SimF16Args a) {
+    using namespace f16;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    __shared__ float norm_max[8];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave >> 2, wc = wave & 3;
+    TileThread t;
+    tile_thread_init(t, tid, a.dpadh * 2);
+    const float radius = *a.radius;
+    const int xcd = blockIdx.x & 7;
+    const int64_t lstride = gridDim.x >> 3;  // gridDim.x is a multiple of 8
+    // this wave's private segment of the candidate list
+    const int seg = blockIdx.x * 8 + __builtin_amdgcn_readfirstlane(wave);
+    const int64_t seg_base = (int64_t)seg * a.seg_cap;
+    int count = 0;
+    for (int64_t local = blockIdx.x >> 3;; local += lstride) {
+        int tqi;
+        int64_t tri;
+        if (!raster(xcd, local, a.tq, a.tr, tqi, tri)) break;
+        // largest row norm of each side of the tile (waves 0-3: query rows, 4-7: ref rows)
+        float nv = tid < 256 ? a.qn[(int64_t)tqi * BM + tid] : a.rn[tri * BN + (tid - 256)];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) nv = fmaxf(nv, __shfl_xor(nv, off));
+        if (lane == 0) norm_max[wave] = nv;
+        f32x16 acc[4][2];
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int n = 0; n < 2; ++n)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.0f;
+        tile_gemm(a.Q + (int64_t)tqi * BM * a.dpadh, a.R + tri * BN * a.dpadh, a.dpadh, smem, t, acc);
+        // (the barriers of the K loop ordered the norm_max writes)
+        const float nq = fmaxf(fmaxf(norm_max[0], norm_max[1]), fmaxf(norm_max[2], norm_max[3]));
+        const float nr = fmaxf(fmaxf(norm_max[4], norm_max[5]), fmaxf(norm_max[6], norm_max[7]));
+        const float eps = (a.c1 * nq * nr + a.c2 * (nq + nr) + a.c3) * 1.001f;
+        const bool all = !(eps < INFINITY);  // also catches NaN (inf * 0)
+        // rounding of the subtraction itself: < 2^-23 relative to the larger operand
+        const float thr = (radius - eps) - 2.4e-7f * (fabsf(radius) + eps);
+        float mx = -INFINITY;
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int n = 0; n < 2; ++n)
+#pragma unroll
+                for (int r = 0; r < 16; r += 2)
+                    mx = fmaxf(mx, fmaxf(acc[m][n][r], acc[m][n][r + 1]));
+        if (all || __any(mx > thr))
+            emit_candidates(a, all, thr, tqi * BM + wr * 128, tri * BN + wc * 64, acc, lane, seg_base, a.seg_cap,
+                            count);
+        __syncthreads();  // the LDS ring and norm_max restart with the next tile
+    }
+    if (lane == 0) a.seg_count[seg] = count;
+}
+
+// grid of a launch: one persistent workgroup per CU (fewer for tiny problems); 8 segments each
+int sim_f16_grid(int tq, int tr) {
+    const int64_t nblk = (int64_t)tq * tr;
+    int64_t grid = ((nblk + 7) / 8) * 8;
+    if (grid > 256) grid = 256;
+    return (int)grid;
+}
+
+int launch_sim_f16(const SimF16Args& a, hipStream_t stream) {
+    static bool attr_done = false;
+    if (!attr_done) {
+        VSC_HIP(hipFuncSetAttribute((const void*)sim_f16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    f16::LDS_BYTES));
+        attr_done = true;
+    }
+    const int grid = sim_f16_grid(a.tq, a.tr);
+    if (grid <= 0) return VSC_OK;
+    hipLaunchKernelGGL(sim_f16_kernel, dim3((unsigned)grid), dim3(512), f16::LDS_BYTES, stream, a);
+    VSC_HIP(hipGetLastError());
+    return VSC_OK;
+}
+
+// ------------------------------------------------------------------------------ exact stage
+//
+// One lane per candidate: acc = fmaf(q[k], r[k], acc), k ascending (the arithmetic contract of the
+// engine; packed rows hold every group of 8 k as [k0 k2 k4 k6 | k1 k3 k5 k7]).
+
+// candidates [x0, x0 + step*k) of one list, `step` threads apart (whole waves stay together)
+__device__ __forceinline__ void rescore_list(const RescoreArgs& a, float radius, const int32_t* ci,
+                                             const int32_t* cj, long long n, long long x0, long long step) {
+    const int lane = threadIdx.x & 63;
+    const long long n_round = (n + 63) & ~63ll;
+    for (long long x = x0; x < n_round; x += step) {
+        const bool valid = x < n;
+        const int i = valid ? ci[x] : 0, j = valid ? cj[x] : 0;
+        const f32x4* q = reinterpret_cast<const f32x4*>(a.Q + (int64_t)i * a.dpad);
+        const f32x4* r = reinterpret_cast<const f32x4*>(a.R + (int64_t)j * a.dpad);
+        float acc = 0.0f;
+        for (int g = 0; g < a.dpad / 8; ++g) {
+            const f32x4 qe = q[2 * g], qo = q[2 * g + 1], re = r[2 * g], ro = r[2 * g + 1];
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                acc = __fmaf_rn(qe[s], re[s], acc);
+                acc = __fmaf_rn(qo[s], ro[s], acc);
+            }
+        }
+        const bool hit = valid && acc > radius;
+        const unsigned long long m = __ballot(hit);
+        if (!m) continue;
+        unsigned long long base = 0;
+        if (lane == 0) base = atomicAdd(a.counter, (unsigned long long)__popcll(m));
+        base = __shfl(base, 0);
+        if ((long long)(base + __popcll(m)) > a.cap) {
+            if (lane == 0) atomicOr(a.overflow, 1);
+            continue;
+        }
+        if (hit) {
+            const unsigned long long pos = base + __popcll(m & ((1ull << lane) - 1));
+            a.out_i[pos] = i;
+            a.out_j[pos] = j;
+            a.out_s[pos] = acc;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void rescore_kernel(RescoreArgs a) {
+    const float radius = *a.radius;
+    unsigned long long seen = 0;
+    for (int seg = blockIdx.x; seg < a.n_seg; seg += gridDim.x) {
+        const int n = min(a.seg_count[seg], a.seg_cap);
+        seen += (unsigned long long)n;
+        rescore_list(a, radius, a.cand_i + (int64_t)seg * a.seg_cap, a.cand_j + (int64_t)seg * a.seg_cap, n,
+                     threadIdx.x, 256);
+    }
+    // shared tail (normally empty)
+    const unsigned long long nt_all = *a.tail_count;
+    const long long nt = nt_all < (unsigned long long)a.tail_cap ? (long long)nt_all : a.tail_cap;
+    if (nt > 0) {
+        rescore_list(a, radius, a.cand_i + a.tail_base, a.cand_j + a.tail_base, nt,
+                     (long long)blockIdx.x * 256 + threadIdx.x, (long long)gridDim.x * 256);
+        if (blockIdx.x == 0) seen += (unsigned long long)nt;
+    }
+    if (threadIdx.x == 0 && seen) atomicAdd(a.n_cand_total, seen);
+}
+
+__global__ void tail_reset_kernel(unsigned long long* tail_count) { *tail_count = 0; }
+
+int launch_rescore(const RescoreArgs& a, hipStream_t stream) {
+    if (a.n_seg <= 0) return VSC_OK;
+    hipLaunchKernelGGL(rescore_kernel, dim3((unsigned)a.n_seg), dim3(256), 0, stream, a);
+    hipLaunchKernelGGL(tail_reset_kernel, dim3(1), dim3(1), 0, stream, a.tail_count);
+    VSC_HIP(hipGetLastError());
+    return VSC_OK;
+}
+
+}  // namespace vscmi

@@ -233,7 +233,16 @@ class FlatIndex:
         ms, n, fl = ctypes.c_double(0), ctypes.c_int64(0), ctypes.c_double(0)
         _lib.check(_lib.lib().vsc_index_profile_read(self._h, ctypes.byref(ms), ctypes.byref(n),
                                                      ctypes.byref(fl), 1 if reset else 0))
-        return {"sim_ms": ms.value, "sim_launches": n.value, "sim_flops": fl.value}
+        out = {"sim_ms": ms.value, "sim_launches": n.value, "sim_flops": fl.value}
+        # per kernel class: fp16 pre-filter GEMM and exact re-scoring of its candidates
+        for cls, name in ((1, "f16"), (2, "rescore")):
+            _lib.check(_lib.lib().vsc_index_profile_read_class(self._h, cls, ctypes.byref(ms), ctypes.byref(n),
+                                                               ctypes.byref(fl), 1 if reset else 0))
+            out.update({f"{name}_ms": ms.value, f"{name}_launches": n.value, f"{name}_flops": fl.value})
+        cand, hits = ctypes.c_int64(0), ctypes.c_int64(0)
+        _lib.check(_lib.lib().vsc_index_search_stats(self._h, ctypes.byref(cand), ctypes.byref(hits)))
+        out["candidates"] = cand.value
+        return out
 
 
 class _RowToVideoId(Sequence):
