@@ -113,22 +113,44 @@ __device__ __forceinline__ void stage_tiles(__amdgpu_buffer_rsrc_t ars, __amdgpu
     for (int n = 0; n < 4; ++n) dma16(brs, t.src_off[n], kt * ROWB, stage + TILE_BYTES + t.dst_off[n]);
 }
 
-// acc = Q[256 rows] . R[256 rows]^T over the whole (padded) dimension.  2-stage ring: K-tile kt lives
-// in stage kt & 1; the barrier of a K-tile sits before its last MFMA group (whose operands are
-// already in registers), after it the stage is free and the DMA of K-tile kt+2 goes out interleaved
-// with that group.
-__device__ __forceinline__ void tile_gemm(const _Float16* qrows, const _Float16* rrows, int dpadh, char* smem,
-                                          const TileThread& t, f32x16 (&acc)[4][2]) {
+// The tile stream.  A workgroup is persistent: the K-tiles of the output tiles it walks form ONE stream
+// through the 2-stage LDS ring (K-tile n of the stream lives in stage n & 1), so only the first tile of a
+// workgroup pays a load prologue: while the last two K-tiles of tile T are multiplied, the first two of
+// tile T+1 are already in flight, and they land during T's epilogue.
+struct TileStream {
+    const _Float16* q;  // operand panels of the current tile (wave-uniform)
+    const _Float16* r;
+    Frags cur;          // fragments (K-tile 0, k-step 0) of the current tile
+    int sp;             // LDS stage holding K-tile 0 of the current tile
+};
+
+__device__ __forceinline__ void stream_begin(TileStream& st, const _Float16* qrows, const _Float16* rrows,
+                                             int dpadh, char* smem, const TileThread& t) {
+    st.q = qrows;
+    st.r = rrows;
+    st.sp = 0;
     const __amdgpu_buffer_rsrc_t ars = tile_rsrc(qrows, dpadh * 2), brs = tile_rsrc(rrows, dpadh * 2);
-    const int nkt = dpadh / BK;  // >= 2 (dpadh is a multiple of 128)
     stage_tiles(ars, brs, 0, smem, t);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    stage_tiles(ars, brs, 1, smem + STAGE_BYTES, t);
-    Frags cur = read_frags(smem, t, 0);
-    int sp = 0;
-    // Register budget: 2 waves per SIMD => 256 VGPRs per lane, 128 of them accumulators.  The A fragment
-    // of the NEXT k-step is therefore read right after the two MFMAs that consumed the current one (it
-    // can reuse the same registers); only the two B fragments are double-buffered.
+    stage_tiles(ars, brs, 1, smem + STAGE_BYTES, t);  // dpadh >= 128: K-tile 1 always exists
+    st.cur = read_frags(smem, t, 0);
+}
+
+// acc += Q[256 rows] . R[256 rows]^T of the stream's current tile; the stream is left on the tile whose
+// panels start at (nq, nr).  For the last tile of a workgroup pass the current panels again: the loop
+// body has no conditionals (the two K-tiles it then fetches past the end are never read).
+//
+// Per K-tile (4 k-steps of 8 MFMAs): the barrier sits before the LAST k-step, whose operands are already
+// in registers; after it the stage is free, and the DMA of the K-tile two ahead goes out interleaved with
+// those 8 MFMAs.  Register budget: 2 waves per SIMD => 256 VGPRs per lane, 128 of them accumulators; the A
+// fragment of the NEXT k-step is read right after the two MFMAs that consumed the current one (same
+// registers), only the two B fragments are double-buffered.
+__device__ __forceinline__ void stream_tile(TileStream& st, const _Float16* nq, const _Float16* nr, int dpadh,
+                                            char* smem, const TileThread& t, f32x16 (&acc)[4][2]) {
+    const int nkt = dpadh / BK;  // >= 2
+    Frags cur = st.cur;
+    int sp = st.sp;
     for (int kt = 0; kt < nkt; ++kt) {
         const char* stage = smem + sp * STAGE_BYTES;
 #pragma unroll
@@ -147,28 +169,37 @@ __device__ __forceinline__ void tile_gemm(const _Float16* qrows, const _Float16*
             cur.b[1] = nb[1];
         }
         // last k-step of the K-tile: every fragment of this stage is in registers
-        const bool n1 = kt + 1 < nkt, n2 = kt + 2 < nkt;
+        const int k2 = kt + 2;
+        const bool in_cur = k2 < nkt;
+        const __amdgpu_buffer_rsrc_t ars = tile_rsrc(in_cur ? st.q : nq, dpadh * 2);
+        const __amdgpu_buffer_rsrc_t brs = tile_rsrc(in_cur ? st.r : nr, dpadh * 2);
+        const int soff = (in_cur ? k2 : k2 - nkt) * ROWB;
         const char* nstage = smem + (sp ^ 1) * STAGE_BYTES;
         char* wstage = smem + sp * STAGE_BYTES;
-        const int soff = (kt + 2) * ROWB;
-        f16x8 nb[2] = {cur.b[0], cur.b[1]};
-        if (n1) {
-            __syncthreads();  // K-tile kt+1 has landed; nobody reads this stage any more
+        // The next K-tile of the stream has landed once EVERY wave's own LDS-DMA pieces have: drain this
+        // wave's count before the barrier (the compiler does not always do it for the builtin -- without
+        // the wait a wave could read pieces another wave's DMA has not delivered yet).
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();  // ... and nobody reads this stage any more
+        f16x8 nb[2];
 #pragma unroll
-            for (int n = 0; n < 2; ++n) nb[n] = *reinterpret_cast<const f16x8*>(nstage + TILE_BYTES + t.rdB[n]);
-        }
+        for (int n = 0; n < 2; ++n) nb[n] = *reinterpret_cast<const f16x8*>(nstage + TILE_BYTES + t.rdB[n]);
 #pragma unroll
         for (int m = 0; m < 4; ++m) {
             acc[m][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur.a[m], cur.b[0], acc[m][0], 0, 0, 0);
-            if (n2) dma16(ars, t.src_off[m], soff, wstage + t.dst_off[m]);
+            dma16(ars, t.src_off[m], soff, wstage + t.dst_off[m]);
             acc[m][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur.a[m], cur.b[1], acc[m][1], 0, 0, 0);
-            if (n2) dma16(brs, t.src_off[m], soff, wstage + TILE_BYTES + t.dst_off[m]);
-            if (n1) cur.a[m] = *reinterpret_cast<const f16x8*>(nstage + t.rdA[m]);
+            dma16(brs, t.src_off[m], soff, wstage + TILE_BYTES + t.dst_off[m]);
+            cur.a[m] = *reinterpret_cast<const f16x8*>(nstage + t.rdA[m]);
         }
         cur.b[0] = nb[0];
         cur.b[1] = nb[1];
         sp ^= 1;
     }
+    st.cur = cur;
+    st.sp = sp;
+    st.q = nq;
+    st.r = nr;
 }
 
 // XCD-aware raster (workgroup b runs on XCD b % 8): every XCD owns a contiguous run of tiles and walks
@@ -239,7 +270,7 @@ __device__ __forceinline__ void emit_candidates(const SimF16Args& a, bool all, f
 __global__ __launch_bounds__(512, 1) void sim_f16_kernel(SimF16Args a) {
     using namespace f16;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    __shared__ float norm_max[8];
+    __shared__ float norm_max_buf[2][8];  // double-buffered by tile parity (no barrier between tiles)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave >> 2, wc = wave & 3;
     TileThread t;
@@ -251,10 +282,20 @@ __global__ __launch_bounds__(512, 1) void sim_f16_kernel(SimF16Args a) {
     const int seg = blockIdx.x * 8 + __builtin_amdgcn_readfirstlane(wave);
     const int64_t seg_base = (int64_t)seg * a.seg_cap;
     int count = 0;
-    for (int64_t local = blockIdx.x >> 3;; local += lstride) {
-        int tqi;
-        int64_t tri;
-        if (!raster(xcd, local, a.tq, a.tr, tqi, tri)) break;
+    int64_t local = blockIdx.x >> 3;
+    int tqi;
+    int64_t tri;
+    if (!raster(xcd, local, a.tq, a.tr, tqi, tri)) {
+        if (lane == 0) a.seg_count[seg] = 0;
+        return;
+    }
+    TileStream st;
+    stream_begin(st, a.Q + (int64_t)tqi * BM * a.dpadh, a.R + tri * BN * a.dpadh, a.dpadh, smem, t);
+    for (int parity = 0;; parity ^= 1) {
+        int ntq = 0;
+        int64_t ntr = 0;
+        const bool has_next = raster(xcd, local + lstride, a.tq, a.tr, ntq, ntr);
+        float* norm_max = norm_max_buf[parity];
         // largest row norm of each side of the tile (waves 0-3: query rows, 4-7: ref rows)
         float nv = tid < 256 ? a.qn[(int64_t)tqi * BM + tid] : a.rn[tri * BN + (tid - 256)];
 #pragma unroll
@@ -267,7 +308,8 @@ __global__ __launch_bounds__(512, 1) void sim_f16_kernel(SimF16Args a) {
             for (int n = 0; n < 2; ++n)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.0f;
-        tile_gemm(a.Q + (int64_t)tqi * BM * a.dpadh, a.R + tri * BN * a.dpadh, a.dpadh, smem, t, acc);
+        stream_tile(st, has_next ? a.Q + (int64_t)ntq * BM * a.dpadh : st.q,
+                    has_next ? a.R + ntr * BN * a.dpadh : st.r, a.dpadh, smem, t, acc);
         // (the barriers of the K loop ordered the norm_max writes)
         const float nq = fmaxf(fmaxf(norm_max[0], norm_max[1]), fmaxf(norm_max[2], norm_max[3]));
         const float nr = fmaxf(fmaxf(norm_max[4], norm_max[5]), fmaxf(norm_max[6], norm_max[7]));
@@ -286,8 +328,13 @@ __global__ __launch_bounds__(512, 1) void sim_f16_kernel(SimF16Args a) {
         if (all || __any(mx > thr))
             emit_candidates(a, all, thr, tqi * BM + wr * 128, tri * BN + wc * 64, acc, lane, seg_base, a.seg_cap,
                             count);
-        __syncthreads();  // the LDS ring and norm_max restart with the next tile
+        if (!has_next) break;
+        local += lstride;
+        tqi = ntq;
+        tri = ntr;
     }
+    // the stream fetched two K-tiles past its end: let them land before the LDS is handed back
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (lane == 0) a.seg_count[seg] = count;
 }
 

@@ -135,6 +135,9 @@ __device__ __forceinline__ void stream_begin(TileStream& st, const float* qrow0,
     st.sp = 0;
     const __amdgpu_buffer_rsrc_t qrs = tile_rsrc(qrow0, dpad), rrs = tile_rsrc(rrow0, dpad);
     stage_tiles(qrs, rrs, 0, smem, t);
+    // explicit: a K-tile has landed only when EVERY wave's own LDS-DMA count has drained (the compiler
+    // usually adds this wait before the barrier, but not reliably for the builtin -- see sim_f16.hip)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();  // K-tile 0 landed
     stage_tiles(qrs, rrs, 1, smem + STAGE_BYTES, t);  // dpad >= 64: K-tile 1 always exists
     st.cur = read_frags(smem, t, 0);
@@ -175,6 +178,7 @@ __device__ __forceinline__ void stream_tile(TileStream& st, bool has_next, const
         Frags nxt = cur;
         if (n1) {
             // the next K-tile (issued one K-tile ago) has landed once every wave's DMA count drains
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
             nxt = read_frags(smem + (sp ^ 1) * STAGE_BYTES, t, 0);
         }
