@@ -165,6 +165,14 @@ __device__ __forceinline__ void stream_tile(TileStream& st, const _Float16* nq, 
                 acc[m][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur.a[m], cur.b[1], acc[m][1], 0, 0, 0);
                 cur.a[m] = *reinterpret_cast<const f16x8*>(stage + (t.rdA[m] ^ ((ks + 1) << 5)));
             }
+            // pin the order: left alone, the scheduler sinks every fragment read to just before its use
+            // and exposes the LDS latency once per k-step
+            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            }
             cur.b[0] = nb[0];
             cur.b[1] = nb[1];
         }
@@ -210,7 +218,7 @@ __device__ __forceinline__ bool raster(int xcd, int64_t local, int tq, int64_t t
     const int64_t per_xcd = (nblk + 7) / 8;
     const int64_t logical = (int64_t)xcd * per_xcd + local;
     if (local >= per_xcd || logical >= nblk) return false;
-    constexpr int GQ = 4;
+    constexpr int GQ = 8;
     const int64_t band_sz = (int64_t)GQ * tr;
     const int64_t band = logical / band_sz, rem = logical % band_sz;
     const int q0 = (int)band * GQ;
@@ -232,7 +240,12 @@ __device__ __forceinline__ void emit_candidates(const SimF16Args& a, bool all, f
 #pragma unroll
     for (int m = 0; m < 4; ++m)
 #pragma unroll
-        for (int n = 0; n < 2; ++n)
+        for (int n = 0; n < 2; ++n) {
+            // candidates are rare: first ask per 32x32 block (16 registers), then per register
+            float bm = acc[m][n][0];
+#pragma unroll
+            for (int r = 1; r < 16; ++r) bm = fmaxf(bm, acc[m][n][r]);
+            if (!all && !__any(bm > thr)) continue;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const unsigned long long hits = __ballot(all || acc[m][n][r] > thr);
@@ -263,6 +276,7 @@ __device__ __forceinline__ void emit_candidates(const SimF16Args& a, bool all, f
                     a.out_j[pos] = j;
                 }
             }
+        }
 }
 
 }  // namespace f16
