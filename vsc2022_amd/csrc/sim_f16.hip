@@ -146,64 +146,75 @@ __device__ __forceinline__ void stream_begin(TileStream& st, const _Float16* qro
 // those 8 MFMAs.  Register budget: 2 waves per SIMD => 256 VGPRs per lane, 128 of them accumulators; the A
 // fragment of the NEXT k-step is read right after the two MFMAs that consumed the current one (same
 // registers), only the two B fragments are double-buffered.
+//
+// FIRST = first K-tile of an output tile: its first k-step multiplies onto a literal zero (srcC is an
+// inline constant), so the 128 accumulators are never cleared with VALU moves.
+template <bool FIRST>
+__device__ __forceinline__ void stream_ktile(TileStream& st, const _Float16* nq, const _Float16* nr, int dpadh,
+                                             int kt, int nkt, Frags& cur, int& sp, char* smem,
+                                             const TileThread& t, f32x16 (&acc)[4][2]) {
+    const f32x16 zero = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+    const char* stage = smem + sp * STAGE_BYTES;
+#pragma unroll
+    for (int ks = 0; ks < 3; ++ks) {
+        f16x8 nb[2];
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+            nb[n] = *reinterpret_cast<const f16x8*>(stage + TILE_BYTES + (t.rdB[n] ^ ((ks + 1) << 5)));
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            acc[m][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur.a[m], cur.b[0], (FIRST && ks == 0) ? zero : acc[m][0], 0, 0, 0);
+            acc[m][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur.a[m], cur.b[1], (FIRST && ks == 0) ? zero : acc[m][1], 0, 0, 0);
+            cur.a[m] = *reinterpret_cast<const f16x8*>(stage + (t.rdA[m] ^ ((ks + 1) << 5)));
+        }
+        // pin the order: left alone, the scheduler sinks every fragment read to just before its use
+        // and exposes the LDS latency once per k-step
+        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
+        cur.b[0] = nb[0];
+        cur.b[1] = nb[1];
+    }
+    // last k-step of the K-tile: every fragment of this stage is in registers
+    const int k2 = kt + 2;
+    const bool in_cur = k2 < nkt;
+    const __amdgpu_buffer_rsrc_t ars = tile_rsrc(in_cur ? st.q : nq, dpadh * 2);
+    const __amdgpu_buffer_rsrc_t brs = tile_rsrc(in_cur ? st.r : nr, dpadh * 2);
+    const int soff = (in_cur ? k2 : k2 - nkt) * ROWB;
+    const char* nstage = smem + (sp ^ 1) * STAGE_BYTES;
+    char* wstage = smem + sp * STAGE_BYTES;
+    // The next K-tile of the stream has landed once EVERY wave's own LDS-DMA pieces have: drain this
+    // wave's count before the barrier (the compiler does not always do it for the builtin -- without
+    // the wait a wave could read pieces another wave's DMA has not delivered yet).
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();  // ... and nobody reads this stage any more
+    f16x8 nb[2];
+#pragma unroll
+    for (int n = 0; n < 2; ++n) nb[n] = *reinterpret_cast<const f16x8*>(nstage + TILE_BYTES + t.rdB[n]);
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+        acc[m][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur.a[m], cur.b[0], acc[m][0], 0, 0, 0);
+        dma16(ars, t.src_off[m], soff, wstage + t.dst_off[m]);
+        acc[m][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur.a[m], cur.b[1], acc[m][1], 0, 0, 0);
+        dma16(brs, t.src_off[m], soff, wstage + TILE_BYTES + t.dst_off[m]);
+        cur.a[m] = *reinterpret_cast<const f16x8*>(nstage + t.rdA[m]);
+    }
+    cur.b[0] = nb[0];
+    cur.b[1] = nb[1];
+    sp ^= 1;
+}
+
+// acc = (not +=) the tile's product; acc needs no initialisation.
 __device__ __forceinline__ void stream_tile(TileStream& st, const _Float16* nq, const _Float16* nr, int dpadh,
                                             char* smem, const TileThread& t, f32x16 (&acc)[4][2]) {
     const int nkt = dpadh / BK;  // >= 2
     Frags cur = st.cur;
     int sp = st.sp;
-    for (int kt = 0; kt < nkt; ++kt) {
-        const char* stage = smem + sp * STAGE_BYTES;
-#pragma unroll
-        for (int ks = 0; ks < 3; ++ks) {
-            f16x8 nb[2];
-#pragma unroll
-            for (int n = 0; n < 2; ++n)
-                nb[n] = *reinterpret_cast<const f16x8*>(stage + TILE_BYTES + (t.rdB[n] ^ ((ks + 1) << 5)));
-#pragma unroll
-            for (int m = 0; m < 4; ++m) {
-                acc[m][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur.a[m], cur.b[0], acc[m][0], 0, 0, 0);
-                acc[m][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur.a[m], cur.b[1], acc[m][1], 0, 0, 0);
-                cur.a[m] = *reinterpret_cast<const f16x8*>(stage + (t.rdA[m] ^ ((ks + 1) << 5)));
-            }
-            // pin the order: left alone, the scheduler sinks every fragment read to just before its use
-            // and exposes the LDS latency once per k-step
-            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-#pragma unroll
-            for (int m = 0; m < 4; ++m) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
-                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-            }
-            cur.b[0] = nb[0];
-            cur.b[1] = nb[1];
-        }
-        // last k-step of the K-tile: every fragment of this stage is in registers
-        const int k2 = kt + 2;
-        const bool in_cur = k2 < nkt;
-        const __amdgpu_buffer_rsrc_t ars = tile_rsrc(in_cur ? st.q : nq, dpadh * 2);
-        const __amdgpu_buffer_rsrc_t brs = tile_rsrc(in_cur ? st.r : nr, dpadh * 2);
-        const int soff = (in_cur ? k2 : k2 - nkt) * ROWB;
-        const char* nstage = smem + (sp ^ 1) * STAGE_BYTES;
-        char* wstage = smem + sp * STAGE_BYTES;
-        // The next K-tile of the stream has landed once EVERY wave's own LDS-DMA pieces have: drain this
-        // wave's count before the barrier (the compiler does not always do it for the builtin -- without
-        // the wait a wave could read pieces another wave's DMA has not delivered yet).
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();  // ... and nobody reads this stage any more
-        f16x8 nb[2];
-#pragma unroll
-        for (int n = 0; n < 2; ++n) nb[n] = *reinterpret_cast<const f16x8*>(nstage + TILE_BYTES + t.rdB[n]);
-#pragma unroll
-        for (int m = 0; m < 4; ++m) {
-            acc[m][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur.a[m], cur.b[0], acc[m][0], 0, 0, 0);
-            dma16(ars, t.src_off[m], soff, wstage + t.dst_off[m]);
-            acc[m][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur.a[m], cur.b[1], acc[m][1], 0, 0, 0);
-            dma16(brs, t.src_off[m], soff, wstage + TILE_BYTES + t.dst_off[m]);
-            cur.a[m] = *reinterpret_cast<const f16x8*>(nstage + t.rdA[m]);
-        }
-        cur.b[0] = nb[0];
-        cur.b[1] = nb[1];
-        sp ^= 1;
-    }
+    stream_ktile<true>(st, nq, nr, dpadh, 0, nkt, cur, sp, smem, t, acc);
+    for (int kt = 1; kt < nkt; ++kt) stream_ktile<false>(st, nq, nr, dpadh, kt, nkt, cur, sp, smem, t, acc);
     st.cur = cur;
     st.sp = sp;
     st.q = nq;
@@ -213,18 +224,22 @@ __device__ __forceinline__ void stream_tile(TileStream& st, const _Float16* nq, 
 // XCD-aware raster (workgroup b runs on XCD b % 8): every XCD owns a contiguous run of tiles and walks
 // it in bands of GQ query tiles, ref tile fastest inside... query tile fastest inside a band column, so
 // the tiles in flight on one XCD share GQ query panels and a short run of ref panels in its L2.
-__device__ __forceinline__ bool raster(int xcd, int64_t local, int tq, int64_t tr, int& tqi, int64_t& tri) {
-    const int64_t nblk = (int64_t)tq * tr;
-    const int64_t per_xcd = (nblk + 7) / 8;
-    const int64_t logical = (int64_t)xcd * per_xcd + local;
+// 32-bit arithmetic on purpose (the host guarantees tq * tr < 2^31): every wave evaluates this once per
+// tile, and 64-bit divisions cost more instructions than the whole epilogue.
+__device__ __forceinline__ bool raster(int xcd, int64_t local64, int tq, int64_t tr64, int& tqi, int64_t& tri) {
+    const unsigned local = (unsigned)local64, tr = (unsigned)tr64;
+    const unsigned nblk = (unsigned)tq * tr;
+    const unsigned per_xcd = (nblk + 7u) >> 3;
+    const unsigned logical = (unsigned)xcd * per_xcd + local;
     if (local >= per_xcd || logical >= nblk) return false;
-    constexpr int GQ = 8;
-    const int64_t band_sz = (int64_t)GQ * tr;
-    const int64_t band = logical / band_sz, rem = logical % band_sz;
-    const int q0 = (int)band * GQ;
-    const int gq = (tq - q0) < GQ ? (tq - q0) : GQ;
-    tri = rem / gq;
-    tqi = q0 + (int)(rem % gq);
+    constexpr unsigned GQ = 8;
+    const unsigned band_sz = GQ * tr;
+    const unsigned band = logical / band_sz, rem = logical - band * band_sz;
+    const unsigned q0 = band * GQ;
+    const unsigned gq = ((unsigned)tq - q0) < GQ ? ((unsigned)tq - q0) : GQ;
+    const unsigned t = gq == GQ ? rem >> 3 : rem / gq;
+    tri = (int64_t)t;
+    tqi = (int)(q0 + rem - t * gq);
     return true;
 }
 
@@ -232,8 +247,8 @@ __device__ __forceinline__ bool raster(int xcd, int64_t local, int tq, int64_t t
 // scans.  Per accumulator register one ballot; the (rare) non-empty ones are ranked with mbcnt.
 // `count` is the wave-uniform fill level of the segment.
 __device__ __forceinline__ void emit_candidates(const SimF16Args& a, bool all, float thr, int row0, int64_t col0,
-                                                const f32x16 (&acc)[4][2], int lane, int64_t seg_base,
-                                                int seg_cap, int& count) {
+                                                const f32x16 (&acc)[4][2], const float (&bm)[4][2], int lane,
+                                                int64_t seg_base, int seg_cap, int& count) {
     // C layout of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
     const int row_base = row0 + 4 * (lane >> 5);
     const int col_base = (int)col0 + (lane & 31);
@@ -241,11 +256,8 @@ __device__ __forceinline__ void emit_candidates(const SimF16Args& a, bool all, f
     for (int m = 0; m < 4; ++m)
 #pragma unroll
         for (int n = 0; n < 2; ++n) {
-            // candidates are rare: first ask per 32x32 block (16 registers), then per register
-            float bm = acc[m][n][0];
-#pragma unroll
-            for (int r = 1; r < 16; ++r) bm = fmaxf(bm, acc[m][n][r]);
-            if (!all && !__any(bm > thr)) continue;
+            // first ask per 32x32 block (its max is already known), then per accumulator register
+            if (!all && !__any(bm[m][n] > thr)) continue;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const unsigned long long hits = __ballot(all || acc[m][n][r] > thr);
@@ -316,12 +328,6 @@ __global__ __launch_bounds__(512, 1) void sim_f16_kernel(SimF16Args a) {
         for (int off = 32; off > 0; off >>= 1) nv = fmaxf(nv, __shfl_xor(nv, off));
         if (lane == 0) norm_max[wave] = nv;
         f32x16 acc[4][2];
-#pragma unroll
-        for (int m = 0; m < 4; ++m)
-#pragma unroll
-            for (int n = 0; n < 2; ++n)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.0f;
         stream_tile(st, has_next ? a.Q + (int64_t)ntq * BM * a.dpadh : st.q,
                     has_next ? a.R + ntr * BN * a.dpadh : st.r, a.dpadh, smem, t, acc);
         // (the barriers of the K loop ordered the norm_max writes)
@@ -331,16 +337,21 @@ __global__ __launch_bounds__(512, 1) void sim_f16_kernel(SimF16Args a) {
         const bool all = !(eps < INFINITY);  // also catches NaN (inf * 0)
         // rounding of the subtraction itself: < 2^-23 relative to the larger operand
         const float thr = (radius - eps) - 2.4e-7f * (fabsf(radius) + eps);
+        // candidates are rare: one max per 32x32 block first, one compare for the whole wave tile
+        float bm[4][2];
         float mx = -INFINITY;
 #pragma unroll
         for (int m = 0; m < 4; ++m)
 #pragma unroll
-            for (int n = 0; n < 2; ++n)
+            for (int n = 0; n < 2; ++n) {
+                float v = fmaxf(acc[m][n][0], acc[m][n][1]);
 #pragma unroll
-                for (int r = 0; r < 16; r += 2)
-                    mx = fmaxf(mx, fmaxf(acc[m][n][r], acc[m][n][r + 1]));
+                for (int r = 2; r < 16; r += 2) v = fmaxf(v, fmaxf(acc[m][n][r], acc[m][n][r + 1]));
+                bm[m][n] = v;
+                mx = fmaxf(mx, v);
+            }
         if (all || __any(mx > thr))
-            emit_candidates(a, all, thr, tqi * BM + wr * 128, tri * BN + wc * 64, acc, lane, seg_base, a.seg_cap,
+            emit_candidates(a, all, thr, tqi * BM + wr * 128, tri * BN + wc * 64, acc, bm, lane, seg_base, a.seg_cap,
                             count);
         if (!has_next) break;
         local += lstride;
