@@ -120,6 +120,7 @@ struct vsc_index {
     DevBuf refh, refn;
     int dpadh = 0;
     bool prefilter = false, prefilter_force = false;
+    double prefilter_density = 0.005;  // expected hit density below which a batch goes through the pre-filter
     unsigned long long stat_candidates = 0, stat_hits = 0;  // last search (vsc_index_profile_read)
     DevBuf cand[3];  // sorted hits of vsc_index_candidates
     hipStream_t stream = nullptr;
@@ -208,6 +209,8 @@ int vsc_index_create(int dim, int metric, int device, vsc_index_t** out) {
         const char* e = getenv("VSC_PREFILTER");
         idx->prefilter = metric == VSC_METRIC_INNER_PRODUCT && !(e && e[0] == '0');
         idx->prefilter_force = idx->prefilter && e && e[0] == '2';
+        const char* d = getenv("VSC_PREFILTER_DENSITY");
+        if (d && atof(d) > 0.0) idx->prefilter_density = atof(d);
     }
     idx->device = device;
     hipError_t e = hipStreamCreateWithFlags(&idx->stream, hipStreamNonBlocking);
@@ -505,7 +508,7 @@ int vsc_index_global_topk(vsc_index_t* idx, const float* q, int64_t nq, int q_me
             // exact kernel is cheaper than pre-filtering and re-scoring nearly everything
             // (exact: ~7.5 ps per pair; re-scoring: ~1 ns per candidate => break-even near 0.5 %).
             const bool f16 = idx->prefilter_force ||
-                             (idx->prefilter && i0 > 0 && (double)K < 0.005 * (double)i0 * (double)idx->ntotal);
+                             (idx->prefilter && i0 > 0 && (double)K < idx->prefilter_density * (double)i0 * (double)idx->ntotal);
             VSC_TRY(enqueue_batch(idx, qp, i0, i1, cap, f16));
             VSC_TRY(enqueue_rethreshold(ctl, idx->ws.hA[0].as<int32_t>(), idx->ws.hA[1].as<int32_t>(),
                                         idx->ws.hA[2].as<float>(), idx->ws.hB[0].as<int32_t>(),

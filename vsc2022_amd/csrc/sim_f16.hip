@@ -14,9 +14,9 @@
 //                      4x2 blocks of 32x32x16 MFMAs; operands by LDS-DMA into an XOR-swizzled image
 //                      (2 stages x 64 KiB); persistent workgroups (1 per CU) walk an XCD-aware raster.
 //                      MFMA-bound: 2*256*256*dpadh flop per tile.
-//   rescore_kernel   : one lane per candidate runs the exact ascending-k fp32 fma chain on the packed
-//                      fp32 rows; rows are brought in coalesced 256-byte pieces by LDS-DMA into a
-//                      swizzled per-wave LDS image.  HBM/L2-bound: 8*dpad bytes per candidate.
+//   rescore_kernel   : four lanes per candidate run the exact ascending-k fp32 fma chain on the packed fp32
+//                      rows, the running sum hopping between them (one 128-byte line per row and load).
+//                      HBM/L2-bound: 8*dpad bytes per candidate.
 #include "kernels.h"
 
 namespace vscmi {
@@ -26,6 +26,12 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 namespace f16 {
+
+// Ablation switches for timing studies only (results are WRONG when set): 1 = no barrier / DMA drain,
+// 2 = no LDS-DMA in the loop, 4 = no fragment reads.  scripts/ablate_f16.sh builds the variants.
+#ifndef VSC_F16_ABLATE
+#define VSC_F16_ABLATE 0
+#endif
 
 constexpr int BM = 256, BN = 256;
 constexpr int BK = 64;                       // fp16 elements per K-tile
@@ -160,12 +166,13 @@ __device__ __forceinline__ void stream_ktile(TileStream& st, const _Float16* nq,
         f16x8 nb[2];
 #pragma unroll
         for (int n = 0; n < 2; ++n)
-            nb[n] = *reinterpret_cast<const f16x8*>(stage + TILE_BYTES + (t.rdB[n] ^ ((ks + 1) << 5)));
+            nb[n] = (VSC_F16_ABLATE & 4) ? cur.b[n]
+                                         : *reinterpret_cast<const f16x8*>(stage + TILE_BYTES + (t.rdB[n] ^ ((ks + 1) << 5)));
 #pragma unroll
         for (int m = 0; m < 4; ++m) {
             acc[m][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur.a[m], cur.b[0], (FIRST && ks == 0) ? zero : acc[m][0], 0, 0, 0);
             acc[m][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur.a[m], cur.b[1], (FIRST && ks == 0) ? zero : acc[m][1], 0, 0, 0);
-            cur.a[m] = *reinterpret_cast<const f16x8*>(stage + (t.rdA[m] ^ ((ks + 1) << 5)));
+            if (!(VSC_F16_ABLATE & 4)) cur.a[m] = *reinterpret_cast<const f16x8*>(stage + (t.rdA[m] ^ ((ks + 1) << 5)));
         }
         // pin the order: left alone, the scheduler sinks every fragment read to just before its use
         // and exposes the LDS latency once per k-step
@@ -189,18 +196,21 @@ __device__ __forceinline__ void stream_ktile(TileStream& st, const _Float16* nq,
     // The next K-tile of the stream has landed once EVERY wave's own LDS-DMA pieces have: drain this
     // wave's count before the barrier (the compiler does not always do it for the builtin -- without
     // the wait a wave could read pieces another wave's DMA has not delivered yet).
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();  // ... and nobody reads this stage any more
+    if (!(VSC_F16_ABLATE & 1)) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();  // ... and nobody reads this stage any more
+    }
     f16x8 nb[2];
 #pragma unroll
-    for (int n = 0; n < 2; ++n) nb[n] = *reinterpret_cast<const f16x8*>(nstage + TILE_BYTES + t.rdB[n]);
+    for (int n = 0; n < 2; ++n)
+        nb[n] = (VSC_F16_ABLATE & 4) ? cur.b[n] : *reinterpret_cast<const f16x8*>(nstage + TILE_BYTES + t.rdB[n]);
 #pragma unroll
     for (int m = 0; m < 4; ++m) {
         acc[m][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur.a[m], cur.b[0], acc[m][0], 0, 0, 0);
-        dma16(ars, t.src_off[m], soff, wstage + t.dst_off[m]);
+        if (!(VSC_F16_ABLATE & 2)) dma16(ars, t.src_off[m], soff, wstage + t.dst_off[m]);
         acc[m][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur.a[m], cur.b[1], acc[m][1], 0, 0, 0);
-        dma16(brs, t.src_off[m], soff, wstage + TILE_BYTES + t.dst_off[m]);
-        cur.a[m] = *reinterpret_cast<const f16x8*>(nstage + t.rdA[m]);
+        if (!(VSC_F16_ABLATE & 2)) dma16(brs, t.src_off[m], soff, wstage + TILE_BYTES + t.dst_off[m]);
+        if (!(VSC_F16_ABLATE & 4)) cur.a[m] = *reinterpret_cast<const f16x8*>(nstage + t.rdA[m]);
     }
     cur.b[0] = nb[0];
     cur.b[1] = nb[1];
@@ -350,7 +360,9 @@ __global__ __launch_bounds__(512, 1) void sim_f16_kernel(SimF16Args a) {
                 bm[m][n] = v;
                 mx = fmaxf(mx, v);
             }
-        if (all || __any(mx > thr))
+        if (VSC_F16_ABLATE) {
+            count += mx == 12345.678f;  // keeps the accumulators alive; garbage results are not emitted
+        } else if (all || __any(mx > thr))
             emit_candidates(a, all, thr, tqi * BM + wr * 128, tri * BN + wc * 64, acc, bm, lane, seg_base, a.seg_cap,
                             count);
         if (!has_next) break;
@@ -387,29 +399,52 @@ int launch_sim_f16(const SimF16Args& a, hipStream_t stream) {
 
 // ------------------------------------------------------------------------------ exact stage
 //
-// One lane per candidate: acc = fmaf(q[k], r[k], acc), k ascending (the arithmetic contract of the
-// engine; packed rows hold every group of 8 k as [k0 k2 k4 k6 | k1 k3 k5 k7]).
+// acc = fmaf(q[k], r[k], acc), k ascending from +0 (the arithmetic contract of the engine; packed rows hold
+// every group of 8 k as [k0 k2 k4 k6 | k1 k3 k5 k7]).  The chain is serial, but nothing says it must stay
+// in one lane: FOUR lanes share a candidate.  In every round of 32 k, lane g of the quad loads the g-th
+// 32-byte group of both rows (so one load instruction touches one full 128-byte line per candidate and
+// row instead of four different lines), and the running sum hops from lane to lane with a quad-rotate
+// DPP move: lane 0 does k 0-7, hands over to lane 1 for k 8-15, ... and lane 3 hands back to lane 0 for the
+// next round.  Every lane executes every step (the other three results are discarded), which costs 4x
+// the fma issue slots of a chain that needs ~3 % of the VALU anyway; the kernel is bound by row traffic.
+__device__ __forceinline__ float quad_rotate(float v) {  // lane g of every quad receives lane (g - 1) & 3
+    return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x93, 0xf, 0xf, true));
+}
 
-// candidates [x0, x0 + step*k) of one list, `step` threads apart (whole waves stay together)
+// candidates of one list; thread x serves candidate x >> 2 (x0 = first thread index, `step` threads apart)
 __device__ __forceinline__ void rescore_list(const RescoreArgs& a, float radius, const int32_t* ci,
                                              const int32_t* cj, long long n, long long x0, long long step) {
-    const int lane = threadIdx.x & 63;
-    const long long n_round = (n + 63) & ~63ll;
-    for (long long x = x0; x < n_round; x += step) {
-        const bool valid = x < n;
-        const int i = valid ? ci[x] : 0, j = valid ? cj[x] : 0;
-        const f32x4* q = reinterpret_cast<const f32x4*>(a.Q + (int64_t)i * a.dpad);
-        const f32x4* r = reinterpret_cast<const f32x4*>(a.R + (int64_t)j * a.dpad);
-        float acc = 0.0f;
-        for (int g = 0; g < a.dpad / 8; ++g) {
-            const f32x4 qe = q[2 * g], qo = q[2 * g + 1], re = r[2 * g], ro = r[2 * g + 1];
+    const int lane = threadIdx.x & 63, g = lane & 3;
+    const long long n_thr = (4 * n + 63) & ~63ll;  // whole waves stay together (DPP, ballot)
+    const int rounds = a.dpad / 32;
+    for (long long x = x0; x < n_thr; x += step) {
+        const long long c = x >> 2;
+        const bool valid = c < n;
+        const int i = valid ? ci[c] : 0, j = valid ? cj[c] : 0;
+        const f32x4* q = reinterpret_cast<const f32x4*>(a.Q + (int64_t)i * a.dpad) + 2 * g;
+        const f32x4* r = reinterpret_cast<const f32x4*>(a.R + (int64_t)j * a.dpad) + 2 * g;
+        float acc = 0.0f;  // the live value sits in lane 0 of the quad at the top of every round
+        f32x4 qe = q[0], qo = q[1], re = r[0], ro = r[1];
+        for (int rd = 0; rd < rounds; ++rd) {
+            const int nx = rd + 1 < rounds ? rd + 1 : rd;  // prefetch the next round's groups
+            const f32x4 nqe = q[8 * nx], nqo = q[8 * nx + 1], nre = r[8 * nx], nro = r[8 * nx + 1];
 #pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                acc = __fmaf_rn(qe[s], re[s], acc);
-                acc = __fmaf_rn(qo[s], ro[s], acc);
+            for (int gp = 0; gp < 4; ++gp) {
+                float v = acc;
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    v = __fmaf_rn(qe[s], re[s], v);
+                    v = __fmaf_rn(qo[s], ro[s], v);
+                }
+                const float passed = quad_rotate(v);  // lane gp's (the only meaningful) v -> lane gp + 1
+                acc = (g == ((gp + 1) & 3)) ? passed : acc;
             }
+            qe = nqe;
+            qo = nqo;
+            re = nre;
+            ro = nro;
         }
-        const bool hit = valid && acc > radius;
+        const bool hit = valid && g == 0 && acc > radius;
         const unsigned long long m = __ballot(hit);
         if (!m) continue;
         unsigned long long base = 0;
