@@ -139,7 +139,10 @@ __device__ __forceinline__ void stream_begin(TileStream& st, const _Float16* qro
     stage_tiles(ars, brs, 0, smem, t);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    stage_tiles(ars, brs, 1, smem + STAGE_BYTES, t);  // dpadh >= 128: K-tile 1 always exists
+    // K-tile 1 (dpadh >= 128: it always exists): query side only, the ref side is issued by K-tile 0's
+    // first k-step like in the steady state
+#pragma unroll
+    for (int n = 0; n < 4; ++n) dma16(ars, t.src_off[n], ROWB, smem + STAGE_BYTES + t.dst_off[n]);
     st.cur = read_frags(smem, t, 0);
 }
 
@@ -148,8 +151,8 @@ __device__ __forceinline__ void stream_begin(TileStream& st, const _Float16* qro
 // body has no conditionals (the two K-tiles it then fetches past the end are never read).
 //
 // Per K-tile (4 k-steps of 8 MFMAs): the barrier sits before the LAST k-step, whose operands are already
-// in registers; after it the stage is free, and the DMA of the K-tile two ahead goes out interleaved with
-// those 8 MFMAs.  Register budget: 2 waves per SIMD => 256 VGPRs per lane, 128 of them accumulators; the A
+// in registers; after it the stage is free, and the DMA of the K-tile two ahead goes into it: the query
+// side interleaved with those 8 MFMAs, the ref side with the first 8 of the next K-tile.  Register budget: 2 waves per SIMD => 256 VGPRs per lane, 128 of them accumulators; the A
 // fragment of the NEXT k-step is read right after the two MFMAs that consumed the current one (same
 // registers), only the two B fragments are double-buffered.
 //
@@ -161,6 +164,15 @@ __device__ __forceinline__ void stream_ktile(TileStream& st, const _Float16* nq,
                                              const TileThread& t, f32x16 (&acc)[4][2]) {
     const f32x16 zero = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
     const char* stage = smem + sp * STAGE_BYTES;
+    // The 8 LDS-DMA issues a wave owes per K-tile are split so that none of them competes with more than
+    // two MFMAs (an issue occupies the wave ~60 cycles, an MFMA the matrix pipe 32): the query side of
+    // K-tile kt+2 goes out in this K-tile's last k-step (below), the ref side of K-tile kt+1 here, in the
+    // first k-step -- its stage was freed by the previous K-tile's barrier.
+    const int k1 = kt + 1;
+    const bool in_cur1 = k1 < nkt;
+    const __amdgpu_buffer_rsrc_t brs1 = tile_rsrc(in_cur1 ? st.r : nr, dpadh * 2);
+    const int soff1 = (in_cur1 ? k1 : k1 - nkt) * ROWB;
+    char* wstage1 = smem + (sp ^ 1) * STAGE_BYTES + TILE_BYTES;
 #pragma unroll
     for (int ks = 0; ks < 3; ++ks) {
         f16x8 nb[2];
@@ -173,6 +185,7 @@ __device__ __forceinline__ void stream_ktile(TileStream& st, const _Float16* nq,
             acc[m][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur.a[m], cur.b[0], (FIRST && ks == 0) ? zero : acc[m][0], 0, 0, 0);
             acc[m][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur.a[m], cur.b[1], (FIRST && ks == 0) ? zero : acc[m][1], 0, 0, 0);
             if (!(VSC_F16_ABLATE & 4)) cur.a[m] = *reinterpret_cast<const f16x8*>(stage + (t.rdA[m] ^ ((ks + 1) << 5)));
+            if (ks == 0 && !(VSC_F16_ABLATE & 2)) dma16(brs1, t.src_off[m], soff1, wstage1 + t.dst_off[m]);
         }
         // pin the order: left alone, the scheduler sinks every fragment read to just before its use
         // and exposes the LDS latency once per k-step
@@ -181,6 +194,7 @@ __device__ __forceinline__ void stream_ktile(TileStream& st, const _Float16* nq,
         for (int m = 0; m < 4; ++m) {
             __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
             __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            if (ks == 0 && !(VSC_F16_ABLATE & 2)) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
         }
         cur.b[0] = nb[0];
         cur.b[1] = nb[1];
@@ -189,7 +203,6 @@ __device__ __forceinline__ void stream_ktile(TileStream& st, const _Float16* nq,
     const int k2 = kt + 2;
     const bool in_cur = k2 < nkt;
     const __amdgpu_buffer_rsrc_t ars = tile_rsrc(in_cur ? st.q : nq, dpadh * 2);
-    const __amdgpu_buffer_rsrc_t brs = tile_rsrc(in_cur ? st.r : nr, dpadh * 2);
     const int soff = (in_cur ? k2 : k2 - nkt) * ROWB;
     const char* nstage = smem + (sp ^ 1) * STAGE_BYTES;
     char* wstage = smem + sp * STAGE_BYTES;
@@ -207,10 +220,16 @@ __device__ __forceinline__ void stream_ktile(TileStream& st, const _Float16* nq,
 #pragma unroll
     for (int m = 0; m < 4; ++m) {
         acc[m][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur.a[m], cur.b[0], acc[m][0], 0, 0, 0);
-        if (!(VSC_F16_ABLATE & 2)) dma16(ars, t.src_off[m], soff, wstage + t.dst_off[m]);
         acc[m][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur.a[m], cur.b[1], acc[m][1], 0, 0, 0);
-        if (!(VSC_F16_ABLATE & 2)) dma16(brs, t.src_off[m], soff, wstage + TILE_BYTES + t.dst_off[m]);
         if (!(VSC_F16_ABLATE & 4)) cur.a[m] = *reinterpret_cast<const f16x8*>(nstage + t.rdA[m]);
+        if (!(VSC_F16_ABLATE & 2)) dma16(ars, t.src_off[m], soff, wstage + t.dst_off[m]);
+    }
+    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        if (!(VSC_F16_ABLATE & 2)) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
     }
     cur.b[0] = nb[0];
     cur.b[1] = nb[1];
