@@ -154,6 +154,42 @@ def test_prefilter_equals_fp32_path_at_scale(gpu):
     assert a[4] > 0 and b[4] == 0  # the default route used the pre-filter, the fp32 route did not
 
 
+def run_knn(q, r, k, mode):
+    from vsc2022_amd.vsc.index import FlatIndex
+
+    with prefilter_mode(mode):
+        idx = FlatIndex(q.shape[1])
+    idx.add(r)
+    D, I = idx.search(q, k)
+    return D, I, search_stats(idx)
+
+
+@pytest.mark.parametrize("nq,nr,d,k", [(300, 5000, 128, 1), (257, 3000, 512, 20), (64, 200, 40, 64), (1000, 9000, 64, 5)])
+def test_knn_with_forced_prefilter_matches_oracle(gpu, orc, nq, nr, d, k):
+    """k-NN through subset threshold -> fp16 pre-filter -> exact stage -> per-row cut (VSC_PREFILTER=2)."""
+    rng = np.random.default_rng(nq + nr + k)
+    q, r = unit(rng, nq, d), unit(rng, nr, d)
+    r[10:40] = r[10]  # ties: equal scores must come out in ascending ref order
+    q[5] = r[10]
+    D, I, cand = run_knn(q, r, k, "2")
+    oD, oI = orc.knn(q, r, k)
+    assert np.array_equal(I, oI)
+    assert np.array_equal(bits(D), bits(oD))
+    assert cand >= nq * k  # the pre-filtered route really ran
+
+
+def test_knn_prefilter_chosen_by_size_matches_oracle(gpu, orc):
+    """Large enough (>= 4e9 pairs, >= 65536 refs) for the route to be taken without forcing it."""
+    rng = np.random.default_rng(21)
+    q, r = unit(rng, 62000, 32), unit(rng, 70000, 32)
+    D, I, cand = run_knn(q, r, 3, None)
+    oD, oI = orc.knn(q, r, 3)
+    assert np.array_equal(I, oI) and np.array_equal(bits(D), bits(oD))
+    assert cand >= 62000 * 3
+    D0, I0, cand0 = run_knn(q, r, 3, "0")
+    assert np.array_equal(I0, oI) and np.array_equal(bits(D0), bits(oD)) and cand0 == 0
+
+
 def test_parity_suites_with_forced_prefilter():
     """All search/candidate parity suites again with the pre-filter on every batch."""
     env = dict(os.environ, VSC_PREFILTER="2")

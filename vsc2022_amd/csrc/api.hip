@@ -63,9 +63,10 @@ struct Workspace {
     DevBuf parts, partj, mat, maps0, maps1;
     DevBuf qh, qn;  // fp16 image + norm bounds of the query rows (pre-filter)
     DevBuf ci, cj, segcnt;  // pre-filter candidates of one batch (per-wave segments + their fill levels)
+    DevBuf rowthr;          // per-row thresholds of the pre-filtered k-NN
     void release() {
         stage.release(); qbuf.release();
-        qh.release(); qn.release(); ci.release(); cj.release(); segcnt.release();
+        qh.release(); qn.release(); ci.release(); cj.release(); segcnt.release(); rowthr.release();
         for (auto& b : hA) b.release();
         for (auto& b : hB) b.release();
         ctl.release(); w0.release(); w1.release(); w2.release(); w3.release(); tmp.release(); cnt.release();
@@ -358,14 +359,15 @@ static int ensure_hit_buffers(vsc_index* idx, int64_t cap) {
     return VSC_OK;
 }
 
-// Append every (row, ref) of query rows [i0, i1) with score > *radius (score space: IP as is, L2
-// negated) to the hit buffer A.
-static int enqueue_batch(vsc_index* idx, const float* qpacked, int64_t i0, int64_t i1, int64_t cap,
-                         bool use_f16 = false) {
+// fp16 pre-filter + exact re-scoring of query rows [i0, i1): appends to hit buffer A every (row, ref, score)
+// with score > *radius -- or, when `row_thr` (one threshold per query row, padded like the fp16 query
+// image) is given, with score >= row_thr[row].
+static int enqueue_f16(vsc_index* idx, const float* qpacked, int64_t i0, int64_t i1, int64_t cap,
+                       const float* row_thr) {
     SelectCtl* ctl = idx->ws.ctl.as<SelectCtl>();
     const int nqb = (int)(i1 - i0);
-    if (use_f16) {
-        // 1. fp16 pre-filter: candidates = pairs whose fp16 score + error bound exceeds the radius
+    {
+        // 1. fp16 pre-filter: candidates = pairs whose fp16 score + error bound exceeds the threshold
         const double D = (double)idx->dpadh;
         SimF16Args f;
         f.Q = idx->ws.qh.as<_Float16>() + i0 * idx->dpadh;
@@ -387,6 +389,7 @@ static int enqueue_batch(vsc_index* idx, const float* qpacked, int64_t i0, int64
         f.c2 = (float)(ldexp(1.0, -25) * 1.001 * sqrt(D));
         f.c3 = (float)(D * ldexp(1.0, -50));
         f.radius = &ctl->radius;
+        f.row_thr = row_thr ? row_thr + i0 : nullptr;
         f.out_i = idx->ws.ci.as<int32_t>();
         f.out_j = idx->ws.cj.as<int32_t>();
         const int grid = sim_f16_grid(f.tq, f.tr);
@@ -421,11 +424,21 @@ static int enqueue_batch(vsc_index* idx, const float* qpacked, int64_t i0, int64
         r.counter = &ctl->n;
         r.cap = cap;
         r.overflow = &ctl->overflow;
+        r.row_thr = row_thr;
         VSC_TRY(prof_begin(idx, &stop, 2));
         VSC_TRY(launch_rescore(r, idx->stream));
         VSC_TRY(prof_end(idx, stop, 0.0, 2));
-        return VSC_OK;
     }
+    return VSC_OK;
+}
+
+// Append every (row, ref) of query rows [i0, i1) with score > *radius (score space: IP as is, L2
+// negated) to the hit buffer A.
+static int enqueue_batch(vsc_index* idx, const float* qpacked, int64_t i0, int64_t i1, int64_t cap,
+                         bool use_f16 = false) {
+    SelectCtl* ctl = idx->ws.ctl.as<SelectCtl>();
+    const int nqb = (int)(i1 - i0);
+    if (use_f16) return enqueue_f16(idx, qpacked, i0, i1, cap, nullptr);
     if (idx->metric == VSC_METRIC_INNER_PRODUCT) {
         SimThreshArgs a;
         a.Q = qpacked + i0 * idx->dpad;
@@ -672,6 +685,65 @@ int vsc_index_range_search(vsc_index_t* idx, const float* q, int64_t nq, int q_m
     return VSC_OK;
 }
 
+// exact fp32 k-NN (inner product) of the packed query rows against the first nr reference rows
+static int knn_exact_ip(vsc_index* idx, const float* qp, int64_t nq, int64_t nr, int k, float* ds, int64_t* dj) {
+    const int tq = (int)((nq + 127) / 128);
+    const int tr = (int)((nr + 127) / 128);
+    // enough workgroups to fill 256 CUs several times over, but no more runs than ref tiles
+    int nchunk = (int)std::min<int64_t>(tr, std::max<int64_t>(1, (2048 + tq - 1) / tq));
+    nchunk = std::min(nchunk, 64);
+    const int64_t nq_pad = (int64_t)tq * 128;
+    VSC_TRY(idx->ws.parts.reserve((size_t)nq_pad * nchunk * k * 4));
+    VSC_TRY(idx->ws.partj.reserve((size_t)nq_pad * nchunk * k * 4));
+    SimKnnArgs a{qp, idx->ref.as<float>(), idx->dpad, (int)nq, (int)nr, tq, tr, nchunk, k,
+                 idx->ws.parts.as<float>(), idx->ws.partj.as<int32_t>()};
+    hipEvent_t stop;
+    VSC_TRY(prof_begin(idx, &stop));
+    VSC_TRY(launch_sim_knn(a, idx->stream));
+    VSC_TRY(prof_end(idx, stop, 2.0 * (double)nq * (double)nr * (double)idx->dim));
+    KnnMergeArgs m{idx->ws.parts.as<float>(), idx->ws.partj.as<int32_t>(), (int)nq, nchunk, k, ds, dj, 0};
+    VSC_TRY(launch_knn_merge(m, idx->stream));
+    return VSC_OK;
+}
+
+// Pre-filtered exact k-NN (inner product).  1. exact k-NN against a SUBSET of the references (the first
+// 1/16): the k-th best score T_i found there is a lower bound of the row's final k-th best.  2. the fp16
+// pre-filter over ALL references passes every pair whose fp16 score + error bound reaches T_i; the exact
+// stage keeps those with exact score >= T_i -- a superset of the final top-k of every row (the subset's own
+// top-k included).  3. (row asc, score desc, ref asc) order, cut at k.  Same result as knn_exact_ip, at the
+// cost of one fp32 pass over 1/16 of the references plus one fp16 pass over all of them.
+// Returns VSC_ERR_OVERFLOW when the hit estimate was too small (the caller then runs the exact kernel).
+static int knn_prefiltered(vsc_index* idx, const float* qp, int64_t nq, int k, float* ds, int64_t* dj) {
+    const int64_t nr = idx->ntotal;
+    // Subset size: the exact pass costs ~2*dim*S / 1e14 s per row, every later hit (k * nr / S per row)
+    // ~3 ns of re-scoring and sorting: the sum is smallest near S = sqrt(300 * k * nr) for dim = 512.
+    const int64_t S = std::min<int64_t>(
+        nr, round_up64(std::max<int64_t>((int64_t)std::sqrt(300.0 * k * (double)nr), 4096), ROW_PAD));
+    if (S < k) return VSC_ERR_OVERFLOW;
+    VSC_TRY(knn_exact_ip(idx, qp, nq, S, k, ds, dj));
+    const int64_t rows_h = round_up64(nq, ROW_PAD_H) + ROW_PAD_H;
+    VSC_TRY(idx->ws.rowthr.reserve((size_t)rows_h * 4));
+    VSC_TRY(launch_knn_row_thr(ds, nq, k, idx->ws.rowthr.as<float>(), rows_h, idx->stream));
+    // expected hits: k * nr / S per row (plus the filter's inflation); generous factor, bounded by the matrix
+    int64_t cap = (int64_t)((double)nq * k * ((double)nr / (double)S) * 4.0) + (1 << 20);
+    cap = std::min<int64_t>(cap, nq * nr + 1024);
+    if (idx->hit_cap_user > 0) cap = idx->hit_cap_user;
+    VSC_TRY(ensure_hit_buffers(idx, cap));
+    VSC_TRY(init_ctl(idx, 0.0f));
+    const int64_t step = 32768;
+    for (int64_t i0 = 0; i0 < nq; i0 += step)
+        VSC_TRY(enqueue_f16(idx, qp, i0, std::min(nq, i0 + step), cap, idx->ws.rowthr.as<float>()));
+    SelectCtl h;
+    VSC_HIP(hipMemcpyAsync(&h, idx->ws.ctl.p, sizeof(h), hipMemcpyDeviceToHost, idx->stream));
+    VSC_HIP(hipStreamSynchronize(idx->stream));
+    idx->stat_candidates = h.n_cand_total;
+    if (h.overflow) return VSC_ERR_OVERFLOW;
+    VSC_TRY(knn_from_hits(idx->ws.hA[0].as<int32_t>(), idx->ws.hA[1].as<int32_t>(), idx->ws.hA[2].as<float>(),
+                          (int64_t)h.n, nq, k, idx->ws.w0, idx->ws.w1, idx->ws.w2, idx->ws.w3, idx->ws.tmp, ds, dj,
+                          idx->stream));
+    return VSC_OK;
+}
+
 int vsc_index_knn(vsc_index_t* idx, const float* q, int64_t nq, int q_mem, int k, float* out_s,
                   int64_t* out_j, int out_mem) {
     if (!idx || nq < 0 || k <= 0 || k > 64 || (nq > 0 && (!q || !out_s || !out_j))) {
@@ -685,8 +757,13 @@ int vsc_index_knn(vsc_index_t* idx, const float* q, int64_t nq, int q_mem, int k
     }
     VSC_HIP(hipSetDevice(idx->device));
     const bool ip = idx->metric == VSC_METRIC_INNER_PRODUCT;
+    const int64_t nr = idx->ntotal;
+    // The pre-filtered route pays off once the matrix is large (it adds sorts and an exact pass over 1/16 of
+    // the references); VSC_PREFILTER=2 forces it for the tests.
+    const bool pre = ip && idx->prefilter && nr >= k &&
+                     (idx->prefilter_force || ((double)nq * (double)nr >= 4e9 && nr >= 65536));
     float* qp = nullptr;
-    VSC_TRY(pack_queries(idx, q, nq, q_mem, &qp));
+    VSC_TRY(pack_queries(idx, q, nq, q_mem, &qp, pre));
     float* ds = out_s;
     int64_t* dj = out_j;
     if (out_mem == VSC_MEM_HOST) {
@@ -695,24 +772,10 @@ int vsc_index_knn(vsc_index_t* idx, const float* q, int64_t nq, int q_mem, int k
         ds = idx->ws.out[0].as<float>();
         dj = idx->ws.out[1].as<int64_t>();
     }
-    const int64_t nr = idx->ntotal;
     if (ip && nr > 0) {
-        const int tq = (int)((nq + 127) / 128);
-        const int tr = (int)((nr + 127) / 128);
-        // enough workgroups to fill 256 CUs several times over, but no more runs than ref tiles
-        int nchunk = (int)std::min<int64_t>(tr, std::max<int64_t>(1, (2048 + tq - 1) / tq));
-        nchunk = std::min(nchunk, 64);
-        const int64_t nq_pad = (int64_t)tq * 128;
-        VSC_TRY(idx->ws.parts.reserve((size_t)nq_pad * nchunk * k * 4));
-        VSC_TRY(idx->ws.partj.reserve((size_t)nq_pad * nchunk * k * 4));
-        SimKnnArgs a{qp, idx->ref.as<float>(), idx->dpad, (int)nq, (int)nr, tq, tr, nchunk, k,
-                     idx->ws.parts.as<float>(), idx->ws.partj.as<int32_t>()};
-        hipEvent_t stop;
-        VSC_TRY(prof_begin(idx, &stop));
-        VSC_TRY(launch_sim_knn(a, idx->stream));
-        VSC_TRY(prof_end(idx, stop, 2.0 * (double)nq * (double)nr * (double)idx->dim));
-        KnnMergeArgs m{idx->ws.parts.as<float>(), idx->ws.partj.as<int32_t>(), (int)nq, nchunk, k, ds, dj, 0};
-        VSC_TRY(launch_knn_merge(m, idx->stream));
+        int rc = pre ? knn_prefiltered(idx, qp, nq, k, ds, dj) : VSC_ERR_OVERFLOW;
+        if (rc == VSC_ERR_OVERFLOW) rc = knn_exact_ip(idx, qp, nq, nr, k, ds, dj);
+        VSC_TRY(rc);
     } else {
         // generic metric (or empty index): explicit score matrix, one run per row
         VSC_TRY(idx->ws.parts.reserve((size_t)nq * k * 4));

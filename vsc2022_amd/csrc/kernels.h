@@ -18,6 +18,9 @@ struct SimF16Args {
     int dpadh; int nq; int i0; int nr; int tq; int tr;
     float c1, c2, c3;                      // |fp16 score - exact score| <= c1*nq*nr + c2*(nq+nr) + c3
     const float* radius; int32_t* out_i; int32_t* out_j;
+    // k-NN mode: per-row thresholds (indexed like qn; the test becomes fp16 score + bound >= row_thr[row]);
+    // nullptr = thresholded search against *radius
+    const float* row_thr;
     // candidate list = one private segment of seg_cap entries per wave of the launch (8 per workgroup)
     // + a shared tail (atomic counter) for waves whose segment is full
     int seg_cap; int* seg_count; int64_t tail_base; long long tail_cap; unsigned long long* tail_count;
@@ -30,6 +33,7 @@ struct RescoreArgs {
     unsigned long long* n_cand_total;      // statistics
     const float* radius; int32_t* out_i; int32_t* out_j; float* out_s;
     unsigned long long* counter; long long cap; int* overflow;
+    const float* row_thr;  // k-NN mode: keep score >= row_thr[global row] (nullptr: score > *radius)
 };
 struct SimKnnArgs {
     const float* Q; const float* R; int dpad; int nq; int nr; int tq; int tr; int nchunk; int k;
@@ -68,6 +72,9 @@ int launch_rescore(const RescoreArgs&, hipStream_t);
 int launch_pack_half(const float*, int64_t, int, _Float16*, float*, int64_t, int, hipStream_t);
 int launch_sim_knn(const SimKnnArgs&, hipStream_t);
 int launch_knn_merge(const KnnMergeArgs&, hipStream_t);
+int knn_from_hits(const int32_t*, const int32_t*, const float*, int64_t, int64_t, int, DevBuf&, DevBuf&, DevBuf&,
+                  DevBuf&, DevBuf&, float*, int64_t*, hipStream_t);
+int launch_knn_row_thr(const float*, int64_t, int, float*, int64_t, hipStream_t);
 int launch_score_matrix(const ScoreMatArgs&, hipStream_t);
 int launch_matrix_thresh(const MatThreshArgs&, hipStream_t);
 int launch_matrix_knn(const MatKnnArgs&, hipStream_t);

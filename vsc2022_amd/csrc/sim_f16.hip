@@ -275,7 +275,18 @@ __device__ __forceinline__ bool raster(int xcd, int64_t local64, int tq, int64_t
 // Candidates of one wave tile -> the wave's PRIVATE segment of the candidate list: no atomics, no
 // scans.  Per accumulator register one ballot; the (rare) non-empty ones are ranked with mbcnt.
 // `count` is the wave-uniform fill level of the segment.
-__device__ __forceinline__ void emit_candidates(const SimF16Args& a, bool all, float thr, int row0, int64_t col0,
+// lower edge of the candidate test for an exact threshold t: a pair with exact score >(=) t has fp16 score
+// >= t - eps; the subtraction's own rounding (< 2^-23 relative to the larger operand) is subtracted again
+__device__ __forceinline__ float candidate_edge(float t, float eps) {
+    return (t - eps) - 2.4e-7f * (fabsf(t) + eps);
+}
+
+// ROWTHR = false: one threshold for the launch (`thr` = edge of *radius, strict test: thresholded search).
+// ROWTHR = true : one threshold per query row (`rt` = the tile's 256 row thresholds in LDS, `thrb[m]` = edge
+//                 of the smallest one of each 32-row block; non-strict test: k-NN, where ties must survive).
+template <bool ROWTHR>
+__device__ __forceinline__ void emit_candidates(const SimF16Args& a, bool all, float thr, const float (&thrb)[4],
+                                                const float* rt, float eps, int row0, int row0_tile, int64_t col0,
                                                 const f32x16 (&acc)[4][2], const float (&bm)[4][2], int lane,
                                                 int64_t seg_base, int seg_cap, int& count) {
     // C layout of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
@@ -286,10 +297,17 @@ __device__ __forceinline__ void emit_candidates(const SimF16Args& a, bool all, f
 #pragma unroll
         for (int n = 0; n < 2; ++n) {
             // first ask per 32x32 block (its max is already known), then per accumulator register
-            if (!all && !__any(bm[m][n] > thr)) continue;
+            if (!all && !__any(ROWTHR ? bm[m][n] >= thrb[m] : bm[m][n] > thr)) continue;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const unsigned long long hits = __ballot(all || acc[m][n][r] > thr);
+                bool cand;
+                if (ROWTHR) {
+                    const int rl = row0_tile + 4 * (lane >> 5) + m * 32 + (r & 3) + 8 * (r >> 2);
+                    cand = acc[m][n][r] >= candidate_edge(rt[rl], eps);
+                } else {
+                    cand = acc[m][n][r] > thr;
+                }
+                const unsigned long long hits = __ballot(all || cand);
                 if (hits == 0ull) continue;
                 const int i = row_base + m * 32 + (r & 3) + 8 * (r >> 2);
                 const int j = col_base + n * 32;
@@ -322,15 +340,17 @@ __device__ __forceinline__ void emit_candidates(const SimF16Args& a, bool all, f
 
 }  // namespace f16
 
+template <bool ROWTHR>
 __global__ __launch_bounds__(512, 1) void sim_f16_kernel(SimF16Args a) {
     using namespace f16;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     __shared__ float norm_max_buf[2][8];  // double-buffered by tile parity (no barrier between tiles)
+    __shared__ float row_thr_buf[2][ROWTHR ? 256 : 1];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave >> 2, wc = wave & 3;
     TileThread t;
     tile_thread_init(t, tid, a.dpadh * 2);
-    const float radius = *a.radius;
+    const float radius = ROWTHR ? 0.0f : *a.radius;
     const int xcd = blockIdx.x & 7;
     const int64_t lstride = gridDim.x >> 3;  // gridDim.x is a multiple of 8
     // this wave's private segment of the candidate list
@@ -356,6 +376,7 @@ __global__ __launch_bounds__(512, 1) void sim_f16_kernel(SimF16Args a) {
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) nv = fmaxf(nv, __shfl_xor(nv, off));
         if (lane == 0) norm_max[wave] = nv;
+        if (ROWTHR && tid < 256) row_thr_buf[parity][tid] = a.row_thr[(int64_t)tqi * BM + tid];
         f32x16 acc[4][2];
         stream_tile(st, has_next ? a.Q + (int64_t)ntq * BM * a.dpadh : st.q,
                     has_next ? a.R + ntr * BN * a.dpadh : st.r, a.dpadh, smem, t, acc);
@@ -364,11 +385,26 @@ __global__ __launch_bounds__(512, 1) void sim_f16_kernel(SimF16Args a) {
         const float nr = fmaxf(fmaxf(norm_max[4], norm_max[5]), fmaxf(norm_max[6], norm_max[7]));
         const float eps = (a.c1 * nq * nr + a.c2 * (nq + nr) + a.c3) * 1.001f;
         const bool all = !(eps < INFINITY);  // also catches NaN (inf * 0)
-        // rounding of the subtraction itself: < 2^-23 relative to the larger operand
-        const float thr = (radius - eps) - 2.4e-7f * (fabsf(radius) + eps);
+        const float thr = candidate_edge(radius, eps);
+        float thrb[4] = {thr, thr, thr, thr};
+        const float* rt = row_thr_buf[ROWTHR ? parity : 0];
+        if (ROWTHR) {
+            // smallest row threshold of each of the wave's four 32-row blocks
+            float v0 = rt[wr * 128 + lane], v1 = rt[wr * 128 + 64 + lane];
+#pragma unroll
+            for (int off = 16; off > 0; off >>= 1) {
+                v0 = fminf(v0, __shfl_xor(v0, off));
+                v1 = fminf(v1, __shfl_xor(v1, off));
+            }
+            thrb[0] = candidate_edge(__shfl(v0, 0), eps);
+            thrb[1] = candidate_edge(__shfl(v0, 32), eps);
+            thrb[2] = candidate_edge(__shfl(v1, 0), eps);
+            thrb[3] = candidate_edge(__shfl(v1, 32), eps);
+        }
         // candidates are rare: one max per 32x32 block first, one compare for the whole wave tile
         float bm[4][2];
         float mx = -INFINITY;
+        bool any_blk = false;
 #pragma unroll
         for (int m = 0; m < 4; ++m)
 #pragma unroll
@@ -378,12 +414,13 @@ __global__ __launch_bounds__(512, 1) void sim_f16_kernel(SimF16Args a) {
                 for (int r = 2; r < 16; r += 2) v = fmaxf(v, fmaxf(acc[m][n][r], acc[m][n][r + 1]));
                 bm[m][n] = v;
                 mx = fmaxf(mx, v);
+                if (ROWTHR) any_blk |= v >= thrb[m];
             }
         if (VSC_F16_ABLATE) {
             count += mx == 12345.678f;  // keeps the accumulators alive; garbage results are not emitted
-        } else if (all || __any(mx > thr))
-            emit_candidates(a, all, thr, tqi * BM + wr * 128, tri * BN + wc * 64, acc, bm, lane, seg_base, a.seg_cap,
-                            count);
+        } else if (all || __any(ROWTHR ? any_blk : mx > thr))
+            emit_candidates<ROWTHR>(a, all, thr, thrb, rt, eps, tqi * BM + wr * 128, wr * 128,
+                                    tri * BN + wc * 64, acc, bm, lane, seg_base, a.seg_cap, count);
         if (!has_next) break;
         local += lstride;
         tqi = ntq;
@@ -405,13 +442,22 @@ int sim_f16_grid(int tq, int tr) {
 int launch_sim_f16(const SimF16Args& a, hipStream_t stream) {
     static bool attr_done = false;
     if (!attr_done) {
-        VSC_HIP(hipFuncSetAttribute((const void*)sim_f16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+        VSC_HIP(hipFuncSetAttribute((const void*)sim_f16_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    f16::LDS_BYTES));
+        VSC_HIP(hipFuncSetAttribute((const void*)sim_f16_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                     f16::LDS_BYTES));
         attr_done = true;
     }
+    if ((int64_t)a.tq * a.tr >= 0x7fffffffLL) {
+        set_error("sim_f16: more than 2^31 output tiles in one launch");
+        return VSC_ERR_INVALID;
+    }
     const int grid = sim_f16_grid(a.tq, a.tr);
     if (grid <= 0) return VSC_OK;
-    hipLaunchKernelGGL(sim_f16_kernel, dim3((unsigned)grid), dim3(512), f16::LDS_BYTES, stream, a);
+    if (a.row_thr)
+        hipLaunchKernelGGL(sim_f16_kernel<true>, dim3((unsigned)grid), dim3(512), f16::LDS_BYTES, stream, a);
+    else
+        hipLaunchKernelGGL(sim_f16_kernel<false>, dim3((unsigned)grid), dim3(512), f16::LDS_BYTES, stream, a);
     VSC_HIP(hipGetLastError());
     return VSC_OK;
 }
@@ -463,7 +509,7 @@ __device__ __forceinline__ void rescore_list(const RescoreArgs& a, float radius,
             re = nre;
             ro = nro;
         }
-        const bool hit = valid && g == 0 && acc > radius;
+        const bool hit = valid && g == 0 && (a.row_thr ? acc >= a.row_thr[i] : acc > radius);
         const unsigned long long m = __ballot(hit);
         if (!m) continue;
         unsigned long long base = 0;
@@ -483,7 +529,7 @@ __device__ __forceinline__ void rescore_list(const RescoreArgs& a, float radius,
 }
 
 __global__ __launch_bounds__(256) void rescore_kernel(RescoreArgs a) {
-    const float radius = *a.radius;
+    const float radius = a.row_thr ? 0.0f : *a.radius;
     unsigned long long seen = 0;
     for (int seg = blockIdx.x; seg < a.n_seg; seg += gridDim.x) {
         const int n = min(a.seg_count[seg], a.seg_cap);

@@ -10,6 +10,7 @@
 //
 // HBM-bound plumbing on <= 2K hits (12-16 B each); the device-wide radix sort is rocPRIM's
 // (AMD's native primitive library) -- it is not on the critical path.
+#include <cfloat>
 #include <cstring>
 
 #include <rocprim/rocprim.hpp>
@@ -169,6 +170,87 @@ int pair_max_device(const int32_t* hi, const int32_t* hj, const float* hs, int64
     VSC_HIP(rocprim::radix_sort_pairs(tmp.p, tb, ra, rb, ka, kb, (size_t)np, 0, 32, stream));
     hipLaunchKernelGGL(pair_out_kernel, dim3(grid_for((int64_t)np)), dim3(256), 0, stream, rb, kb, hs,
                        (int64_t)np, out_q, out_r, out_s, out_first);
+    VSC_HIP(hipGetLastError());
+    return VSC_OK;
+}
+
+// ----------------------------------------------------------------------------- k-NN from a hit list
+//
+// Second half of the pre-filtered k-NN (api.hip, vsc_index_knn): the exact stage delivered, in any order,
+// every (row, ref, score) with score >= the row's threshold -- at least k per row.  Order them by
+// (row asc, score desc, ref asc) with two stable radix sorts and cut each row at k.
+
+__global__ __launch_bounds__(256) void knn_keys_kernel(const int32_t* hi, const float* hs, int64_t n,
+                                                       uint64_t* key64) {
+    const int64_t x = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (x >= n) return;
+    key64[x] = ((uint64_t)(uint32_t)hi[x] << 32) | (uint32_t)~f2key(hs[x]);  // ascending = score descending
+}
+
+__global__ __launch_bounds__(256) void knn_cut_kernel(const uint64_t* key64, const uint32_t* ref, int64_t n,
+                                                      int64_t nq, int k, float* out_s, int64_t* out_j) {
+    const int64_t x = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (x >= nq * k) return;
+    const int64_t row = x / k;
+    const int slot = (int)(x % k);
+    // first element of the row: lower bound of (row << 32)
+    const uint64_t want = (uint64_t)row << 32;
+    int64_t lo = 0, hi = n;
+    while (lo < hi) {
+        const int64_t mid = (lo + hi) >> 1;
+        if (key64[mid] < want) lo = mid + 1;
+        else hi = mid;
+    }
+    const int64_t e = lo + slot;
+    const bool have = e < n && (int64_t)(key64[e] >> 32) == row;
+    out_s[x] = have ? key2f(~(uint32_t)(key64[e] & 0xffffffffu)) : -FLT_MAX;
+    out_j[x] = have ? (int64_t)ref[e] : -1;
+}
+
+int knn_from_hits(const int32_t* hi, const int32_t* hj, const float* hs, int64_t n, int64_t nq, int k, DevBuf& w0,
+                  DevBuf& w1, DevBuf& w2, DevBuf& w3, DevBuf& tmp, float* out_s, int64_t* out_j,
+                  hipStream_t stream) {
+    const int64_t nn = n > 0 ? n : 1;
+    VSC_TRY(w0.reserve(sizeof(uint64_t) * nn));
+    VSC_TRY(w1.reserve(sizeof(uint64_t) * nn));
+    VSC_TRY(w2.reserve(sizeof(uint32_t) * nn));
+    VSC_TRY(w3.reserve(sizeof(uint32_t) * nn));
+    uint64_t* ka = w0.as<uint64_t>();
+    uint64_t* kb = w1.as<uint64_t>();
+    uint32_t* ra = w2.as<uint32_t>();
+    uint32_t* rb = w3.as<uint32_t>();
+    if (n > 0) {
+        hipLaunchKernelGGL(knn_keys_kernel, dim3(grid_for(n)), dim3(256), 0, stream, hi, hs, n, ka);
+        VSC_HIP(hipGetLastError());
+        const uint32_t* refs_in = reinterpret_cast<const uint32_t*>(hj);
+        const int end_bit = 32 + bits_for((uint64_t)(nq > 0 ? nq : 1));
+        size_t need1 = 0, need2 = 0;
+        VSC_HIP(rocprim::radix_sort_pairs(nullptr, need1, refs_in, rb, ka, kb, (size_t)n, 0, 32, stream));
+        VSC_HIP(rocprim::radix_sort_pairs(nullptr, need2, kb, ka, rb, ra, (size_t)n, 0, end_bit, stream));
+        VSC_TRY(tmp.reserve(need1 > need2 ? need1 : need2));
+        size_t tb = tmp.bytes;
+        // 1. refs ascending (payload: the row/score key) ...
+        VSC_HIP(rocprim::radix_sort_pairs(tmp.p, tb, refs_in, rb, ka, kb, (size_t)n, 0, 32, stream));
+        tb = tmp.bytes;
+        // 2. ... then, stably, row ascending / score descending
+        VSC_HIP(rocprim::radix_sort_pairs(tmp.p, tb, kb, ka, rb, ra, (size_t)n, 0, end_bit, stream));
+    }
+    hipLaunchKernelGGL(knn_cut_kernel, dim3(grid_for(nq * k)), dim3(256), 0, stream, ka, ra, n, nq, k, out_s, out_j);
+    VSC_HIP(hipGetLastError());
+    return VSC_OK;
+}
+
+// row_thr[i] = k-th best score of row i (out of a k-NN result), +inf for the padding rows
+__global__ __launch_bounds__(256) void knn_row_thr_kernel(const float* knn_s, int64_t nq, int k, float* row_thr,
+                                                          int64_t rows) {
+    const int64_t x = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (x >= rows) return;
+    row_thr[x] = x < nq ? knn_s[x * k + (k - 1)] : INFINITY;
+}
+
+int launch_knn_row_thr(const float* knn_s, int64_t nq, int k, float* row_thr, int64_t rows, hipStream_t stream) {
+    if (rows <= 0) return VSC_OK;
+    hipLaunchKernelGGL(knn_row_thr_kernel, dim3(grid_for(rows)), dim3(256), 0, stream, knn_s, nq, k, row_thr, rows);
     VSC_HIP(hipGetLastError());
     return VSC_OK;
 }
