@@ -59,7 +59,14 @@ int vsc_device_count(void);
 
 /* ---------------------------------------------------------------- flat index
  * Replaces faiss.index_factory(dim, "Flat", metric) + index.add(x) (vsc/index.py:82,94).
- * The reference set stays resident in HBM across searches; add is incremental. */
+ * The reference set stays resident in HBM across searches; add is incremental.
+ *
+ * Every score the library returns is the fp32 chain acc = fmaf(q[k], r[k], acc), k ascending.  For
+ * inner-product indexes the thresholded searches and the k-NN first evaluate the score matrix in fp16
+ * on the matrix cores and hand to that exact stage every pair whose fp16 score plus a rigorous error
+ * bound reaches the threshold; the outputs are bit-identical to the all-fp32 route.
+ * Environment, read when a handle is created: VSC_PREFILTER=0 disables the pre-filter, =2 forces it on
+ * every batch / every k-NN regardless of size (tests). */
 int vsc_index_create(int dim, int metric, int device, vsc_index_t** out);
 int vsc_index_destroy(vsc_index_t* idx);
 int vsc_index_add(vsc_index_t* idx, const float* x, int64_t n, int x_mem);

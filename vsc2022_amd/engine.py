@@ -47,6 +47,47 @@ def _dev_ptr(t: torch.Tensor) -> int:
     return t.data_ptr()
 
 
+def row_normalize_device(x: torch.Tensor) -> torch.Tensor:
+    """Rows scaled to unit L2 norm by libvscmi (zero rows stay zero), HBM in, HBM out."""
+    x = x.to(torch.float32).contiguous()
+    out = torch.empty_like(x)
+    if x.shape[0]:
+        torch.cuda.synchronize(x.device)
+        _lib.check(_lib.lib().vsc_row_normalize(_dev_ptr(x), x.shape[0], x.shape[1], _lib.MEM_DEVICE, _dev_ptr(out),
+                                                _lib.MEM_DEVICE, x.device.index))
+    return out
+
+
+def score_normalize_device(queries: torch.Tensor, refs: torch.Tensor, noise: torch.Tensor, beta: float = 1.0,
+                           l2_normalize: bool = True, replace_dim: bool = True):
+    """`score_normalize` (vsc/baseline/score_normalization.py:31-105) on frame-row tensors that stay in HBM.
+
+    Same algebra as the list-of-VideoFeature mirror in vsc/baseline/score_normalization.py: drop the
+    coordinate with the lowest variance over the noise set, row-normalise, append -beta * (best inner
+    product with the noise set) to every query row and 1 to every reference row.  The 1-NN runs through
+    `vsc_index_knn` (fp16 pre-filter + exact stage: bit-identical to the exact kernel).  The variance is
+    taken on the device in float64 (the list mirror keeps numpy's float32 `var` so that it picks the
+    reference's column even on near-ties).  Returns (queries', refs').
+    """
+    dev = queries.device
+    if replace_dim:
+        weakest = int(noise.to(torch.float64).var(dim=0, unbiased=False).argmin().item())
+        keep = [c for c in range(noise.shape[1]) if c != weakest]
+        sel = torch.tensor(keep, dtype=torch.int64, device=dev)
+        queries, refs, noise = (t.index_select(1, sel) for t in (queries, refs, noise))
+    if l2_normalize:
+        queries, refs, noise = (row_normalize_device(t) for t in (queries, refs, noise))
+    noise_index = FlatIndex(int(noise.shape[1]), _lib.METRIC_INNER_PRODUCT, dev.index)
+    torch.cuda.synchronize(dev)
+    noise_index.add(noise)
+    best, _ = noise_index.search(queries, 1)
+    del noise_index
+    penalty = torch.from_numpy(best[:, :1]).to(dev) * (-float(beta))
+    q2 = torch.cat([queries, penalty], dim=1).contiguous()
+    r2 = torch.cat([refs, torch.ones((refs.shape[0], 1), dtype=torch.float32, device=dev)], dim=1).contiguous()
+    return q2, r2
+
+
 class DeviceMatcher:
     """One GPU's share of the matching pipeline.
 
