@@ -190,12 +190,15 @@ def sharded_hits(local_search, local_matrix_size: int, k_global: int, group=None
 
     local_search(k_local) -> (i, j, s, radius): this rank's global-threshold search with budget
     k_local (hits sorted by (score desc, row asc, ref asc); radius = the search's final radius).
-    local_matrix_size = n_local_query_rows * n_ref_rows.  Starts from k_local = 2*K/world and doubles
+    local_matrix_size = n_local_query_rows * n_ref_rows.  Starts from k_local = 1.25*K/world and doubles
     the budget of any rank whose own cut is not strictly below the global cut (skewed shards), until
     the result is exact everywhere.  Returns (i, j, s) = this rank's share of the global top-K.
     """
     rank, world = _world(group)
-    k_local = max(1, min(k_global, 2 * k_global // max(world, 1)))
+    # A rank's share of the global top-K is K/world up to sampling noise when the shards are alike; the
+    # local search costs more the larger its budget (re-scoring, selection and sorting scale with it), so
+    # start 25 % above the even share and let the doubling below handle skewed shards.
+    k_local = max(1, min(k_global, (5 * k_global) // (4 * max(world, 1)) + 1))
     if k_local_start is not None:
         k_local = max(1, min(k_global, int(k_local_start)))
     while True:
