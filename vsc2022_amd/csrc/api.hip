@@ -698,9 +698,13 @@ static int knn_exact_ip(vsc_index* idx, const float* qp, int64_t nq, int64_t nr,
     }
     const int tq = (int)((nq + 127) / 128);
     const int tr = (int)((nr + 127) / 128);
-    // enough workgroups to fill 256 CUs several times over, but no more runs than ref tiles
-    int nchunk = (int)std::min<int64_t>(tr, std::max<int64_t>(1, (2048 + tq - 1) / tq));
+    // Runs per query tile.  With >= 256 query tiles one run each already fills the 256 CUs, and every
+    // extra run starts with empty top-k lists and pays the insertion storm again (k = 20, 65536 x 110 k:
+    // 113 TFLOP/s with one run per query tile, 93 with four).  With few query tiles the references are
+    // split until ~1024 workgroups exist (2000 x 1 M: 39 TFLOP/s with 64 runs, 24 with 32).
+    int nchunk = tq >= 256 ? 1 : (int)std::min<int64_t>(tr, (1024 + tq - 1) / tq);
     nchunk = std::min(nchunk, 64);
+    if (const char* e = getenv("VSC_KNN_NCHUNK")) nchunk = std::max(1, std::min(std::min(atoi(e), tr), 64));
     const int64_t nq_pad = (int64_t)tq * 128;
     VSC_TRY(idx->ws.parts.reserve((size_t)nq_pad * nchunk * k * 4));
     VSC_TRY(idx->ws.partj.reserve((size_t)nq_pad * nchunk * k * 4));
