@@ -9,6 +9,7 @@ The constants are the reference's (vsc/descriptor_eval_lib.py:23-24, vsc/baselin
 tn_max_step=5, min_length=4.
 """
 import ctypes
+import os
 from dataclasses import dataclass
 from typing import Optional
 
@@ -210,7 +211,7 @@ class DeviceMatcher:
         of n_qvid_global videos; the two global cuts are resolved with vsc2022_amd.dist.
         """
         sharded = n_qvid_global is not None and torch.distributed.is_initialized() and \
-            torch.distributed.get_world_size(group) > 1
+            (torch.distributed.get_world_size(group) > 1 or os.environ.get("VSC_FORCE_SHARDED") == "1")
         nq_glob = n_qvid_global if n_qvid_global is not None else self.n_qvid
         K = int(RETRIEVE_PER_QUERY * nq_glob)
         n_cand_cut = int(CANDIDATES_PER_QUERY * nq_glob)
