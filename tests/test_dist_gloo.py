@@ -154,3 +154,47 @@ def test_ref_sharded_knn_merge_equals_single_index(tmp_path):
     r[50:60] = r[10:20]
     D, I = orc.knn(q, r, 7)
     assert np.array_equal(got["I"], I) and np.array_equal(got["D"].view(np.uint32), D.view(np.uint32))
+
+
+def _select_worker(rank, world, port, out_path):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        sys.path[:0] = [ROOT]
+        from vsc2022_amd.dist import distributed_prefix_select
+
+        rng = np.random.default_rng(100 + rank)
+        res = []
+        for case in range(12):
+            crng = np.random.default_rng(1000 + case)  # same on every rank
+            k = int(crng.integers(1, 120))
+            n = int(rng.integers(0, 200))              # some lists are longer than k, some empty
+            x = rng.normal(size=n).astype(np.float32)
+            if case % 2 == 0:
+                x = np.round(x * 3) / 3                # heavy ties, also across ranks
+            x = np.sort(x)[::-1].copy()
+            n_take, tau = distributed_prefix_select(torch.from_numpy(x), k)
+            res.append((case, k, x, n_take, tau))
+        torch.save(res, f"{out_path}.{rank}")
+    finally:
+        dist.destroy_process_group()
+
+
+def test_prefix_select_world3_ties_and_long_lists(tmp_path):
+    """Exact global top-k prefix per rank under (score desc, rank asc, position asc), lists sorted, with
+    ties across ranks and lists longer than k (only their leading k elements can matter)."""
+    out = str(tmp_path / "sel")
+    world = 3
+    mp.spawn(_select_worker, args=(world, 29950 + os.getpid() % 1000, out), nprocs=world, join=True)
+    per_rank = [torch.load(f"{out}.{r}", weights_only=False) for r in range(world)]
+    for case in range(12):
+        k = per_rank[0][case][1]
+        lists = [per_rank[r][case][2] for r in range(world)]
+        order = sorted(((-float(v), r, p) for r in range(world) for p, v in enumerate(lists[r])))
+        top = order[:k]
+        for r in range(world):
+            want = sum(1 for _, rr, _ in top if rr == r)
+            assert per_rank[r][case][3] == want, (case, r, per_rank[r][case][3], want)
+        if len(order) > k:
+            assert all(np.float32(per_rank[r][case][4]) == np.float32(-top[-1][0]) for r in range(world))
