@@ -1,0 +1,93 @@
+#!/usr/bin/env python3
+"""Soak test: random shapes, the pre-filtered routes (forced on every batch / every k-NN) against the
+all-fp32 route on the same GPU -- global top-K, k-NN and range search must agree bit for bit.
+
+    python scripts/fuzz_prefilter.py --seconds 120 --seed 0
+"""
+import argparse
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+
+from vsc2022_amd.vsc.index import FlatIndex
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--seconds", type=float, default=120.0)
+ap.add_argument("--seed", type=int, default=0)
+ap.add_argument("--only", type=int, default=-1, help="replay the random stream, run only this case")
+args = ap.parse_args()
+rng = np.random.default_rng(args.seed)
+
+
+def make(mode, d):
+    old = os.environ.get("VSC_PREFILTER")
+    os.environ["VSC_PREFILTER"] = mode
+    try:
+        return FlatIndex(d)
+    finally:
+        if old is None:
+            os.environ.pop("VSC_PREFILTER", None)
+        else:
+            os.environ["VSC_PREFILTER"] = old
+
+
+def bits(x):
+    return np.ascontiguousarray(x, dtype=np.float32).view(np.uint32)
+
+
+t_end = time.time() + args.seconds
+n_cases = 0
+while time.time() < t_end:
+    d = int(rng.choice([3, 17, 40, 64, 100, 128, 200, 256, 384, 512, 600]))
+    nq = int(rng.integers(1, 4000))
+    nr = int(rng.integers(1, 25000))
+    style = int(rng.integers(0, 4))
+    q = rng.standard_normal((nq, d)).astype(np.float32)
+    r = rng.standard_normal((nr, d)).astype(np.float32)
+    if style != 1:  # unit rows (descriptor-like); style 1 keeps raw gaussian rows (norm ~ sqrt(d))
+        q /= np.linalg.norm(q, axis=1, keepdims=True)
+        r /= np.linalg.norm(r, axis=1, keepdims=True)
+    if style == 2 and nr > 20:  # duplicates -> exact ties
+        r[rng.integers(0, nr, nr // 5)] = r[int(rng.integers(0, nr))]
+        q[rng.integers(0, nq, max(1, nq // 7))] = r[int(rng.integers(0, nr))]
+    if style == 3:  # widely different norms
+        q *= rng.uniform(0.01, 20.0, (nq, 1)).astype(np.float32)
+        r *= rng.uniform(0.01, 20.0, (nr, 1)).astype(np.float32)
+    if os.environ.get("FUZZ_VERBOSE"):
+        print(f"case {n_cases}: d={d} nq={nq} nr={nr} style={style}", flush=True)
+    cut = int(rng.integers(0, nr + 1))
+    K = int(rng.integers(1, max(2, min(nq * nr, 200000))))
+    k = int(rng.integers(1, min(64, nr) + 1))
+    if args.only >= 0 and n_cases != args.only:
+        n_cases += 1
+        if n_cases > args.only:
+            break
+        continue
+    a, b = make("2", d), make("0", d)
+    for idx in (a, b):
+        idx.add(r[:cut])
+        idx.add(r[cut:])
+    if os.environ.get("FUZZ_VERBOSE"):
+        print(f"   cut={cut} K={K}", flush=True)
+    ra, rb = a.global_topk(q, K), b.global_topk(q, K)
+    assert len(ra[2]) == len(rb[2]) and np.array_equal(ra[0], rb[0]) and np.array_equal(ra[1], rb[1]) \
+        and np.array_equal(bits(ra[2]), bits(rb[2])) and ra[3] == rb[3], ("topk", d, nq, nr, K, style)
+    if os.environ.get("FUZZ_VERBOSE"):
+        print(f"   topk ok; k={k}", flush=True)
+    Da, Ia = a.search(q, k)
+    Db, Ib = b.search(q, k)
+    assert np.array_equal(Ia, Ib) and np.array_equal(bits(Da), bits(Db)), ("knn", d, nq, nr, k, style)
+    if os.environ.get("FUZZ_VERBOSE"):
+        print("   knn ok", flush=True)
+    if nq * nr <= 4_000_000:
+        radius = float(np.quantile(ra[2], 0.5)) if len(ra[2]) else 0.0
+        la, xa, ya = a.range_search(q, radius)
+        lb, xb, yb = b.range_search(q, radius)
+        assert np.array_equal(la, lb) and np.array_equal(ya, yb) and np.array_equal(bits(xa), bits(xb)), \
+            ("range", d, nq, nr, radius, style)
+    n_cases += 1
+print(f"fuzz ok: {n_cases} random cases (top-K, k-NN, range search) bit-identical between the pre-filtered and the "
+      f"fp32 routes")

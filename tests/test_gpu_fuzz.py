@@ -1,0 +1,19 @@
+"""Short soak run of scripts/fuzz_prefilter.py: random shapes / norms / ties, the pre-filtered routes forced on
+against the all-fp32 route on the same GPU (top-K, k-NN, range search bit-identical).  A longer run of the same
+script is what found the re-scoring kernel walking unwritten candidates after a candidate-list overflow."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", [11, 12])
+def test_fuzz_prefilter_vs_fp32_route(seed):
+    r = subprocess.run([sys.executable, "scripts/fuzz_prefilter.py", "--seconds", "15", "--seed", str(seed)], cwd=ROOT,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    assert "fuzz ok" in r.stdout

@@ -529,6 +529,10 @@ __device__ __forceinline__ void rescore_list(const RescoreArgs& a, float radius,
 }
 
 __global__ __launch_bounds__(256) void rescore_kernel(RescoreArgs a) {
+    // After an overflow the candidate list has holes (a wave whose tail reservation did not fit skipped its
+    // writes but the tail counter moved on): the host reruns the search with larger buffers, so do nothing
+    // rather than chase unwritten (row, ref) pairs through memory.
+    if (*a.overflow) return;
     const float radius = a.row_thr ? 0.0f : *a.radius;
     unsigned long long seen = 0;
     for (int seg = blockIdx.x; seg < a.n_seg; seg += gridDim.x) {
