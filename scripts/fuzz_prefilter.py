@@ -18,6 +18,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--seconds", type=float, default=120.0)
 ap.add_argument("--seed", type=int, default=0)
 ap.add_argument("--only", type=int, default=-1, help="replay the random stream, run only this case")
+ap.add_argument("--big", action="store_true", help="larger shapes, pre-filter chosen by the density / size rules")
 args = ap.parse_args()
 rng = np.random.default_rng(args.seed)
 
@@ -44,6 +45,10 @@ while time.time() < t_end:
     d = int(rng.choice([3, 17, 40, 64, 100, 128, 200, 256, 384, 512, 600]))
     nq = int(rng.integers(1, 4000))
     nr = int(rng.integers(1, 25000))
+    if args.big:
+        d = int(rng.choice([32, 64, 128, 256]))
+        nq = int(rng.integers(2000, 70000))
+        nr = int(rng.integers(20000, 150000))
     style = int(rng.integers(0, 4))
     q = rng.standard_normal((nq, d)).astype(np.float32)
     r = rng.standard_normal((nr, d)).astype(np.float32)
@@ -59,14 +64,14 @@ while time.time() < t_end:
     if os.environ.get("FUZZ_VERBOSE"):
         print(f"case {n_cases}: d={d} nq={nq} nr={nr} style={style}", flush=True)
     cut = int(rng.integers(0, nr + 1))
-    K = int(rng.integers(1, max(2, min(nq * nr, 200000))))
+    K = int(rng.integers(1, max(2, min(nq * nr, 3000000 if args.big else 200000))))
     k = int(rng.integers(1, min(64, nr) + 1))
     if args.only >= 0 and n_cases != args.only:
         n_cases += 1
         if n_cases > args.only:
             break
         continue
-    a, b = make("2", d), make("0", d)
+    a, b = make("1" if args.big else "2", d), make("0", d)
     for idx in (a, b):
         idx.add(r[:cut])
         idx.add(r[cut:])
