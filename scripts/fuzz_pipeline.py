@@ -1,0 +1,70 @@
+#!/usr/bin/env python3
+"""Soak test of the whole hot path against the CPU oracle: random small datasets (ragged videos, planted
+copies, static videos => ties) through CandidateGeneration.query and VCSLLocalizationMaxSim.localize_all;
+candidates and localised matches must equal the oracle's bit for bit (the checks of __graft_entry__.smoke()
+on a stream of random configurations).
+
+    python scripts/fuzz_pipeline.py --seconds 120 --seed 0
+"""
+import argparse
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "oracle")]
+import numpy as np
+import oracle as orc
+
+from vsc2022_amd import synth
+from vsc2022_amd.vsc.baseline.localization import VCSLLocalizationMaxSim
+from vsc2022_amd.vsc.candidates import CandidateGeneration, MaxScoreAggregation
+from vsc2022_amd.vsc.index import VideoFeature
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--seconds", type=float, default=120.0)
+ap.add_argument("--seed", type=int, default=0)
+args = ap.parse_args()
+rng = np.random.default_rng(args.seed)
+t_end = time.time() + args.seconds
+n_cases = n_matches = 0
+while time.time() < t_end:
+    dim = int(rng.choice([16, 64, 100, 256, 512]))
+    n_query, n_ref = int(rng.integers(1, 30)), int(rng.integers(1, 50))
+    qlo, rlo = int(rng.integers(1, 20)), int(rng.integers(1, 20))
+    q_frames, r_frames = (qlo, qlo + int(rng.integers(0, 60))), (rlo, rlo + int(rng.integers(0, 80)))
+    case = dict(seed=int(rng.integers(1 << 30)), n_query=n_query, n_ref=n_ref, dim=dim, q_frames=q_frames,
+                r_frames=r_frames, planted_frac=float(rng.uniform(0, 0.8)), static_frac=float(rng.uniform(0, 0.3)),
+                noise=float(rng.choice([0.0, 0.02, 0.05, 0.2])))
+    queries, refs, _ = synth.make_dataset(**case)
+    qf, rf = synth.to_video_features(queries, VideoFeature), synth.to_video_features(refs, VideoFeature)
+    K = int(rng.choice([1, 7, 100 * len(qf), 1200 * len(qf)]))
+    tn = dict(tn_max_step=int(rng.choice([5, 10])), min_length=int(rng.choice([4, 5])))
+    bias = float(rng.choice([0.0, 0.5]))
+    cands = CandidateGeneration(rf, MaxScoreAggregation()).query(qf, K)
+    Q = np.concatenate([v.feature for v in qf])
+    R = np.concatenate([v.feature for v in rf])
+    row2q = np.repeat(np.arange(len(qf), dtype=np.int32), [len(v) for v in qf])
+    row2r = np.repeat(np.arange(len(rf), dtype=np.int32), [len(v) for v in rf])
+    oi, oj, os_ = orc.global_threshold_search(Q, R, K)
+    oq, orr, ops, _ = orc.pair_max(oi, oj, os_, row2q, row2r)
+    assert len(cands) == len(oq) and np.array_equal(cands.q_ord, oq) and np.array_equal(cands.r_ord, orr) \
+        and np.array_equal(cands.scores.view(np.uint32), ops.view(np.uint32)), ("candidates", case, K)
+    top = cands[: 5 * len(qf)]
+    loc = VCSLLocalizationMaxSim(qf, rf, "TN", similarity_bias=bias, **tn)
+    matches = loc.localize_all(top)
+    exp = []
+    for c in top:
+        qv, rv = loc.queries[c.query_id], loc.refs[c.ref_id]
+        sims = orc.pair_sims(qv.feature, rv.feature, bias)
+        for (x1, y1, x2, y2) in orc.tn(sims, **tn):
+            exp.append((c.query_id, c.ref_id, np.float32(sims[x1:x2, y1:y2].max() - np.float32(bias)),
+                        qv.timestamps[x1][0], qv.timestamps[x2][1], rv.timestamps[y1][0], rv.timestamps[y2][1]))
+    assert len(matches) == len(exp), ("match count", case, K, tn, bias, len(matches), len(exp))
+    for m, e in zip(matches, exp):
+        assert (m.query_id, m.ref_id) == (e[0], e[1]), ("match ids", case)
+        assert np.float32(m.score).view(np.uint32) == e[2].view(np.uint32), ("match score", case)
+        assert (m.query_start, m.query_end, m.ref_start, m.ref_end) == e[3:], ("match box", case)
+    n_cases += 1
+    n_matches += len(matches)
+print(f"fuzz ok: {n_cases} random datasets, {n_matches} localised matches, all equal to the CPU oracle")

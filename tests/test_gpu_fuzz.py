@@ -17,3 +17,12 @@ def test_fuzz_prefilter_vs_fp32_route(seed):
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
     assert "fuzz ok" in r.stdout
+
+
+@pytest.mark.gpu
+def test_fuzz_pipeline_vs_oracle():
+    """Random small datasets through candidates + TN localisation, every output equal to the CPU oracle."""
+    r = subprocess.run([sys.executable, "scripts/fuzz_pipeline.py", "--seconds", "15", "--seed", "21"], cwd=ROOT,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    assert "fuzz ok" in r.stdout
