@@ -92,7 +92,13 @@ struct DevBuf {
             return VSC_ERR_NOMEM;
         }
         bytes = want;
-        if (poison_mode()) (void)hipMemset(p, 0xFF, bytes);
+        if (poison_mode()) {
+            // hipMemset on device memory is asynchronous and runs on the NULL stream, which the library's
+            // non-blocking streams do not wait for: without the sync the fill can land AFTER a kernel has
+            // written the buffer (seen as "missing references" after an incremental add)
+            (void)hipMemset(p, 0xFF, bytes);
+            (void)hipDeviceSynchronize();
+        }
         return VSC_OK;
     }
     void release() {
