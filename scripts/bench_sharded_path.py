@@ -14,7 +14,8 @@ from vsc2022_amd.engine import DeviceMatcher
 
 os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
 os.environ.setdefault("MASTER_PORT", "29533")
-dist.init_process_group("gloo", rank=0, world_size=1)
+torch.cuda.set_device(0)
+dist.init_process_group(os.environ.get("BACKEND", "gloo"), rank=0, world_size=1)
 dev = torch.device("cuda", 0)
 g = torch.Generator(device=dev)
 g.manual_seed(1)

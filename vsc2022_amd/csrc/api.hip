@@ -343,16 +343,19 @@ static int pack_queries(vsc_index* idx, const float* q, int64_t nq, int q_mem, f
     return VSC_OK;
 }
 
-static int ensure_hit_buffers(vsc_index* idx, int64_t cap) {
+// cap: kept hits (list A, and the compaction target B of the thresholded search); ccap: candidates of ONE
+// pre-filter launch (defaults to cap)
+static int ensure_hit_buffers(vsc_index* idx, int64_t cap, int64_t ccap = -1, bool need_b = true) {
+    if (ccap < 0) ccap = cap;
     for (int c = 0; c < 3; ++c) {
         VSC_TRY(idx->ws.hA[c].reserve((size_t)cap * 4));
-        VSC_TRY(idx->ws.hB[c].reserve((size_t)cap * 4));
+        if (need_b) VSC_TRY(idx->ws.hB[c].reserve((size_t)cap * 4));
     }
     if (idx->prefilter) {
-        // candidate list: `cap` entries in per-wave segments + a shared tail of `cap` entries, so any
-        // distribution of <= cap candidates over the waves fits
-        VSC_TRY(idx->ws.ci.reserve((size_t)cap * 8));
-        VSC_TRY(idx->ws.cj.reserve((size_t)cap * 8));
+        // candidate list: `ccap` entries in per-wave segments + a shared tail of `ccap` entries, so any
+        // distribution of <= ccap candidates over the waves fits
+        VSC_TRY(idx->ws.ci.reserve((size_t)ccap * 8));
+        VSC_TRY(idx->ws.cj.reserve((size_t)ccap * 8));
         VSC_TRY(idx->ws.segcnt.reserve(2048 * sizeof(int)));
     }
     VSC_TRY(idx->ws.ctl.reserve(sizeof(SelectCtl)));
@@ -363,7 +366,8 @@ static int ensure_hit_buffers(vsc_index* idx, int64_t cap) {
 // with score > *radius -- or, when `row_thr` (one threshold per query row, padded like the fp16 query
 // image) is given, with score >= row_thr[row].
 static int enqueue_f16(vsc_index* idx, const float* qpacked, int64_t i0, int64_t i1, int64_t cap,
-                       const float* row_thr) {
+                       const float* row_thr, int64_t ccap = -1) {
+    if (ccap < 0) ccap = cap;  // capacity of the candidate list (cap: of the hit list)
     SelectCtl* ctl = idx->ws.ctl.as<SelectCtl>();
     const int nqb = (int)(i1 - i0);
     {
@@ -393,10 +397,10 @@ static int enqueue_f16(vsc_index* idx, const float* qpacked, int64_t i0, int64_t
         f.out_i = idx->ws.ci.as<int32_t>();
         f.out_j = idx->ws.cj.as<int32_t>();
         const int grid = sim_f16_grid(f.tq, f.tr);
-        f.seg_cap = (int)std::min<int64_t>(cap / (grid * 8), 0x7fffffff);
+        f.seg_cap = (int)std::min<int64_t>(ccap / (grid * 8), 0x7fffffff);
         f.seg_count = idx->ws.segcnt.as<int>();
         f.tail_base = (int64_t)f.seg_cap * grid * 8;
-        f.tail_cap = 2 * cap - f.tail_base;
+        f.tail_cap = 2 * ccap - f.tail_base;
         f.tail_count = &ctl->n_tail;
         f.overflow = &ctl->overflow;
         hipEvent_t stop;
@@ -738,14 +742,19 @@ static int knn_prefiltered(vsc_index* idx, const float* qp, int64_t nq, int k, f
     VSC_TRY(idx->ws.rowthr.reserve((size_t)rows_h * 4));
     VSC_TRY(launch_knn_row_thr(ds, nq, k, idx->ws.rowthr.as<float>(), rows_h, idx->stream));
     // expected hits: k * nr / S per row (plus the filter's inflation); generous factor, bounded by the matrix
-    int64_t cap = (int64_t)((double)nq * k * ((double)nr / (double)S) * 4.0) + (1 << 20);
+    const int64_t step = 32768;
+    const double per_row = (double)k * ((double)nr / (double)S) * 4.0;
+    int64_t cap = (int64_t)((double)nq * per_row) + (1 << 20);
     cap = std::min<int64_t>(cap, nq * nr + 1024);
     if (idx->hit_cap_user > 0) cap = idx->hit_cap_user;
-    VSC_TRY(ensure_hit_buffers(idx, cap));
+    // the candidate list is consumed slab by slab, only the hits accumulate over the whole query set
+    const int64_t slab_rows = std::min(nq, step);
+    int64_t ccap = std::min<int64_t>((int64_t)((double)slab_rows * per_row) + (1 << 20), slab_rows * nr + 1024);
+    ccap = std::min(ccap, std::max<int64_t>(cap, 1024));
+    VSC_TRY(ensure_hit_buffers(idx, cap, ccap, false));
     VSC_TRY(init_ctl(idx, 0.0f));
-    const int64_t step = 32768;
     for (int64_t i0 = 0; i0 < nq; i0 += step)
-        VSC_TRY(enqueue_f16(idx, qp, i0, std::min(nq, i0 + step), cap, idx->ws.rowthr.as<float>()));
+        VSC_TRY(enqueue_f16(idx, qp, i0, std::min(nq, i0 + step), cap, idx->ws.rowthr.as<float>(), ccap));
     SelectCtl h;
     VSC_HIP(hipMemcpyAsync(&h, idx->ws.ctl.p, sizeof(h), hipMemcpyDeviceToHost, idx->stream));
     VSC_HIP(hipStreamSynchronize(idx->stream));
