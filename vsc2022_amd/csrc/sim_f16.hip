@@ -416,7 +416,7 @@ __global__ __launch_bounds__(512, 1) void sim_f16_kernel(SimF16Args a) {
                 mx = fmaxf(mx, v);
                 if (ROWTHR) any_blk |= v >= thrb[m];
             }
-        if (VSC_F16_ABLATE) {
+        if (VSC_F16_ABLATE & 7) {
             count += mx == 12345.678f;  // keeps the accumulators alive; garbage results are not emitted
         } else if (all || __any(ROWTHR ? any_blk : mx > thr))
             emit_candidates<ROWTHR>(a, all, thr, thrb, rt, eps, tqi * BM + wr * 128, wr * 128,
