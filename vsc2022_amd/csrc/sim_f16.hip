@@ -476,9 +476,36 @@ __device__ __forceinline__ float quad_rotate(float v) {  // lane g of every quad
     return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x93, 0xf, 0xf, true));
 }
 
+// Hits are collected per wave in LDS and appended to the global list 49-64 at a time: one atomic on the
+// (single, hot) list counter per flush instead of one per 16 candidates.
+struct WaveHits {
+    int i[64];
+    int j[64];
+    float s[64];
+};
+
+__device__ __forceinline__ void flush_hits(const RescoreArgs& a, WaveHits& buf, int& pend) {
+    if (pend == 0) return;
+    const int lane = threadIdx.x & 63;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this wave's LDS writes are visible to its other lanes
+    unsigned long long base = 0;
+    if (lane == 0) base = atomicAdd(a.counter, (unsigned long long)pend);
+    base = __shfl(base, 0);
+    if ((long long)(base + pend) > a.cap) {
+        if (lane == 0) atomicOr(a.overflow, 1);
+    } else if (lane < pend) {
+        a.out_i[base + lane] = buf.i[lane];
+        a.out_j[base + lane] = buf.j[lane];
+        a.out_s[base + lane] = buf.s[lane];
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // reads done before the buffer is refilled
+    pend = 0;
+}
+
 // candidates of one list; thread x serves candidate x >> 2 (x0 = first thread index, `step` threads apart)
 __device__ __forceinline__ void rescore_list(const RescoreArgs& a, float radius, const int32_t* ci,
-                                             const int32_t* cj, long long n, long long x0, long long step) {
+                                             const int32_t* cj, long long n, long long x0, long long step,
+                                             WaveHits& buf, int& pend) {
     const int lane = threadIdx.x & 63, g = lane & 3;
     const long long n_thr = (4 * n + 63) & ~63ll;  // whole waves stay together (DPP, ballot)
     const int rounds = a.dpad / 32;
@@ -510,21 +537,15 @@ __device__ __forceinline__ void rescore_list(const RescoreArgs& a, float radius,
             ro = nro;
         }
         const bool hit = valid && g == 0 && (a.row_thr ? acc >= a.row_thr[i] : acc > radius);
-        const unsigned long long m = __ballot(hit);
-        if (!m) continue;
-        unsigned long long base = 0;
-        if (lane == 0) base = atomicAdd(a.counter, (unsigned long long)__popcll(m));
-        base = __shfl(base, 0);
-        if ((long long)(base + __popcll(m)) > a.cap) {
-            if (lane == 0) atomicOr(a.overflow, 1);
-            continue;
-        }
+        const unsigned long long m = __ballot(hit);  // <= 16 hits per pass
         if (hit) {
-            const unsigned long long pos = base + __popcll(m & ((1ull << lane) - 1));
-            a.out_i[pos] = i;
-            a.out_j[pos] = j;
-            a.out_s[pos] = acc;
+            const int p = pend + __popcll(m & ((1ull << lane) - 1));
+            buf.i[p] = i;
+            buf.j[p] = j;
+            buf.s[p] = acc;
         }
+        pend += __popcll(m);
+        if (pend > 48) flush_hits(a, buf, pend);
     }
 }
 
@@ -533,22 +554,26 @@ __global__ __launch_bounds__(256) void rescore_kernel(RescoreArgs a) {
     // writes but the tail counter moved on): the host reruns the search with larger buffers, so do nothing
     // rather than chase unwritten (row, ref) pairs through memory.
     if (*a.overflow) return;
+    __shared__ WaveHits wave_hits[4];
+    WaveHits& buf = wave_hits[threadIdx.x >> 6];
+    int pend = 0;
     const float radius = a.row_thr ? 0.0f : *a.radius;
     unsigned long long seen = 0;
     for (int seg = blockIdx.x; seg < a.n_seg; seg += gridDim.x) {
         const int n = min(a.seg_count[seg], a.seg_cap);
         seen += (unsigned long long)n;
         rescore_list(a, radius, a.cand_i + (int64_t)seg * a.seg_cap, a.cand_j + (int64_t)seg * a.seg_cap, n,
-                     threadIdx.x, 256);
+                     threadIdx.x, 256, buf, pend);
     }
     // shared tail (normally empty)
     const unsigned long long nt_all = *a.tail_count;
     const long long nt = nt_all < (unsigned long long)a.tail_cap ? (long long)nt_all : a.tail_cap;
     if (nt > 0) {
         rescore_list(a, radius, a.cand_i + a.tail_base, a.cand_j + a.tail_base, nt,
-                     (long long)blockIdx.x * 256 + threadIdx.x, (long long)gridDim.x * 256);
+                     (long long)blockIdx.x * 256 + threadIdx.x, (long long)gridDim.x * 256, buf, pend);
         if (blockIdx.x == 0) seen += (unsigned long long)nt;
     }
+    flush_hits(a, buf, pend);
     if (threadIdx.x == 0 && seen) atomicAdd(a.n_cand_total, seen);
 }
 
