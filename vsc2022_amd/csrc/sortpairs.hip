@@ -94,16 +94,23 @@ __global__ __launch_bounds__(256) void pair_key_kernel(const int32_t* hi, const 
 __global__ __launch_bounds__(256) void pair_heads_kernel(const uint64_t* key, const uint32_t* rank,
                                                          int64_t n, uint32_t* head_rank,
                                                          uint64_t* head_key, unsigned long long* count) {
+    // one atomic per workgroup on the (single) counter, not one per wavefront
+    __shared__ unsigned int wave_cnt[4];
+    __shared__ unsigned long long block_base;
     const int64_t x = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    const int lane = threadIdx.x & 63;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const bool head = (x < n) && (x == 0 || key[x] != key[x - 1]);
     const unsigned long long m = __ballot(head);
-    if (!m) return;
-    unsigned long long base = 0;
-    if (lane == 0) base = atomicAdd(count, (unsigned long long)__popcll(m));
-    base = __shfl(base, 0);
+    if (lane == 0) wave_cnt[wave] = (unsigned int)__popcll(m);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned int tot = wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
+        block_base = tot ? atomicAdd(count, (unsigned long long)tot) : 0ull;
+    }
+    __syncthreads();
     if (head) {
-        const unsigned long long pos = base + __popcll(m & ((1ull << lane) - 1));
+        unsigned long long pos = block_base + __popcll(m & ((1ull << lane) - 1));
+        for (int w = 0; w < wave; ++w) pos += wave_cnt[w];
         head_rank[pos] = rank[x];  // stable sort => smallest rank of the run == first appearance
         head_key[pos] = key[x];
     }
