@@ -121,7 +121,7 @@ struct vsc_index {
     DevBuf refh, refn;
     int dpadh = 0;
     bool prefilter = false, prefilter_force = false;
-    double prefilter_density = 0.005;  // expected hit density below which a batch goes through the pre-filter
+    double prefilter_density = 0.02;  // expected hit density below which a batch goes through the pre-filter
     unsigned long long stat_candidates = 0, stat_hits = 0;  // last search (vsc_index_profile_read)
     DevBuf cand[3];  // sorted hits of vsc_index_candidates
     hipStream_t stream = nullptr;
@@ -523,7 +523,7 @@ int vsc_index_global_topk(vsc_index_t* idx, const float* q, int64_t nq, int q_me
             // After i0 rows the radius sits near the K-th best of i0 * ntotal scores, so about
             // K / (i0 * ntotal) of this batch's pairs are hits.  While that density is high the
             // exact kernel is cheaper than pre-filtering and re-scoring nearly everything
-            // (exact: ~7.5 ps per pair; re-scoring: ~1 ns per candidate => break-even near 0.5 %).
+            // (exact: ~7.5 ps per pair; re-scoring: ~0.5 ns per candidate; measured optimum near 2 %).
             const bool f16 = idx->prefilter_force ||
                              (idx->prefilter && i0 > 0 && (double)K < idx->prefilter_density * (double)i0 * (double)idx->ntotal);
             VSC_TRY(enqueue_batch(idx, qp, i0, i1, cap, f16));
