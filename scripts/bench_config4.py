@@ -19,7 +19,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import torch
 
-from vsc2022_amd.engine import DeviceMatcher, score_normalize_device
+from vsc2022_amd.engine import DeviceMatcher, DeviceScoreNormalizer
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--query-videos", type=int, default=40000)
@@ -57,12 +57,20 @@ q_off = np.arange(args.query_videos + 1, dtype=np.int64) * args.query_frames
 r_off = np.arange(args.ref_videos + 1, dtype=np.int64) * args.ref_frames
 
 
-def run():
+# resident state (untimed, like the reference index of bench.py): normalised noise index, normalised refs
+t0 = time.perf_counter()
+norm = DeviceScoreNormalizer(noise, beta=args.beta)
+m = DeviceMatcher(norm.refs(refs), r_off, 0)
+torch.cuda.synchronize()
+t_setup = time.perf_counter() - t0
+
+
+def step():
+    """everything that depends on the queries"""
     t0 = time.perf_counter()
-    q2, r2 = score_normalize_device(queries, refs, noise, beta=args.beta)
+    q2 = norm.queries(queries)
     torch.cuda.synchronize()
     t1 = time.perf_counter()
-    m = DeviceMatcher(r2, r_off, 0)
     m.set_queries(q2, q_off)
     torch.cuda.synchronize()
     t2 = time.perf_counter()
@@ -72,10 +80,12 @@ def run():
     return (t1 - t0, t2 - t1, t3 - t2), res
 
 
-run()  # warm-up (allocations, first-touch)
-(ts, ti, tm), res = run()
+step()  # warm-up (allocations, first-touch)
+(ts, ti, tm), res = step()
 total = ts + ti + tm
 print(f"config 4 on one GPU: {args.query_videos} query videos ({nq} frames) vs {nr} ref frames, {args.noise_rows} noise frames")
-print(f"  score normalisation {ts*1e3:.0f} ms | index + TN context upload {ti*1e3:.0f} ms | search+candidates+TN {tm*1e3:.0f} ms "
-      f"| total {total*1e3:.0f} ms = {args.query_videos/total:.0f} query-videos/s")
+print(f"  resident state (noise index, normalised reference index) built in {t_setup*1e3:.0f} ms")
+print(f"  per query set: score normalisation of the queries (row L2 + 1-NN vs the noise set) {ts*1e3:.0f} ms | "
+      f"query upload {ti*1e3:.0f} ms | search+candidates+TN {tm*1e3:.0f} ms | total {total*1e3:.0f} ms = "
+      f"{args.query_videos/total:.0f} query-videos/s")
 print(f"  hits {res.n_hits}, candidates {res.n_candidates}, pairs localised {res.n_localized}, matches {res.n_matches}")

@@ -59,34 +59,52 @@ def row_normalize_device(x: torch.Tensor) -> torch.Tensor:
     return out
 
 
-def score_normalize_device(queries: torch.Tensor, refs: torch.Tensor, noise: torch.Tensor, beta: float = 1.0,
-                           l2_normalize: bool = True, replace_dim: bool = True):
-    """`score_normalize` (vsc/baseline/score_normalization.py:31-105) on frame-row tensors that stay in HBM.
+class DeviceScoreNormalizer:
+    """`score_normalize` (vsc/baseline/score_normalization.py:31-105) on frame-row tensors that stay in HBM,
+    with the noise set resident: built once, then applied to any number of query / reference batches.
 
     Same algebra as the list-of-VideoFeature mirror in vsc/baseline/score_normalization.py: drop the
     coordinate with the lowest variance over the noise set, row-normalise, append -beta * (best inner
     product with the noise set) to every query row and 1 to every reference row.  The 1-NN runs through
     `vsc_index_knn` (fp16 pre-filter + exact stage: bit-identical to the exact kernel).  The variance is
     taken on the device in float64 (the list mirror keeps numpy's float32 `var` so that it picks the
-    reference's column even on near-ties).  Returns (queries', refs').
+    reference's column even on near-ties).
     """
-    dev = queries.device
-    if replace_dim:
-        weakest = int(noise.to(torch.float64).var(dim=0, unbiased=False).argmin().item())
-        keep = [c for c in range(noise.shape[1]) if c != weakest]
-        sel = torch.tensor(keep, dtype=torch.int64, device=dev)
-        queries, refs, noise = (t.index_select(1, sel) for t in (queries, refs, noise))
-    if l2_normalize:
-        queries, refs, noise = (row_normalize_device(t) for t in (queries, refs, noise))
-    noise_index = FlatIndex(int(noise.shape[1]), _lib.METRIC_INNER_PRODUCT, dev.index)
-    torch.cuda.synchronize(dev)
-    noise_index.add(noise)
-    best, _ = noise_index.search(queries, 1)
-    del noise_index
-    penalty = torch.from_numpy(best[:, :1]).to(dev) * (-float(beta))
-    q2 = torch.cat([queries, penalty], dim=1).contiguous()
-    r2 = torch.cat([refs, torch.ones((refs.shape[0], 1), dtype=torch.float32, device=dev)], dim=1).contiguous()
-    return q2, r2
+
+    def __init__(self, noise: torch.Tensor, beta: float = 1.0, l2_normalize: bool = True, replace_dim: bool = True):
+        self.beta, self.l2_normalize = float(beta), bool(l2_normalize)
+        dev = noise.device
+        self.sel = None
+        if replace_dim:
+            weakest = int(noise.to(torch.float64).var(dim=0, unbiased=False).argmin().item())
+            keep = [c for c in range(noise.shape[1]) if c != weakest]
+            self.sel = torch.tensor(keep, dtype=torch.int64, device=dev)
+        noise = self._prepare(noise)
+        self.noise_index = FlatIndex(int(noise.shape[1]), _lib.METRIC_INNER_PRODUCT, dev.index)
+        torch.cuda.synchronize(dev)
+        self.noise_index.add(noise)
+
+    def _prepare(self, x: torch.Tensor) -> torch.Tensor:
+        if self.sel is not None:
+            x = x.index_select(1, self.sel)
+        return row_normalize_device(x) if self.l2_normalize else x.to(torch.float32).contiguous()
+
+    def queries(self, q: torch.Tensor) -> torch.Tensor:
+        q = self._prepare(q)
+        best, _ = self.noise_index.search(q, 1)
+        penalty = torch.from_numpy(best[:, :1]).to(q.device) * (-self.beta)
+        return torch.cat([q, penalty], dim=1).contiguous()
+
+    def refs(self, r: torch.Tensor) -> torch.Tensor:
+        r = self._prepare(r)
+        return torch.cat([r, torch.ones((r.shape[0], 1), dtype=torch.float32, device=r.device)], dim=1).contiguous()
+
+
+def score_normalize_device(queries: torch.Tensor, refs: torch.Tensor, noise: torch.Tensor, beta: float = 1.0,
+                           l2_normalize: bool = True, replace_dim: bool = True):
+    """One-shot form of DeviceScoreNormalizer: returns (queries', refs')."""
+    norm = DeviceScoreNormalizer(noise, beta=beta, l2_normalize=l2_normalize, replace_dim=replace_dim)
+    return norm.queries(queries), norm.refs(refs)
 
 
 class DeviceMatcher:
