@@ -261,12 +261,15 @@ __device__ __forceinline__ bool raster(int xcd, int64_t local64, int tq, int64_t
     const unsigned per_xcd = (nblk + 7u) >> 3;
     const unsigned logical = (unsigned)xcd * per_xcd + local;
     if (local >= per_xcd || logical >= nblk) return false;
-    constexpr unsigned GQ = 8;
+#ifndef VSC_F16_GQ
+#define VSC_F16_GQ 8
+#endif
+    constexpr unsigned GQ = VSC_F16_GQ;  // band height in query tiles (swept 4..32 on one box: see DESIGN.md)
     const unsigned band_sz = GQ * tr;
     const unsigned band = logical / band_sz, rem = logical - band * band_sz;
     const unsigned q0 = band * GQ;
     const unsigned gq = ((unsigned)tq - q0) < GQ ? ((unsigned)tq - q0) : GQ;
-    const unsigned t = gq == GQ ? rem >> 3 : rem / gq;
+    const unsigned t = gq == GQ ? rem / GQ : rem / gq;
     tri = (int64_t)t;
     tqi = (int)(q0 + rem - t * gq);
     return true;
