@@ -40,9 +40,19 @@ constexpr int TILE_BYTES = BM * ROWB;        // 32 KiB per operand
 constexpr int STAGE_BYTES = 2 * TILE_BYTES;  // A + B
 constexpr int LDS_BYTES = 2 * STAGE_BYTES;   // 128 KiB
 
+// cache policy of the LDS-DMA loads (aux bits of the buffer instruction: 1 = sc0, 2 = nt, 16 = sc1), per operand.
+// Measured on one box (fp16 kernel ms per step): default 366; nt on the ref side 438, on the query side 438, on
+// both 495 (the panels ARE reused out of L2 by the workgroups of an XCD); sc0 / sc1 366.
+#ifndef VSC_F16_AUX_Q
+#define VSC_F16_AUX_Q 0
+#endif
+#ifndef VSC_F16_AUX_R
+#define VSC_F16_AUX_R 0
+#endif
+template <int AUX = 0>
 __device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rsrc, int voff, int soff, char* lds) {
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)lds, 16, voff,
-                                             soff, 0, 0);
+                                             soff, 0, AUX);
 }
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t tile_rsrc(const void* base, int row_bytes) {
     const uint64_t p = reinterpret_cast<uint64_t>(base);
@@ -114,9 +124,9 @@ __device__ __forceinline__ void mfma8(const Frags& f, f32x16 (&acc)[4][2]) {
 __device__ __forceinline__ void stage_tiles(__amdgpu_buffer_rsrc_t ars, __amdgpu_buffer_rsrc_t brs, int kt,
                                             char* stage, const TileThread& t) {
 #pragma unroll
-    for (int n = 0; n < 4; ++n) dma16(ars, t.src_off[n], kt * ROWB, stage + t.dst_off[n]);
+    for (int n = 0; n < 4; ++n) dma16<VSC_F16_AUX_Q>(ars, t.src_off[n], kt * ROWB, stage + t.dst_off[n]);
 #pragma unroll
-    for (int n = 0; n < 4; ++n) dma16(brs, t.src_off[n], kt * ROWB, stage + TILE_BYTES + t.dst_off[n]);
+    for (int n = 0; n < 4; ++n) dma16<VSC_F16_AUX_R>(brs, t.src_off[n], kt * ROWB, stage + TILE_BYTES + t.dst_off[n]);
 }
 
 // The tile stream.  A workgroup is persistent: the K-tiles of the output tiles it walks form ONE stream
@@ -142,7 +152,7 @@ __device__ __forceinline__ void stream_begin(TileStream& st, const _Float16* qro
     // K-tile 1 (dpadh >= 128: it always exists): query side only, the ref side is issued by K-tile 0's
     // first k-step like in the steady state
 #pragma unroll
-    for (int n = 0; n < 4; ++n) dma16(ars, t.src_off[n], ROWB, smem + STAGE_BYTES + t.dst_off[n]);
+    for (int n = 0; n < 4; ++n) dma16<VSC_F16_AUX_Q>(ars, t.src_off[n], ROWB, smem + STAGE_BYTES + t.dst_off[n]);
     st.cur = read_frags(smem, t, 0);
 }
 
@@ -185,7 +195,7 @@ __device__ __forceinline__ void stream_ktile(TileStream& st, const _Float16* nq,
             acc[m][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur.a[m], cur.b[0], (FIRST && ks == 0) ? zero : acc[m][0], 0, 0, 0);
             acc[m][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur.a[m], cur.b[1], (FIRST && ks == 0) ? zero : acc[m][1], 0, 0, 0);
             if (!(VSC_F16_ABLATE & 4)) cur.a[m] = *reinterpret_cast<const f16x8*>(stage + (t.rdA[m] ^ ((ks + 1) << 5)));
-            if (ks == 0 && !(VSC_F16_ABLATE & 2)) dma16(brs1, t.src_off[m], soff1, wstage1 + t.dst_off[m]);
+            if (ks == 0 && !(VSC_F16_ABLATE & 2)) dma16<VSC_F16_AUX_R>(brs1, t.src_off[m], soff1, wstage1 + t.dst_off[m]);
         }
         // pin the order: left alone, the scheduler sinks every fragment read to just before its use
         // and exposes the LDS latency once per k-step
@@ -222,7 +232,7 @@ __device__ __forceinline__ void stream_ktile(TileStream& st, const _Float16* nq,
         acc[m][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur.a[m], cur.b[0], acc[m][0], 0, 0, 0);
         acc[m][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur.a[m], cur.b[1], acc[m][1], 0, 0, 0);
         if (!(VSC_F16_ABLATE & 4)) cur.a[m] = *reinterpret_cast<const f16x8*>(nstage + t.rdA[m]);
-        if (!(VSC_F16_ABLATE & 2)) dma16(ars, t.src_off[m], soff, wstage + t.dst_off[m]);
+        if (!(VSC_F16_ABLATE & 2)) dma16<VSC_F16_AUX_Q>(ars, t.src_off[m], soff, wstage + t.dst_off[m]);
     }
     __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
 #pragma unroll
