@@ -14,12 +14,13 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _data():
+def _data(seed=5):
     sys.path.insert(0, ROOT)
     from vsc2022_amd import synth
 
-    q, r, gts = synth.make_dataset(seed=5, n_query=64, n_ref=120, dim=128, q_frames=(8, 30), r_frames=(8, 40),
-                                   planted_frac=0.3, static_frac=0.0)
+    shape = {5: (64, 120, 128), 6: (37, 80, 64), 7: (90, 60, 256)}[seed]
+    q, r, gts = synth.make_dataset(seed=seed, n_query=shape[0], n_ref=shape[1], dim=shape[2], q_frames=(8, 30),
+                                   r_frames=(8, 40), planted_frac=0.3, static_frac=0.0)
     return q, r
 
 
@@ -36,7 +37,7 @@ def _result_arrays(res):
                 bscore=res.box_score.cpu().numpy(), n=np.array([res.n_hits, res.n_candidates, res.n_localized, res.n_matches]))
 
 
-def _worker(rank, world, port, out_dir):
+def _worker(rank, world, port, out_dir, seed):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), LOCAL_RANK="0")
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
@@ -44,7 +45,7 @@ def _worker(rank, world, port, out_dir):
         from vsc2022_amd import dist as vdist
         from vsc2022_amd.engine import DeviceMatcher
 
-        q, r = _data()
+        q, r = _data(seed)
         rf, roff = _pack(r)
         lo, hi = vdist.shard_ranges(len(q), world)[rank]
         qf, qoff = _pack(q[lo:hi])
@@ -57,10 +58,11 @@ def _worker(rank, world, port, out_dir):
         dist.destroy_process_group()
 
 
-def test_sharded_engine_equals_single_process(gpu, tmp_path):
+@pytest.mark.parametrize("seed,world", [(5, 2), (6, 3), (7, 2)])
+def test_sharded_engine_equals_single_process(gpu, tmp_path, seed, world):
     from vsc2022_amd.engine import DeviceMatcher
 
-    q, r = _data()
+    q, r = _data(seed)
     rf, roff = _pack(r)
     qf, qoff = _pack(q)
     m = DeviceMatcher(rf, roff, 0)
@@ -69,8 +71,8 @@ def test_sharded_engine_equals_single_process(gpu, tmp_path):
     del m
     torch.cuda.empty_cache()
     port = 29650 + os.getpid() % 500
-    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
-    parts = [np.load(tmp_path / f"rank{k}.npz") for k in range(2)]
+    mp.spawn(_worker, args=(world, port, str(tmp_path), seed), nprocs=world, join=True)
+    parts = [np.load(tmp_path / f"rank{k}.npz") for k in range(world)]
     for p in parts:  # every rank holds the same global candidate table = the single-process one
         assert np.array_equal(p["cq"], single["cq"]) and np.array_equal(p["cr"], single["cr"])
         assert np.array_equal(p["cs"].view(np.uint32), single["cs"].view(np.uint32))
