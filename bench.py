@@ -237,6 +237,10 @@ def main():
                 "peak": peak,
                 "unit": "TFLOP/s",
                 "frac": achieved / peak,
+                # what the matrix pipes sustain on this part with everything but the MFMAs compiled out of the
+                # same kernel (the clock drops under matrix load): profiles/r01_ablation_sim_f16.md
+                "peak_sustained_measured": 1625.0 if use_f16 else 155.0,
+                "frac_of_sustained": achieved / (1625.0 if use_f16 else 155.0),
                 "traffic": traffic,
                 "traffic_unit": "bytes/launch (PMC FETCH_SIZE x2 + WRITE_SIZE, profiles/r01_pmc_prefilter.md)",
                 "launches": k_launches,
