@@ -66,7 +66,10 @@ int vsc_device_count(void);
  * on the matrix cores and hand to that exact stage every pair whose fp16 score plus a rigorous error
  * bound reaches the threshold; the outputs are bit-identical to the all-fp32 route.
  * Environment, read when a handle is created: VSC_PREFILTER=0 disables the pre-filter, =2 forces it on
- * every batch / every k-NN regardless of size (tests). */
+ * every batch / every k-NN regardless of size (tests); VSC_PREFILTER_DENSITY=<fraction> moves the hit
+ * density below which a batch of the thresholded search is pre-filtered (default 0.02).  Tuning / debug
+ * aids read per call: VSC_KNN_NCHUNK (runs per query tile of the exact k-NN), VSC_SIM_GRID (persistent grid
+ * of the exact similarity kernel), VSC_POISON_ALLOC=1 (fresh device buffers filled with 0xFF). */
 int vsc_index_create(int dim, int metric, int device, vsc_index_t** out);
 int vsc_index_destroy(vsc_index_t* idx);
 int vsc_index_add(vsc_index_t* idx, const float* x, int64_t n, int x_mem);
