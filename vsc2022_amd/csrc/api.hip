@@ -64,9 +64,10 @@ struct Workspace {
     DevBuf qh, qn;  // fp16 image + norm bounds of the query rows (pre-filter)
     DevBuf ci, cj, segcnt;  // pre-filter candidates of one batch (per-wave segments + their fill levels)
     DevBuf rowthr;          // per-row thresholds of the pre-filtered k-NN
+    DevBuf slices;          // per-panel slice counters of the panel-stationary pre-filter
     void release() {
         stage.release(); qbuf.release();
-        qh.release(); qn.release(); ci.release(); cj.release(); segcnt.release(); rowthr.release();
+        qh.release(); qn.release(); ci.release(); cj.release(); segcnt.release(); rowthr.release(); slices.release();
         for (auto& b : hA) b.release();
         for (auto& b : hB) b.release();
         ctl.release(); w0.release(); w1.release(); w2.release(); w3.release(); tmp.release(); cnt.release();
@@ -79,17 +80,26 @@ struct Workspace {
 // written, rows >= n zero).  Host sources are staged in chunks.
 // Optional second image for the fp16 pre-filter: rows_out_h rows of dpadh halves + one norm per row.
 struct HalfImage {
-    _Float16* rows = nullptr;
-    float* norms = nullptr;
+    _Float16* rows = nullptr;  // natural layout: first row to write; fragment-major: base of the WHOLE image
+    float* norms = nullptr;    // first norm to write
     int64_t rows_out = 0;
     int dpadh = 0;
+    bool frag = false;         // fragment-major reference image of the panel-stationary pre-filter (sim_f16p.hip)
+    int64_t row0 = 0;          // fragment-major: absolute index of the first row written
 };
+
+static int pack_half_any(const float* x, int64_t n, int dim, const HalfImage& h, int64_t r0, int64_t rows_out,
+                         hipStream_t stream) {
+    if (h.frag)
+        return launch_pack_half_frag(x, n, dim, h.rows, h.norms + r0, h.row0 + r0, rows_out, h.dpadh, stream);
+    return launch_pack_half(x, n, dim, h.rows + r0 * h.dpadh, h.norms + r0, rows_out, h.dpadh, stream);
+}
 
 static int pack_into(const float* x, int64_t n, int dim, int mem, float* dst, int64_t rows_out, int dpad,
                      Workspace& ws, hipStream_t stream, const HalfImage& h = HalfImage()) {
     if (mem == VSC_MEM_DEVICE || n == 0) {
         VSC_TRY(launch_pack_rows(x, n, dim, dst, rows_out, dpad, stream));
-        if (h.rows) VSC_TRY(launch_pack_half(x, n, dim, h.rows, h.norms, h.rows_out, h.dpadh, stream));
+        if (h.rows) VSC_TRY(pack_half_any(x, n, dim, h, 0, h.rows_out, stream));
         return VSC_OK;
     }
     const int64_t chunk_rows = std::max<int64_t>(1, (int64_t)(256ll << 20) / ((int64_t)dim * 4));
@@ -100,9 +110,7 @@ static int pack_into(const float* x, int64_t n, int dim, int mem, float* dst, in
         const bool last = (r0 + rows == n);
         const int64_t out_rows = last ? rows_out - r0 : rows;
         VSC_TRY(launch_pack_rows(ws.stage.as<float>(), rows, dim, dst + r0 * dpad, out_rows, dpad, stream));
-        if (h.rows)
-            VSC_TRY(launch_pack_half(ws.stage.as<float>(), rows, dim, h.rows + r0 * h.dpadh, h.norms + r0,
-                                     last ? h.rows_out - r0 : rows, h.dpadh, stream));
+        if (h.rows) VSC_TRY(pack_half_any(ws.stage.as<float>(), rows, dim, h, r0, last ? h.rows_out - r0 : rows, stream));
         VSC_HIP(hipStreamSynchronize(stream));  // staging buffer is reused
     }
     return VSC_OK;
@@ -120,6 +128,7 @@ struct vsc_index {
     // thresholded inner-product searches (sim_f16.hip).  Not kept for L2 indexes.
     DevBuf refh, refn;
     int dpadh = 0;
+    bool frag = false;  // refh is fragment-major (dpadh <= 512: panel-stationary pre-filter), else natural
     bool prefilter = false, prefilter_force = false;
     double prefilter_density = 0.02;  // expected hit density below which a batch goes through the pre-filter
     unsigned long long stat_candidates = 0, stat_hits = 0;  // last search (vsc_index_profile_read)
@@ -203,6 +212,9 @@ int vsc_index_create(int dim, int metric, int device, vsc_index_t** out) {
     idx->dim = dim;
     idx->dpad = round_up(dim, K_PAD);
     idx->dpadh = round_up(dim, 128);
+    idx->frag = idx->dpadh <= F16P_MAX_DPADH;  // VSC_F16_KERNEL=ring keeps the 256x256 LDS-ring kernel (A/B runs)
+    if (const char* e = getenv("VSC_F16_KERNEL"))
+        if (e[0] == 'r') idx->frag = false;
     idx->metric = metric;
     {
         // VSC_PREFILTER=0 keeps every search on the all-fp32 kernel (A/B and debugging);
@@ -279,11 +291,11 @@ int vsc_index_add(vsc_index_t* idx, const float* x, int64_t n, int x_mem) {
         return VSC_ERR_INVALID;
     }
     VSC_HIP(hipSetDevice(idx->device));
-    const int64_t need_rows = round_up64(idx->ntotal + n, ROW_PAD_H);
+    const int64_t need_rows = round_up64(idx->ntotal + n, ROW_PAD_REF);
     if (need_rows > idx->cap_rows) {
         // grow geometrically; keep the old rows
         int64_t cap = std::max<int64_t>(need_rows, idx->cap_rows + idx->cap_rows / 2);
-        cap = round_up64(cap, ROW_PAD_H);
+        cap = round_up64(cap, ROW_PAD_REF);
         DevBuf nb, nh, nn;
         VSC_TRY(nb.reserve((size_t)cap * idx->dpad * 4));
         if (idx->prefilter) {
@@ -294,7 +306,8 @@ int vsc_index_add(vsc_index_t* idx, const float* x, int64_t n, int x_mem) {
             VSC_HIP(hipMemcpyAsync(nb.p, idx->ref.p, (size_t)idx->ntotal * idx->dpad * 4,
                                    hipMemcpyDeviceToDevice, idx->stream));
             if (idx->prefilter) {
-                VSC_HIP(hipMemcpyAsync(nh.p, idx->refh.p, (size_t)idx->ntotal * idx->dpadh * 2,
+                // (fragment-major: whole 64-row tiles; the padding rows of the last one are rewritten below)
+                VSC_HIP(hipMemcpyAsync(nh.p, idx->refh.p, (size_t)round_up64(idx->ntotal, 64) * idx->dpadh * 2,
                                        hipMemcpyDeviceToDevice, idx->stream));
                 VSC_HIP(hipMemcpyAsync(nn.p, idx->refn.p, (size_t)idx->ntotal * 4, hipMemcpyDeviceToDevice,
                                        idx->stream));
@@ -312,7 +325,9 @@ int vsc_index_add(vsc_index_t* idx, const float* x, int64_t n, int x_mem) {
     float* dst = idx->ref.as<float>() + idx->ntotal * idx->dpad;
     HalfImage h;
     if (idx->prefilter) {
-        h.rows = idx->refh.as<_Float16>() + idx->ntotal * idx->dpadh;
+        h.frag = idx->frag;
+        h.row0 = idx->ntotal;
+        h.rows = idx->frag ? idx->refh.as<_Float16>() : idx->refh.as<_Float16>() + idx->ntotal * idx->dpadh;
         h.norms = idx->refn.as<float>() + idx->ntotal;
         h.rows_out = need_rows - idx->ntotal;
         h.dpadh = idx->dpadh;
@@ -373,53 +388,95 @@ static int enqueue_f16(vsc_index* idx, const float* qpacked, int64_t i0, int64_t
     {
         // 1. fp16 pre-filter: candidates = pairs whose fp16 score + error bound exceeds the threshold
         const double D = (double)idx->dpadh;
-        SimF16Args f;
-        f.Q = idx->ws.qh.as<_Float16>() + i0 * idx->dpadh;
-        f.R = idx->refh.as<_Float16>();
-        f.qn = idx->ws.qn.as<float>() + i0;
-        f.rn = idx->refn.as<float>();
-        f.dpadh = idx->dpadh;
-        f.nq = nqb;
-        f.i0 = (int)i0;
-        f.nr = (int)idx->ntotal;
-        f.tq = (nqb + 255) / 256;
-        f.tr = (int)((idx->ntotal + 255) / 256);
         // |fp16 score - exact score| <= c1 |q||r| + c2 (|q| + |r|) + c3   (|x| = L2 norm):
         //   rounding to fp16: |x - h(x)| <= 2^-11 |x| + 2^-25 per element (normal / subnormal range)
         //     => sum |q r - h(q) h(r)| <= (2^-10 + 2^-22) |q||r| + 2^-25 * 1.001 * sqrt(D) (|q|+|r|) + D 2^-50
         //   accumulation: the exact fp32 fma chain (D roundings) and the MFMA's fp32 accumulation
         //     (D/16 instructions of 16 products + addend) each stay within 2^-23 |q||r| per operation
-        f.c1 = (float)(ldexp(1.0, -10) + ldexp(1.0, -22) + (2.0 * D + D / 16.0 + 16.0) * ldexp(1.0, -23));
-        f.c2 = (float)(ldexp(1.0, -25) * 1.001 * sqrt(D));
-        f.c3 = (float)(D * ldexp(1.0, -50));
-        f.radius = &ctl->radius;
-        f.row_thr = row_thr ? row_thr + i0 : nullptr;
-        f.out_i = idx->ws.ci.as<int32_t>();
-        f.out_j = idx->ws.cj.as<int32_t>();
-        const int grid = sim_f16_grid(f.tq, f.tr);
-        f.seg_cap = (int)std::min<int64_t>(ccap / (grid * 8), 0x7fffffff);
-        f.seg_count = idx->ws.segcnt.as<int>();
-        f.tail_base = (int64_t)f.seg_cap * grid * 8;
-        f.tail_cap = 2 * ccap - f.tail_base;
-        f.tail_count = &ctl->n_tail;
-        f.overflow = &ctl->overflow;
+        const float c1 = (float)(ldexp(1.0, -10) + ldexp(1.0, -22) + (2.0 * D + D / 16.0 + 16.0) * ldexp(1.0, -23));
+        const float c2 = (float)(ldexp(1.0, -25) * 1.001 * sqrt(D));
+        const float c3 = (float)(D * ldexp(1.0, -50));
+        int32_t* const cand_i = idx->ws.ci.as<int32_t>();
+        int32_t* const cand_j = idx->ws.cj.as<int32_t>();
+        int grid = 0, seg_cap = 0;
+        int64_t tail_base = 0;
+        long long tail_cap = 0;
         hipEvent_t stop;
-        VSC_TRY(prof_begin(idx, &stop, 1));
-        VSC_TRY(launch_sim_f16(f, idx->stream));
+        if (idx->frag) {
+            // panel-stationary kernel (sim_f16p.hip): LDS-resident query panels x the fragment-major reference image
+            SimF16PArgs f;
+            sim_f16p_plan(nqb, idx->ntotal, &f.npanel, &f.nsteps, &f.slice, &grid);
+            VSC_TRY(idx->ws.slices.reserve((size_t)f.npanel * sizeof(int)));
+            f.Q = idx->ws.qh.as<_Float16>() + i0 * idx->dpadh;
+            f.Rf = idx->refh.p;
+            f.qn = idx->ws.qn.as<float>() + i0;
+            f.rn = idx->refn.as<float>();
+            f.dpadh = idx->dpadh;
+            f.nq = nqb;
+            f.i0 = (int)i0;
+            f.nr = (int)idx->ntotal;
+            f.next_slice = idx->ws.slices.as<int>();
+            f.c1 = c1; f.c2 = c2; f.c3 = c3;
+            f.radius = &ctl->radius;
+            f.row_thr = row_thr ? row_thr + i0 : nullptr;
+            f.out_i = cand_i;
+            f.out_j = cand_j;
+            seg_cap = (int)std::min<int64_t>(ccap / (grid * 8), 0x7fffffff);
+            tail_base = (int64_t)seg_cap * grid * 8;
+            tail_cap = 2 * ccap - tail_base;
+            f.seg_cap = seg_cap;
+            f.seg_count = idx->ws.segcnt.as<int>();
+            f.tail_base = tail_base;
+            f.tail_cap = tail_cap;
+            f.tail_count = &ctl->n_tail;
+            f.overflow = &ctl->overflow;
+            VSC_TRY(prof_begin(idx, &stop, 1));
+            VSC_TRY(launch_sim_f16p(f, grid, idx->stream));
+        } else {
+            // dims > 512: 256x256 LDS-ring kernel (sim_f16.hip) on the natural image
+            SimF16Args f;
+            f.Q = idx->ws.qh.as<_Float16>() + i0 * idx->dpadh;
+            f.R = idx->refh.as<_Float16>();
+            f.qn = idx->ws.qn.as<float>() + i0;
+            f.rn = idx->refn.as<float>();
+            f.dpadh = idx->dpadh;
+            f.nq = nqb;
+            f.i0 = (int)i0;
+            f.nr = (int)idx->ntotal;
+            f.tq = (nqb + 255) / 256;
+            f.tr = (int)((idx->ntotal + 255) / 256);
+            f.c1 = c1; f.c2 = c2; f.c3 = c3;
+            f.radius = &ctl->radius;
+            f.row_thr = row_thr ? row_thr + i0 : nullptr;
+            f.out_i = cand_i;
+            f.out_j = cand_j;
+            grid = sim_f16_grid(f.tq, f.tr);
+            seg_cap = (int)std::min<int64_t>(ccap / (grid * 8), 0x7fffffff);
+            tail_base = (int64_t)seg_cap * grid * 8;
+            tail_cap = 2 * ccap - tail_base;
+            f.seg_cap = seg_cap;
+            f.seg_count = idx->ws.segcnt.as<int>();
+            f.tail_base = tail_base;
+            f.tail_cap = tail_cap;
+            f.tail_count = &ctl->n_tail;
+            f.overflow = &ctl->overflow;
+            VSC_TRY(prof_begin(idx, &stop, 1));
+            VSC_TRY(launch_sim_f16(f, idx->stream));
+        }
         VSC_TRY(prof_end(idx, stop, 2.0 * (double)nqb * (double)idx->ntotal * (double)idx->dim, 1));
         // 2. exact scores of the candidates; those above the radius join the kept hits
         RescoreArgs r;
         r.Q = qpacked;
         r.R = idx->ref.as<float>();
         r.dpad = idx->dpad;
-        r.cand_i = f.out_i;
-        r.cand_j = f.out_j;
+        r.cand_i = cand_i;
+        r.cand_j = cand_j;
         r.n_seg = grid * 8;
-        r.seg_cap = f.seg_cap;
-        r.seg_count = f.seg_count;
-        r.tail_base = f.tail_base;
-        r.tail_cap = f.tail_cap;
-        r.tail_count = f.tail_count;
+        r.seg_cap = seg_cap;
+        r.seg_count = idx->ws.segcnt.as<int>();
+        r.tail_base = tail_base;
+        r.tail_cap = tail_cap;
+        r.tail_count = &ctl->n_tail;
         r.n_cand_total = &ctl->n_cand_total;
         r.radius = &ctl->radius;
         r.out_i = idx->ws.hA[0].as<int32_t>();

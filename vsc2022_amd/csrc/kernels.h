@@ -26,6 +26,23 @@ struct SimF16Args {
     int seg_cap; int* seg_count; int64_t tail_base; long long tail_cap; unsigned long long* tail_count;
     int* overflow;
 };
+// panel-stationary fp16 pre-filter (sim_f16p.hip; dpadh <= 512): the query side is the natural fp16 image, the
+// reference side the FRAGMENT-MAJOR image written by launch_pack_half_frag (layout.hip)
+constexpr int F16P_PANEL_ROWS = 128;  // query rows per LDS-resident panel
+constexpr int F16P_COL_STEP = 512;    // reference columns per workgroup step (8 waves x 64); row padding of the image
+constexpr int F16P_MAX_DPADH = 512;   // the panel must fit the LDS: 128 rows x dpadh x 2 B <= 128 KiB
+struct SimF16PArgs {
+    const _Float16* Q; const void* Rf;
+    const float* qn; const float* rn;      // per-row upper bounds of the L2 norm (+inf: row not representable)
+    int dpadh; int nq; int i0; int nr;
+    int npanel; int nsteps; int slice;     // work split (sim_f16p_plan); items = (panel, slice of col-steps)
+    int* next_slice;                       // [npanel] slices handed out so far (zeroed by the launcher)
+    float c1, c2, c3;
+    const float* radius; const float* row_thr;  // as in SimF16Args
+    int32_t* out_i; int32_t* out_j;
+    int seg_cap; int* seg_count; int64_t tail_base; long long tail_cap; unsigned long long* tail_count;
+    int* overflow;
+};
 struct RescoreArgs {
     const float* Q; const float* R; int dpad;  // packed fp32 images (exact arithmetic contract)
     const int32_t* cand_i; const int32_t* cand_j; int n_seg; int seg_cap; const int* seg_count;
@@ -69,6 +86,9 @@ int launch_sim_thresh(const SimThreshArgs&, hipStream_t);
 int launch_sim_f16(const SimF16Args&, hipStream_t);
 int sim_f16_grid(int tq, int tr);
 int launch_rescore(const RescoreArgs&, hipStream_t);
+void sim_f16p_plan(int64_t nq, int64_t nr, int* npanel, int* nsteps, int* slice, int* grid);
+int launch_sim_f16p(const SimF16PArgs&, int grid, hipStream_t);
+int launch_pack_half_frag(const float*, int64_t, int, _Float16*, float*, int64_t, int64_t, int, hipStream_t);
 int launch_pack_half(const float*, int64_t, int, _Float16*, float*, int64_t, int, hipStream_t);
 int launch_sim_knn(const SimKnnArgs&, hipStream_t);
 int launch_knn_merge(const KnnMergeArgs&, hipStream_t);

@@ -80,6 +80,55 @@ int launch_pack_half(const float* src, int64_t n, int dim, _Float16* dst, float*
     return VSC_OK;
 }
 
+// The same for the REFERENCE side of the panel-stationary pre-filter (sim_f16p.hip): fragment-major image.
+// Rows are grouped in wave tiles of 64 (two 32-row MFMA blocks n = 0, 1); the 16-byte piece holding k =
+// 16 ks + 8 h .. + 7 of row j sits at piece index
+//     ((j / 64) * (dpadh / 16) + ks) * 128 + ((j / 32) & 1) * 64 + h * 32 + (j % 32)
+// i.e. the B operand of one v_mfma_f32_32x32x16_f16 (lane l: row l & 31, k half l >> 5) is 1 KiB of
+// consecutive memory.  `row0` = absolute index of the first row written (incremental adds append to a
+// partly filled tile); rows [row0 + n, row0 + rows_out) are zero filled.  One wave per row, one piece per lane.
+__global__ __launch_bounds__(256) void pack_half_frag_kernel(const float* __restrict__ src, int64_t n, int dim,
+                                                             _Float16* __restrict__ image, float* __restrict__ norms,
+                                                             int64_t row0, int64_t rows_out, int dpadh) {
+    typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+    const int lane = threadIdx.x & 63;
+    const int64_t rel = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (rel >= rows_out) return;
+    const int64_t row = row0 + rel;
+    const int nks = dpadh / 16;
+    const float* r = src + rel * dim;
+    float ss = 0.0f;
+    bool bad = false;
+    for (int c = lane; c < dpadh / 8; c += 64) {
+        f16x8 h;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int k = c * 8 + e;
+            const float x = (rel < n && k < dim) ? r[k] : 0.0f;
+            bad |= !(fabsf(x) <= 65504.0f);
+            ss = __fmaf_rn(x, x, ss);
+            h[e] = (_Float16)x;  // round to nearest even
+        }
+        const int ks = c >> 1, hh = c & 1;
+        const int64_t piece = ((row >> 6) * nks + ks) * 128 + ((row >> 5) & 1) * 64 + hh * 32 + (row & 31);
+        reinterpret_cast<f16x8*>(image)[piece] = h;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) ss += __shfl_xor(ss, off);
+    const bool any_bad = __any(bad);
+    if (lane == 0) norms[rel] = (any_bad || dim > 8192) ? INFINITY : sqrtf(ss) * 1.0005f;
+}
+
+// image: base of the whole fragment-major image; norms: first norm to write (row0's)
+int launch_pack_half_frag(const float* src, int64_t n, int dim, _Float16* image, float* norms, int64_t row0,
+                          int64_t rows_out, int dpadh, hipStream_t stream) {
+    if (rows_out <= 0) return VSC_OK;
+    hipLaunchKernelGGL(pack_half_frag_kernel, dim3((unsigned)((rows_out + 3) / 4)), dim3(256), 0, stream, src, n, dim,
+                       image, norms, row0, rows_out, dpadh);
+    VSC_HIP(hipGetLastError());
+    return VSC_OK;
+}
+
 // One wave per row.  The squared norm is the ascending-k fp32 fma chain (the oracle's order), so a
 // single lane walks the row for the norm; the division is done by all lanes.  Rows are short
 // (<= a few KB) and the kernel is bandwidth-trivial next to the search.

@@ -1,0 +1,348 @@
+// Panel-stationary fp16 pre-filter of the thresholded searches (gfx950), dims <= 512.
+//
+// Same contract as sim_f16.hip (candidates = every pair whose fp16 score + rigorous error bound reaches the
+// threshold; vsc/index.py:142-165 semantics are restored by the exact stage), different data flow:
+//
+//   * a 128-row QUERY PANEL (all of K: <= 128 KiB of fp16) sits in LDS for as long as a workgroup works on
+//     it -- [k chunk of 128][row][16-byte slot ^ (row & 15)], conflict-free for the 32x32x16 A-fragment
+//     reads (16 lanes of a ds_read_b128 phase = 16 rows with distinct row & 15 = all 64 banks);
+//   * the REFERENCE rows stream straight into registers from a FRAGMENT-MAJOR fp16 image (layout.hip): the B
+//     fragment of one MFMA is one fully coalesced 1 KiB buffer load, fetched PF-1 k-steps ahead into a
+//     register ring.  No LDS-DMA, no barrier and no LDS write in the steady state;
+//   * 8 waves; wave w owns all 128 panel rows x columns [64 w, 64 w + 64) of a 512-column step: 4 x 2 blocks
+//     of v_mfma_f32_32x32x16_f16, 128 accumulator registers, 2 waves per SIMD;
+//   * work = (panel, slice of reference col-steps) items behind one atomic counter per panel.  A workgroup
+//     stays on its panel while slices are left (the panel is loaded once), then helps the panel with the
+//     most slices left: the XCDs of one part run at speeds 10 % apart under the power cap, a static split
+//     leaves the fast ones idle at the end of every launch.
+//
+// Against the 256x256 LDS-ring kernel: the same bytes per flop out of L2, but none of them crosses the LDS
+// twice, a third less LDS read traffic, no barriers -- MFMA busy 84 % instead of 64 % of the cycles, and the
+// workgroups of an XCD walk the same reference stream in step, so that every line is fetched once per XCD.
+// MFMA-bound (power-capped): 2 * 128 * 512 * dpadh flop per workgroup col-step.
+#include "kernels.h"
+
+namespace vscmi {
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+namespace f16p {
+
+constexpr int PR = F16P_PANEL_ROWS;  // 128
+constexpr int CSW = F16P_COL_STEP;   // 512
+constexpr int PF = 8;                // register ring: k-steps (7 in flight = 14 KiB per wave)
+
+__device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rsrc, int voff, char* lds) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)lds, 16, voff, 0, 0, 0);
+}
+__device__ __forceinline__ f16x8 bload(__amdgpu_buffer_rsrc_t rs, int voff, int soff) {
+    return __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, 0));
+}
+__device__ __forceinline__ const char* uniform_ptr(const char* p) {
+    const uint64_t v = reinterpret_cast<uint64_t>(p);
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+    return reinterpret_cast<const char*>(((uint64_t)hi << 32) | lo);
+}
+
+// One output tile (128 panel rows x the wave's 64 columns, K = NKC x 128): A fragments from the LDS panel one
+// k-step ahead, B fragments from the ring, refilled PF-1 k-steps ahead (voffset = 16 * lane + {0, 1024},
+// soffset = position in the item's slice); the stream continues into the wave's next tile at `so_next`.
+// Straight-line code, every LDS address = base register + immediate; the issue order is pinned (left alone
+// the scheduler sinks every read to just before its use).  acc = (not +=) the product.
+template <int NKC>
+__device__ __forceinline__ void tile_mma(const char* smem, const int (&abase)[8], f16x8 (&a)[4], f16x8 (&ring)[PF][2],
+                                         __amdgpu_buffer_rsrc_t rs, int so_tile, int so_next, int lane16,
+                                         f32x16 (&acc)[4][2]) {
+    const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    constexpr int NKS = NKC * 8;
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) {
+        const int t = ks + PF - 1;  // k-step that goes into the ring slot freed by k-step ks - 1
+        const int so = (t < NKS) ? so_tile + t * 2048 : so_next + (t - NKS) * 2048;
+        const int kn = (ks + 1) % NKS;  // A fragments of the next k-step (the next tile starts at 0 again)
+        const char* anext = smem + (kn >> 3) * 32768 + abase[kn & 7];
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            acc[m][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[m], ring[ks % PF][0], ks == 0 ? zero : acc[m][0], 0, 0, 0);
+            acc[m][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[m], ring[ks % PF][1], ks == 0 ? zero : acc[m][1], 0, 0, 0);
+            a[m] = *reinterpret_cast<const f16x8*>(anext + m * 8192);
+            if (m < 2) ring[(ks + PF - 1) % PF][m] = bload(rs, lane16 + m * 1024, so);
+        }
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            if (m < 2) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+        }
+    }
+}
+
+// lower edge of the candidate test for an exact threshold t: a pair with exact score >(=) t has fp16 score
+// >= t - eps; the subtraction's own rounding (< 2^-23 relative to the larger operand) is subtracted again
+__device__ __forceinline__ float candidate_edge(float t, float eps) { return (t - eps) - 2.4e-7f * (fabsf(t) + eps); }
+
+// Candidates of one wave tile -> the wave's PRIVATE segment of the candidate list (no atomics, no scans; a
+// shared atomic tail only when the segment is full).  Per 32x32 block one question first (its per-lane
+// maximum is known), then one ballot per accumulator register of the few blocks that hold a candidate.
+//   ROWTHR = false: thr[n] = edge of *radius for the lane's column of block column n (strict test)
+//   ROWTHR = true : rt = the panel's 128 row thresholds, rtmin[m] = smallest of row block m, eps[n] = the
+//                   lane's column bounds (non-strict test: k-NN ties must survive)
+template <bool ROWTHR>
+__device__ __forceinline__ void emit_candidates(const SimF16PArgs& a, const bool (&all)[2], const float (&thr)[2],
+                                                const float (&eps)[2], const float* rt, const float (&rtmin)[4],
+                                                int row0, int col0, const f32x16 (&acc)[4][2],
+                                                const float (&bm)[4][2], int lane, int64_t seg_base, int& count) {
+    // C layout of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
+    const int rl0 = 4 * (lane >> 5);
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int n = 0; n < 2; ++n) {
+            const bool blk = all[n] || (ROWTHR ? bm[m][n] >= candidate_edge(rtmin[m], eps[n]) : bm[m][n] > thr[n]);
+            if (!__any(blk)) continue;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int rl = rl0 + m * 32 + (r & 3) + 8 * (r >> 2);
+                bool cand;
+                if (ROWTHR)
+                    cand = acc[m][n][r] >= candidate_edge(rt[rl], eps[n]);
+                else
+                    cand = acc[m][n][r] > thr[n];
+                const unsigned long long hits = __ballot(all[n] || cand);
+                if (hits == 0ull) continue;
+                const int i = row0 + rl;
+                const int j = col0 + n * 32 + (lane & 31);
+                const unsigned long long ok = __ballot(((hits >> lane) & 1ull) && i < a.nq && j < a.nr);
+                if (ok == 0ull) continue;
+                const int total = __popcll(ok);
+                int64_t pos;
+                if (count + total <= a.seg_cap) {
+                    pos = seg_base + count;
+                    count += total;
+                } else {
+                    // segment full (candidates are not spread evenly): shared tail behind the segments
+                    unsigned long long base = 0;
+                    if (lane == 0) base = atomicAdd(a.tail_count, (unsigned long long)total);
+                    base = __shfl(base, 0);
+                    if ((long long)(base + total) > a.tail_cap) {
+                        if (lane == 0) atomicOr(a.overflow, 1);
+                        continue;
+                    }
+                    pos = a.tail_base + (int64_t)base;
+                }
+                if ((ok >> lane) & 1ull) {
+                    pos += __popcll(ok & ((1ull << lane) - 1));
+                    a.out_i[pos] = a.i0 + i;
+                    a.out_j[pos] = j;
+                }
+            }
+        }
+}
+
+}  // namespace f16p
+
+template <int NKC, bool ROWTHR>
+__global__ __launch_bounds__(512) void sim_f16p_kernel(SimF16PArgs a) {
+    using namespace f16p;
+    extern __shared__ __attribute__((aligned(16))) char smem[];  // the panel: NKC x 32 KiB
+    __shared__ float qn_max_w[8];
+    __shared__ float rt_sh[ROWTHR ? PR : 1];
+    __shared__ int item_sh[2];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    constexpr int NKS = NKC * 8;
+    constexpr int ROWB = NKC * 256;    // bytes per fp16 row
+    constexpr int TILEB = NKS * 2048;  // bytes per 64-row wave tile of the fragment-major image
+    const int lane16 = lane * 16;
+    // LDS byte offset of the lane's A fragment at k-step u of a k chunk (+ chunk * 32768 + block m * 8192)
+    int abase[8];
+    {
+        const int hi = lane >> 5, r15 = lane & 15, rl = lane & 31;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) abase[u] = rl * 256 + ((((2 * u) | hi) ^ r15) << 4);
+    }
+    const float radius = ROWTHR ? 0.0f : *a.radius;
+    const int seg = blockIdx.x * 8 + wave;  // this wave's private segment of the candidate list
+    const int64_t seg_base = (int64_t)seg * a.seg_cap;
+    int count = 0;
+    const int nslice = (a.nsteps + a.slice - 1) / a.slice;
+    int cur_panel = -1;
+    float nq_max = 0.f;
+    float rtmin[4] = {0.f, 0.f, 0.f, 0.f};
+    int panel = blockIdx.x % a.npanel;
+    for (;;) {
+        // ---- next work item: a slice of this workgroup's panel, else of the panel with the most left
+        __syncthreads();
+        if (wave == 0) {
+            int p = panel, s = 0;
+            for (;;) {
+                if (lane == 0) s = atomicAdd(&a.next_slice[p], 1);
+                s = __shfl(s, 0);
+                if (s < nslice) break;
+                int best = 0x7fffffff, bp = 0x7fffffff;
+                for (int q0 = 0; q0 < a.npanel; q0 += 64) {
+                    const int q = q0 + lane;
+                    const int pp = (q + (int)blockIdx.x) % a.npanel;  // ties: nearest after the workgroup's own
+                    const int v = q < a.npanel ? __hip_atomic_load(&a.next_slice[pp], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                                               : 0x7fffffff;
+                    if (v < best) { best = v; bp = pp; }
+                }
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) {
+                    const int ob = __shfl_xor(best, off), op = __shfl_xor(bp, off);
+                    if (ob < best || (ob == best && op < bp)) { best = ob; bp = op; }
+                }
+                if (best >= nslice) { p = -1; break; }
+                p = bp;
+            }
+            if (lane == 0) { item_sh[0] = p; item_sh[1] = s; }
+        }
+        __syncthreads();
+        panel = item_sh[0];
+        const int sl = item_sh[1];
+        if (panel < 0) break;
+        const int cs0 = sl * a.slice, cs1 = min(a.nsteps, cs0 + a.slice);
+        if (panel != cur_panel) {
+            __syncthreads();  // (item_sh is read; nobody reads the old panel any more)
+            // query panel -> LDS [k chunk][row][slot ^ (row & 15)]: the swizzle is applied to the SOURCE address,
+            // an LDS-DMA instruction writes its 64 x 16 bytes to consecutive LDS addresses
+            const __amdgpu_buffer_rsrc_t qrs = __builtin_amdgcn_make_buffer_rsrc(
+                (void*)uniform_ptr(reinterpret_cast<const char*>(a.Q) + (int64_t)panel * PR * ROWB), 0, PR * ROWB, 0x00020000);
+#pragma unroll
+            for (int n = 0; n < NKC * 4; ++n) {
+                const int p = n * 512 + tid;
+                const int kc = p >> 11, row = (p >> 4) & 127, slot = p & 15;
+                const int c = kc * 16 + (slot ^ (row & 15));
+                dma16(qrs, row * ROWB + c * 16, smem + (n * 512 + wave * 64) * 16);
+            }
+            // largest row norm of the panel (rows past the batch do not count); k-NN: the row thresholds
+            const bool in_batch = tid < PR && panel * PR + tid < a.nq;
+            float nv = in_batch ? a.qn[(int64_t)panel * PR + tid] : 0.f;
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) nv = fmaxf(nv, __shfl_xor(nv, off));
+            if (lane == 0) qn_max_w[wave] = nv;
+            if (ROWTHR && tid < PR) rt_sh[tid] = in_batch ? a.row_thr[(int64_t)panel * PR + tid] : INFINITY;
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's DMA pieces have landed ...
+            __syncthreads();                                  // ... and so have everybody else's
+            nq_max = fmaxf(qn_max_w[0], qn_max_w[1]);
+            if (ROWTHR) {
+                // smallest row threshold of each 32-row block
+                float v0 = rt_sh[lane], v1 = rt_sh[64 + lane];
+#pragma unroll
+                for (int off = 16; off > 0; off >>= 1) {
+                    v0 = fminf(v0, __shfl_xor(v0, off));
+                    v1 = fminf(v1, __shfl_xor(v1, off));
+                }
+                rtmin[0] = __shfl(v0, 0);
+                rtmin[1] = __shfl(v0, 32);
+                rtmin[2] = __shfl(v1, 0);
+                rtmin[3] = __shfl(v1, 32);
+            }
+            cur_panel = panel;
+        }
+        // ---- this wave's stream: tiles (cs * 8 + wave), cs = cs0 .. cs1-1, TILEB contiguous bytes each.
+        // Buffer resource = the item's slice of the fragment-major image (reads past its end return 0).
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+            (void*)uniform_ptr(reinterpret_cast<const char*>(a.Rf) + (int64_t)cs0 * 8 * TILEB), 0, (cs1 - cs0) * 8 * TILEB,
+            0x00020000);
+        int so_tile = wave * TILEB;
+        f16x8 ring[PF][2];
+#pragma unroll
+        for (int dd = 0; dd < PF - 1; ++dd) {
+            // (NKS >= 8 > PF - 1: the ring never reaches into the next tile here)
+            ring[dd][0] = bload(rs, lane16, so_tile + dd * 2048);
+            ring[dd][1] = bload(rs, lane16 + 1024, so_tile + dd * 2048);
+        }
+        f16x8 afr[4];
+#pragma unroll
+        for (int m = 0; m < 4; ++m) afr[m] = *reinterpret_cast<const f16x8*>(smem + abase[0] + m * 8192);
+        for (int cs = cs0; cs < cs1; ++cs) {
+            const int col0 = cs * CSW + wave * 64;
+            // norm bounds of the lane's two columns (the image is padded to whole col-steps)
+            const float rn0 = a.rn[col0 + (lane & 31)], rn1 = a.rn[col0 + 32 + (lane & 31)];
+            f32x16 acc[4][2];
+            tile_mma<NKC>(smem, abase, afr, ring, rs, so_tile, so_tile + 8 * TILEB, lane16, acc);
+            so_tile += 8 * TILEB;
+            const float eps[2] = {(a.c1 * nq_max * rn0 + a.c2 * (nq_max + rn0) + a.c3) * 1.001f,
+                                  (a.c1 * nq_max * rn1 + a.c2 * (nq_max + rn1) + a.c3) * 1.001f};
+            const bool all[2] = {!(eps[0] < INFINITY), !(eps[1] < INFINITY)};  // also catches NaN (inf * 0)
+            const float thr[2] = {candidate_edge(radius, eps[0]), candidate_edge(radius, eps[1])};
+            // candidates are rare: one max per 32x32 block first, one compare for the whole wave tile
+            float bm[4][2];
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+#pragma unroll
+                for (int n = 0; n < 2; ++n) {
+                    float x = fmaxf(fmaxf(acc[m][n][0], acc[m][n][1]), acc[m][n][2]);
+#pragma unroll
+                    for (int r = 3; r < 15; r += 2) x = fmaxf(fmaxf(x, acc[m][n][r]), acc[m][n][r + 1]);
+                    bm[m][n] = fmaxf(x, acc[m][n][15]);
+                }
+            bool any_blk = all[0] || all[1];
+            if (ROWTHR) {
+#pragma unroll
+                for (int m = 0; m < 4; ++m)
+                    any_blk |= bm[m][0] >= candidate_edge(rtmin[m], eps[0]) || bm[m][1] >= candidate_edge(rtmin[m], eps[1]);
+            } else {
+                const float x0 = fmaxf(fmaxf(bm[0][0], bm[1][0]), fmaxf(bm[2][0], bm[3][0]));
+                const float x1 = fmaxf(fmaxf(bm[0][1], bm[1][1]), fmaxf(bm[2][1], bm[3][1]));
+                any_blk |= x0 > thr[0] || x1 > thr[1];
+            }
+            if (__any(any_blk))
+                emit_candidates<ROWTHR>(a, all, thr, eps, rt_sh, rtmin, panel * PR, col0, acc, bm, lane, seg_base, count);
+        }
+    }
+    if (lane == 0) a.seg_count[seg] = count;
+}
+
+// Work split of one launch: slices (in col-steps) such that every workgroup sees >= ~16 items when the
+// problem allows it (the stealing balances to within one item), between 4 and 64 col-steps each
+void sim_f16p_plan(int64_t nq, int64_t nr, int* npanel, int* nsteps, int* slice, int* grid) {
+    using namespace f16p;
+    const int64_t P = (nq + PR - 1) / PR, S = (nr + CSW - 1) / CSW;
+    int64_t sl = (S * P) / (256 * 16);
+    sl = std::max<int64_t>(4, std::min<int64_t>(64, sl));
+    sl = std::min(sl, std::max<int64_t>(S, 1));
+    const int64_t items = P * ((S + sl - 1) / sl);
+    *npanel = (int)P;
+    *nsteps = (int)S;
+    *slice = (int)sl;
+    *grid = (int)std::max<int64_t>(1, std::min<int64_t>(256, items));
+}
+
+template <int NKC>
+static int launch_nkc(const SimF16PArgs& a, int grid, hipStream_t stream) {
+    const int lds = NKC * 32768;
+    // (per device, not per process: a handle on a second device needs its own attribute)
+    static bool attr_done[64] = {};
+    int dev = 0;
+    VSC_HIP(hipGetDevice(&dev));
+    if (dev < 0 || dev >= 64 || !attr_done[dev]) {
+        VSC_HIP(hipFuncSetAttribute((const void*)sim_f16p_kernel<NKC, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        VSC_HIP(hipFuncSetAttribute((const void*)sim_f16p_kernel<NKC, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        if (dev >= 0 && dev < 64) attr_done[dev] = true;
+    }
+    if (a.row_thr)
+        hipLaunchKernelGGL((sim_f16p_kernel<NKC, true>), dim3((unsigned)grid), dim3(512), lds, stream, a);
+    else
+        hipLaunchKernelGGL((sim_f16p_kernel<NKC, false>), dim3((unsigned)grid), dim3(512), lds, stream, a);
+    VSC_HIP(hipGetLastError());
+    return VSC_OK;
+}
+
+int launch_sim_f16p(const SimF16PArgs& a, int grid, hipStream_t stream) {
+    if (grid <= 0 || a.npanel <= 0 || a.nsteps <= 0) return VSC_OK;
+    VSC_HIP(hipMemsetAsync(a.next_slice, 0, (size_t)a.npanel * sizeof(int), stream));
+    switch (a.dpadh) {
+        case 128: return launch_nkc<1>(a, grid, stream);
+        case 256: return launch_nkc<2>(a, grid, stream);
+        case 384: return launch_nkc<3>(a, grid, stream);
+        case 512: return launch_nkc<4>(a, grid, stream);
+    }
+    set_error("sim_f16p: dpadh %d is not one of 128, 256, 384, 512", a.dpadh);
+    return VSC_ERR_INVALID;
+}
+
+}  // namespace vscmi

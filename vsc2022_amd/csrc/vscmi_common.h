@@ -37,6 +37,7 @@ void set_error(const char* fmt, ...);
 // the arithmetic contract shared with the oracle (acc = fmaf(q[k], r[k], acc), k = 0..d-1).
 constexpr int ROW_PAD = 128;
 constexpr int ROW_PAD_H = 256;  // row padding of everything the 256x256 fp16 pre-filter tiles read
+constexpr int ROW_PAD_REF = 512;  // row padding of the reference images (whole 512-column steps of sim_f16p.hip)
 constexpr int K_PAD = 64;  // >= 2 K-tiles of 32 per row: the tile stream prefetches two K-tiles ahead
 
 __host__ __device__ inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
