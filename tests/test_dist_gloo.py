@@ -198,3 +198,120 @@ def test_prefix_select_world3_ties_and_long_lists(tmp_path):
             assert per_rank[r][case][3] == want, (case, r, per_rank[r][case][3], want)
         if len(order) > k:
             assert all(np.float32(per_rank[r][case][4]) == np.float32(-top[-1][0]) for r in range(world))
+
+
+# ---------------------------------------------------------------- one shard holds the whole top-K
+def _skew_all_worker(rank, world, port, out_path):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        sys.path[:0] = [ROOT]
+        from vsc2022_amd import dist as vdist
+
+        K = 100
+        rng = np.random.default_rng(50 + rank)
+        # rank 0: 400 scores near 1 (the entire global top-K and more); the others: noise near 0
+        full = (0.9 + 0.1 * rng.random(400) if rank == 0 else 0.1 * rng.random(300)).astype(np.float32)
+        full = np.sort(full)[::-1].copy()
+        calls = []
+
+        def local_search(k_local):
+            calls.append(k_local)
+            s = torch.from_numpy(full[:k_local].copy())
+            z = torch.zeros(len(s), dtype=torch.int32)
+            return z, z, s, float("-inf")
+
+        hi, hj, hs, tau = vdist.sharded_hits(local_search, 10 ** 9, K, k_local_start=63)
+        torch.save((hs.numpy(), tau, calls), f"{out_path}.{rank}")
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_hits_terminates_when_one_shard_holds_the_whole_topk(tmp_path):
+    """Rank 0's list is cut at k_local == K with the global cut equal to its last element (never 'exact' by the
+    tau > cut rule); rank 1 is exact from the start.  Every rank must leave the loop on the same iteration."""
+    out = str(tmp_path / "skew")
+    mp.spawn(_skew_all_worker, args=(2, 29300 + os.getpid() % 500, out), nprocs=2, join=True)
+    r0 = torch.load(f"{out}.0", weights_only=False)
+    r1 = torch.load(f"{out}.1", weights_only=False)
+    assert len(r0[0]) == 100 and len(r1[0]) == 0
+    assert r0[2][-1] == 100, r0[2]       # rank 0 doubled its budget up to K
+    assert r1[2] == [63], r1[2]          # the exact rank kept its first result (no repeated search)
+    assert np.float32(r0[1]) == np.float32(r1[1]) == r0[0][-1]
+
+
+# ---------------------------------------------------------------- reference-sharded index (configs[4])
+class _OracleIndex:
+    """FlatIndex stand-in over the CPU oracle (there is no GPU here): what is under test is refshard.py."""
+
+    def __init__(self, rows):
+        self.rows = np.ascontiguousarray(rows, dtype=np.float32)
+        self.ntotal = len(self.rows)
+
+    def search(self, x, k):
+        import oracle as orc
+
+        return orc.knn(np.ascontiguousarray(x, dtype=np.float32), self.rows, k)
+
+    def global_topk(self, x, K, device_out=False):
+        import oracle as orc
+
+        i, j, s, info = orc.global_threshold_search(np.ascontiguousarray(x, dtype=np.float32), self.rows, K,
+                                                    return_info=True)
+        return i, j, s, info["radius"]
+
+
+def _refshard_data():
+    rng = np.random.default_rng(11)
+    q = rng.standard_normal((70, 24)).astype(np.float32)
+    r = rng.standard_normal((260, 24)).astype(np.float32)
+    r[200:215] = r[20:35]      # duplicate rows in different shards: exact score ties across ranks
+    q[5] = q[6]                # and duplicate query rows: ties resolved by (row, ref)
+    q /= np.linalg.norm(q, axis=1, keepdims=True)
+    r /= np.linalg.norm(r, axis=1, keepdims=True)
+    return q, r
+
+
+def _refshard_worker(rank, world, port, out_path):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        sys.path[:0] = [ROOT, os.path.join(ROOT, "oracle")]
+        from vsc2022_amd import dist as vdist
+        from vsc2022_amd.refshard import RefShardedIndex
+
+        q, r = _refshard_data()
+        lo, hi = vdist.shard_ranges(len(r), world)[rank]
+        idx = RefShardedIndex(_OracleIndex(r[lo:hi]), lo, len(r))
+        D, I = idx.search(q, 9)
+        res = {"D": D, "I": I}
+        for K in (50, 700, 5000):
+            i, j, s, tau = idx.global_topk(q, K, k_local_start=K // 6 + 1)
+            res[f"i{K}"], res[f"j{K}"], res[f"s{K}"] = i.numpy(), j.numpy(), s.numpy()
+        np.savez(f"{out_path}.{rank}.npz", **res)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_ref_sharded_index_equals_single_index(tmp_path):
+    """world 3: per-row k-NN and the global top-K over column shards equal the single-index results bit for
+    bit (ties across shards included); every rank holds the same merged result."""
+    sys.path[:0] = [ROOT, os.path.join(ROOT, "oracle")]
+    import oracle as orc
+
+    out = str(tmp_path / "rs")
+    world = 3
+    mp.spawn(_refshard_worker, args=(world, 29400 + os.getpid() % 500, out), nprocs=world, join=True)
+    q, r = _refshard_data()
+    D, I = orc.knn(q, r, 9)
+    for rank in range(world):
+        got = np.load(f"{out}.{rank}.npz")
+        assert np.array_equal(got["I"], I) and np.array_equal(got["D"].view(np.uint32), D.view(np.uint32))
+        for K in (50, 700, 5000):
+            # K small enough that the reference's schedule never re-thresholds on a tie: plain exact top-K
+            S = (q @ r.T).astype(np.float32)
+            i, j, s = orc.global_threshold_search(q, r, K)
+            assert np.array_equal(got[f"i{K}"], i) and np.array_equal(got[f"j{K}"], j), (rank, K)
+            assert np.array_equal(got[f"s{K}"].view(np.uint32), s.view(np.uint32))

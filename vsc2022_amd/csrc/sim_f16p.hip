@@ -92,7 +92,7 @@ __device__ __forceinline__ float candidate_edge(float t, float eps) { return (t 
 template <bool ROWTHR>
 __device__ __forceinline__ void emit_candidates(const SimF16PArgs& a, const bool (&all)[2], const float (&thr)[2],
                                                 const float (&eps)[2], const float* rt, const float (&rtmin)[4],
-                                                int row0, int col0, const f32x16 (&acc)[4][2],
+                                                int row0, int col0, bool interior, const f32x16 (&acc)[4][2],
                                                 const float (&bm)[4][2], int lane, int64_t seg_base, int& count) {
     // C layout of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
     const int rl0 = 4 * (lane >> 5);
@@ -114,7 +114,8 @@ __device__ __forceinline__ void emit_candidates(const SimF16PArgs& a, const bool
                 if (hits == 0ull) continue;
                 const int i = row0 + rl;
                 const int j = col0 + n * 32 + (lane & 31);
-                const unsigned long long ok = __ballot(((hits >> lane) & 1ull) && i < a.nq && j < a.nr);
+                // (tiles that reach past the batch or the references drop their padding rows / columns)
+                const unsigned long long ok = interior ? hits : __ballot(((hits >> lane) & 1ull) && i < a.nq && j < a.nr);
                 if (ok == 0ull) continue;
                 const int total = __popcll(ok);
                 int64_t pos;
@@ -291,7 +292,8 @@ __global__ __launch_bounds__(512) void sim_f16p_kernel(SimF16PArgs a) {
                 any_blk |= x0 > thr[0] || x1 > thr[1];
             }
             if (__any(any_blk))
-                emit_candidates<ROWTHR>(a, all, thr, eps, rt_sh, rtmin, panel * PR, col0, acc, bm, lane, seg_base, count);
+                emit_candidates<ROWTHR>(a, all, thr, eps, rt_sh, rtmin, panel * PR, col0,
+                                        panel * PR + PR <= a.nq && col0 + 64 <= a.nr, acc, bm, lane, seg_base, count);
         }
     }
     if (lane == 0) a.seg_count[seg] = count;

@@ -101,18 +101,36 @@ def _all_gather_scalar(v: int, device, group) -> List[int]:
     return [int(x.item()) for x in out]
 
 
-def distributed_prefix_select(sorted_scores: torch.Tensor, k_total: int, group=None) -> Tuple[int, float]:
+def _all_gather_vec(v: torch.Tensor, group) -> torch.Tensor:
+    """[world, len(v)] from every rank's small 1-D int64 vector (one collective, no host sync unless gloo)."""
+    rank, world = _world(group)
+    if world == 1:
+        return v.unsqueeze(0)
+    host = _via_host(v, group)
+    send = v.cpu() if host else v
+    out = [torch.empty_like(send) for _ in range(world)]
+    dist.all_gather(out, send, group=group)
+    return torch.stack(out).to(v.device)
+
+
+def distributed_prefix_select(sorted_scores: torch.Tensor, k_total: int, group=None, ties: str = "rank"
+                              ) -> Tuple[int, float]:
     """How many leading elements of this rank's score-DESCENDING list belong to the global top
-    `k_total` of the union of all ranks' lists, under the total order (score desc, rank asc,
-    local position asc).  Returns (n_take, tau) with tau the k_total-th best score (or -inf when
-    the union is shorter than k_total).
+    `k_total` of the union of all ranks' lists.  Returns (n_take, tau) with tau the k_total-th best
+    score (-inf when the union is shorter than k_total).
+
+    ties="rank": total order (score desc, rank asc, local position asc) -- exactly k_total elements are
+                 taken over all ranks (query-sharded search: rank order IS query-row order).
+    ties="all" : every element tied with tau is taken (reference-sharded search: the caller orders the
+                 ties by (query row, ref row) after gathering them and cuts at k_total).
+
+    Three collectives (all-reduce of a 65537-entry histogram that also carries the list lengths,
+    all-reduce of the second-level histogram, all-gather of the tie counts) and ONE host sync at the end:
+    everything in between stays on the device.
     """
     rank, world = _world(group)
     device = sorted_scores.device
     n_local = int(sorted_scores.numel())
-    total = sum(_all_gather_scalar(n_local, device, group))
-    if total <= k_total:
-        return n_local, float("-inf")
     if k_total <= 0:
         return 0, float("inf")
     # The list is sorted, and a rank can contribute at most k_total elements: everything below is
@@ -121,38 +139,39 @@ def distributed_prefix_select(sorted_scores: torch.Tensor, k_total: int, group=N
     lead = sorted_scores[: min(n_local, k_total)]
     n_lead = int(lead.numel())
     asc = score_keys(lead).flip(0).contiguous() if n_lead else torch.zeros(0, dtype=torch.int64, device=device)
+    steps = torch.arange(65537, dtype=torch.int64, device=device)
 
-    def count_ge(bounds: torch.Tensor) -> torch.Tensor:
-        """number of local keys >= each bound"""
-        return n_lead - torch.searchsorted(asc, bounds)
-
-    def level(base: int, shift: int, floor_above: int):
+    def level(base: torch.Tensor, shift: int) -> torch.Tensor:
         """65536-bin histogram of the keys in [base, base + 65536 << shift), bins of width 1 << shift"""
-        bounds = base + (torch.arange(65537, dtype=torch.int64, device=device) << shift)
-        ge = count_ge(bounds)
+        ge = n_lead - torch.searchsorted(asc, base + (steps << shift))
         return (ge[:-1] - ge[1:]).to(torch.int64)
 
-    hist = _all_reduce_sum(level(0, 16, 0), group)
-    # walk from the top bin: first bin whose cumulative count reaches k_total
-    cum = torch.cumsum(hist.flip(0), 0)
-    b1 = 65535 - int(torch.searchsorted(cum, torch.tensor([k_total], dtype=torch.int64, device=device)).item())
-    above1 = int(cum[65535 - b1 - 1].item()) if b1 < 65535 else 0
-    hist2 = _all_reduce_sum(level(b1 << 16, 0, 0), group)
-    cum2 = torch.cumsum(hist2.flip(0), 0)
-    need = k_total - above1
-    b2 = 65535 - int(torch.searchsorted(cum2, torch.tensor([need], dtype=torch.int64, device=device)).item())
-    above2 = int(cum2[65535 - b2 - 1].item()) if b2 < 65535 else 0
+    def pick(hist: torch.Tensor, need: torch.Tensor):
+        """walk from the top bin: (bin, elements above it) of the first bin whose cumulative count reaches `need`"""
+        cum = torch.cumsum(hist.flip(0), 0)
+        pos = torch.searchsorted(cum, need.reshape(1)).clamp(max=65535)[0]
+        above = torch.where(pos > 0, cum[(pos - 1).clamp(min=0)], torch.zeros_like(pos))
+        return 65535 - pos, above
+
+    zero = torch.zeros((), dtype=torch.int64, device=device)
+    k_t = torch.tensor(k_total, dtype=torch.int64, device=device)
+    h1 = _all_reduce_sum(torch.cat([level(zero, 16), torch.tensor([n_local], dtype=torch.int64, device=device)]), group)
+    total = h1[65536]
+    b1, above1 = pick(h1[:65536], k_t)
+    h2 = _all_reduce_sum(level(b1 << 16, 0), group)
+    b2, above2 = pick(h2, k_t - above1)
     tau_key = (b1 << 16) | b2
-    n_gt_global = above1 + above2
-    m = k_total - n_gt_global  # elements tied with tau that still fit
-    edge = count_ge(torch.tensor([tau_key, tau_key + 1], dtype=torch.int64, device=device))
-    n_gt = int(edge[1].item())
-    n_eq = int(edge[0].item()) - n_gt
-    ties = _all_gather_scalar(n_eq, device, group)
-    before = sum(ties[:rank])
-    take_ties = max(0, min(n_eq, m - before))
-    tau = key_to_score(tau_key)
-    return n_gt + take_ties, float(tau)
+    edge = n_lead - torch.searchsorted(asc, torch.stack([tau_key, tau_key + 1]))
+    n_gt, n_eq = edge[1], edge[0] - edge[1]
+    eq_all = _all_gather_vec(n_eq.reshape(1), group)[:, 0]
+    before = eq_all[:rank].sum()
+    m = k_t - (above1 + above2)  # elements tied with tau that still fit
+    take_ties = n_eq if ties == "all" else torch.minimum(n_eq, (m - before).clamp(min=0))
+    res = torch.stack([n_gt + take_ties, tau_key, total]).cpu()  # the one host sync
+    n_take, tau_key_h, total_h = (int(x) for x in res)
+    if total_h <= k_total:
+        return n_local, float("-inf")
+    return n_take, float(key_to_score(tau_key_h))
 
 
 def all_gather_varlen(t: torch.Tensor, group=None) -> torch.Tensor:
@@ -182,8 +201,8 @@ class ShardedCandidates:
         return int(self.score.numel())
 
 
-def merge_hits(local_scores_sorted: torch.Tensor, k_global: int, complete_above: float, group=None
-               ) -> Tuple[int, float, bool]:
+def merge_hits(local_scores_sorted: torch.Tensor, k_global: int, complete_above: float, group=None,
+               ties: str = "rank") -> Tuple[int, float, bool]:
     """Step 1: prefix of the local hit list that survives the global K cut.
 
     `complete_above`: every local hit with score > complete_above is present in the local list
@@ -191,20 +210,25 @@ def merge_hits(local_scores_sorted: torch.Tensor, k_global: int, complete_above:
     local cut is not strictly below the global one -- the caller must then rerun that rank's
     local search with a larger local K (all ranks call merge_hits again).
     """
-    n_take, tau = distributed_prefix_select(local_scores_sorted, k_global, group)
+    n_take, tau = distributed_prefix_select(local_scores_sorted, k_global, group, ties)
     exact = (complete_above == float("-inf")) or (tau > complete_above)
     return n_take, tau, exact
 
 
 def sharded_hits(local_search, local_matrix_size: int, k_global: int, group=None, device=None,
-                 k_local_start: Optional[int] = None):
+                 k_local_start: Optional[int] = None, ties: str = "rank"):
     """Exact global top-`k_global` hits from per-rank searches.
 
     local_search(k_local) -> (i, j, s, radius): this rank's global-threshold search with budget
     k_local (hits sorted by (score desc, row asc, ref asc); radius = the search's final radius).
-    local_matrix_size = n_local_query_rows * n_ref_rows.  Starts from k_local = 1.25*K/world and doubles
-    the budget of any rank whose own cut is not strictly below the global cut (skewed shards), until
-    the result is exact everywhere.  Returns (i, j, s) = this rank's share of the global top-K.
+    local_matrix_size = rows x columns of this rank's part of the score matrix.  Starts from k_local =
+    1.25*K/world and doubles the budget of any rank whose own cut is not strictly below the global cut
+    (skewed shards), until the result is exact everywhere.  A rank that already is exact keeps its
+    result across the retries (its list stays complete above a cut that can only rise) and only takes
+    part in the collectives; a rank whose budget has reached K is exact by construction (nothing beyond
+    its K best can be among the global K best).  Every rank leaves the loop on the same, all-reduced
+    flag.  Returns (i, j, s, tau) = this rank's share of the global top-K (ties="all": including every
+    hit tied with tau, see distributed_prefix_select).
     """
     rank, world = _world(group)
     # A rank's share of the global top-K is K/world up to sampling noise when the shards are alike; the
@@ -213,21 +237,27 @@ def sharded_hits(local_search, local_matrix_size: int, k_global: int, group=None
     k_local = max(1, min(k_global, (5 * k_global) // (4 * max(world, 1)) + 1))
     if k_local_start is not None:
         k_local = max(1, min(k_global, int(k_local_start)))
+    cached = None
     while True:
-        hi, hj, hs, radius = local_search(k_local)
-        n = int(hs.numel())
-        if n >= local_matrix_size:
-            complete_above = float("-inf")      # the whole local matrix was kept
-        elif n >= k_local:
-            complete_above = float(hs[-1].item())  # truncated at k_local: ties with the last may be missing
-        else:
-            complete_above = float(radius)      # hits <= radius were dropped by the schedule
-        n_take, tau, exact = merge_hits(hs, k_global, complete_above, group)
+        if cached is None:
+            hi, hj, hs, radius = local_search(k_local)
+            n = int(hs.numel())
+            if n >= local_matrix_size:
+                complete_above = float("-inf")      # the whole local matrix was kept
+            elif n >= k_local:
+                complete_above = float(hs[-1].item())  # truncated at k_local: ties with the last may be missing
+            else:
+                complete_above = float(radius)      # hits <= radius were dropped by the schedule
+            cached = (hi, hj, hs, complete_above)
+        hi, hj, hs, complete_above = cached
+        n_take, tau, exact = merge_hits(hs, k_global, complete_above, group, ties)
+        exact = exact or k_local >= k_global
         all_exact = all_reduce_max_int(0 if exact else 1, hs.device if device is None else device, group) == 0
-        if all_exact or k_local >= k_global:
+        if all_exact:
             return hi[:n_take], hj[:n_take], hs[:n_take], tau
         if not exact:
             k_local = min(k_global, k_local * 2)
+            cached = None
 
 
 def merge_candidates(q_vid: torch.Tensor, r_vid: torch.Tensor, score: torch.Tensor, first_i: torch.Tensor,

@@ -1,0 +1,103 @@
+"""Reference-sharded search (BASELINE configs[4]): every rank holds a contiguous slice
+of the reference rows in its own HBM-resident flat index, every rank sees ALL queries, and the per-shard
+results are merged over `torch.distributed` (RCCL on GPUs, gloo in the CPU tests).
+
+This is what the reference gets from FAISS when the index does not fit one device
+(`vsc/index.py:153` `ngpu=-1`, `vsc/index.py:171` / `vsc/baseline/score_normalization.py:88-89`
+`faiss.index_cpu_to_all_gpus`, IndexShards): same results as one index over the concatenated rows.
+
+  * `search(x, k)`        per-row k-NN: `vsc_index_knn` on the shard, local ids + row offset, one
+                           all-gather of the [nq, k] (score, id) pairs, per-row merge by (score desc, id asc)
+                           (`dist.ref_sharded_knn`).
+  * `global_topk(x, K)`   the K best pairs of the whole score matrix (the search of
+                           `vsc/index.py:142-165` when the columns are sharded): per-shard global-threshold
+                           search with a local budget, exact distributed selection of the K-th best score
+                           (histogram all-reduce, `dist.distributed_prefix_select`), all-gather of the
+                           survivors, final order (score desc, query row asc, ref row asc).
+
+Result contract: identical to a single index over all rows (bit for bit: scores are the same fp32 fma
+chains) whenever the reference's own batch schedule does not drop hits tied with a re-threshold radius
+(the same caveat as the query-sharded path).
+"""
+from typing import Optional, Tuple
+
+import numpy as np
+import torch
+
+from vsc2022_amd import dist as vdist
+
+
+class RefShardedIndex:
+    """One rank's slice of a reference set + the collectives that make it look like one index.
+
+    `local_index` quacks like `vsc2022_amd.vsc.index.FlatIndex` (`.search(x, k) -> (D, I)`,
+    `.global_topk(x, K, device_out=...) -> (i, j, s, radius)`, `.ntotal`); the CPU tests plug in an
+    oracle-backed stand-in, production uses FlatIndex.  `row0` = global id of the shard's first row,
+    `n_total` = rows of the whole reference set.
+    """
+
+    def __init__(self, local_index, row0: int, n_total: int, group=None, device: Optional[torch.device] = None):
+        self.local, self.row0, self.n_total, self.group = local_index, int(row0), int(n_total), group
+        self.device = device if device is not None else torch.device("cpu")
+
+    @classmethod
+    def build(cls, ref_rows, dim: int, metric: int, device_index: int, group=None) -> "RefShardedIndex":
+        """Shard `ref_rows` ([n, dim] array / tensor that every rank can see, e.g. an np.memmap of the
+        descriptor file) by `dist.shard_ranges` and add this rank's rows to a FlatIndex on its GPU."""
+        from vsc2022_amd.vsc.index import FlatIndex
+
+        rank, world = vdist._world(group)
+        n_total = int(ref_rows.shape[0])
+        lo, hi = vdist.shard_ranges(n_total, world)[rank]
+        idx = FlatIndex(dim, metric, device_index)
+        if hi > lo:
+            idx.add(ref_rows[lo:hi])
+        return cls(idx, lo, n_total, group, torch.device("cuda", device_index))
+
+    @property
+    def ntotal(self) -> int:
+        return self.n_total
+
+    # ---- per-row k-NN (faiss index.search over IndexShards)
+    def search(self, x, k: int) -> Tuple[np.ndarray, np.ndarray]:
+        """(D float32 [n, k], I int64 [n, k]) with GLOBAL reference ids; identical on every rank."""
+        n = int(x.shape[0])
+        n_loc = int(self.local.ntotal)
+        D = np.full((n, k), -np.inf, dtype=np.float32)
+        I = np.full((n, k), -1, dtype=np.int64)
+        kk = min(k, n_loc)
+        if kk > 0 and n > 0:
+            d, i = self.local.search(x, kk)
+            D[:, :kk] = d
+            I[:, :kk] = np.where(i >= 0, i + self.row0, -1)
+        gD, gI = vdist.ref_sharded_knn(torch.from_numpy(D).to(self.device), torch.from_numpy(I).to(self.device), k,
+                                       self.group)
+        return gD.cpu().numpy(), gI.cpu().numpy()
+
+    # ---- global top-K of the whole score matrix
+    def global_topk(self, x, K: int, k_local_start: Optional[int] = None):
+        """(i int32, j int64 GLOBAL ref row, s float32, tau): the K best (query row, ref row) pairs over all
+        shards, ordered (score desc, row asc, ref asc); torch tensors on `self.device`, identical on every rank."""
+        n = int(x.shape[0])
+        n_loc = int(self.local.ntotal)
+
+        def local_search(k_local):
+            if n == 0 or n_loc == 0:
+                z = torch.zeros(0, dtype=torch.int32, device=self.device)
+                return z, z, torch.zeros(0, dtype=torch.float32, device=self.device), float("-inf")
+            i, j, s, rad = self.local.global_topk(x, k_local, device_out=self.device.type == "cuda")
+            if not isinstance(s, torch.Tensor):
+                i, j, s = (torch.from_numpy(np.ascontiguousarray(a)).to(self.device) for a in (i, j, s))
+            return i, j, s, rad
+
+        hi, hj, hs, tau = vdist.sharded_hits(local_search, n * n_loc, int(K), self.group, self.device,
+                                             k_local_start=k_local_start, ties="all")
+        packed = torch.stack([hi.to(torch.int64), hj.to(torch.int64) + self.row0,
+                              hs.contiguous().view(torch.int32).to(torch.int64)], dim=1)
+        allp = vdist.all_gather_varlen(packed, self.group)
+        s = allp[:, 2].to(torch.int32).view(torch.float32)
+        # (score desc, row asc, ref asc): stable sorts from the least significant key up
+        o = torch.sort(allp[:, 1], stable=True).indices
+        o = o[torch.sort(allp[o, 0], stable=True).indices]
+        o = o[torch.sort(-s[o].to(torch.float64), stable=True).indices][: int(K)]
+        return allp[o, 0].to(torch.int32), allp[o, 1], s[o], tau

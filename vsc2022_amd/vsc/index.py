@@ -156,6 +156,10 @@ class FlatIndex:
             import torch
 
             x = x.to(torch.float32).contiguous()
+            if x.is_cuda:
+                # libvscmi runs on its own non-blocking stream: whatever torch kernel produced (or converted)
+                # these rows must have finished before the library reads them
+                torch.cuda.synchronize(x.device)
         if x.ndim != 2 or x.shape[1] != self.d:
             raise ValueError(f"expected [n, {self.d}] features, got {tuple(x.shape)}")
         p, mem = _lib.ptr(x)
