@@ -16,11 +16,18 @@ Fixtures
   g5_localization_*    VCSLLocalizationMaxSim / CandidateScore .localize_all -> Match rows
   g6_end_to_end        evaluate_descriptor_track-equivalent flow + matching flow: uAP, segment AP
   g7_metrics           random matches -> match_metric / average_precision values of vsc/metrics.py
+  g8_config1_pipeline  BASELINE configs[0] shape (50 x 20 vs 50 x 20 rows, 512-d, K = 60 000), through FILES and
+                       the reference's own entry points: evaluate_descriptor_track() and
+                       sscd_baseline.main() WITH --score_norm_features (beta 1.2, bias 0.5, MaxSim TN) and
+                       --ground_truth.  Inputs are regenerated from the seed by vsc2022_amd/synth.py; the
+                       fixture holds their checksum and the reference's outputs.
 """
 import argparse
+import hashlib
 import io
 import os
 import sys
+import tempfile
 
 import numpy as np
 
@@ -296,12 +303,85 @@ def gen_g7():
     return "g7_metrics", out
 
 
+G8 = dict(seed=80, n_query=50, n_ref=50, dim=512, q_frames=(20, 20), r_frames=(20, 20), planted_frac=0.2, noise=0.05,
+          copy_len=(8, 20))
+G8_NOISE = dict(seed=81, n_videos=30, frames=(20, 20))
+
+
+def g8_inputs():
+    """(queries, refs, noise, gts) of the config-1 fixture; shared with tests/test_gpu_config1.py via synth."""
+    q, r, gts = synth.make_dataset(**G8)
+    noise = synth.make_videos(np.random.default_rng(G8_NOISE["seed"]), G8_NOISE["n_videos"], G8["dim"],
+                              G8_NOISE["frames"], "R")
+    for k, v in enumerate(noise):  # loaded as Dataset.REFS by the reference, and must not share ids with the refs
+        v.video_id = f"R{900000 + k:06d}"
+    return q, r, noise, gts
+
+
+def inputs_digest(*video_lists):
+    h = hashlib.sha256()
+    for vids in video_lists:
+        for v in vids:
+            h.update(str(v.video_id).encode())
+            h.update(np.ascontiguousarray(v.feature, dtype=np.float32).tobytes())
+            h.update(np.ascontiguousarray(v.timestamps, dtype=np.float32).tobytes())
+    return h.hexdigest()
+
+
+def gen_g8():
+    import matplotlib
+
+    matplotlib.use("Agg")
+    from vsc.baseline import sscd_baseline as ref_sscd
+    from vsc.descriptor_eval_lib import evaluate_descriptor_track
+    from vsc.metrics import Dataset, evaluate_matching_track
+
+    assert ref_sscd.__file__.startswith(REFERENCE)
+    q, r, noise, gts = g8_inputs()
+    out = {"digest": np.array(inputs_digest(q, r, noise))}
+    with tempfile.TemporaryDirectory() as tmp:
+        qp, rp, npth, gtp = (os.path.join(tmp, n) for n in ("q.npz", "r.npz", "noise.npz", "gt.csv"))
+        store_features(qp, vf(q))
+        store_features(rp, vf(r))
+        store_features(npth, vf(noise))
+        Match.write_csv([Match(g.query_id, g.ref_id, 1.0, g.query_start, g.query_end, g.ref_start, g.ref_end)
+                         for g in gts], gtp)
+        # 1. descriptor track (vsc/descriptor_eval_lib.py:27-60)
+        ap, cands = evaluate_descriptor_track(qp, rp, gtp)
+        out["desc_uap"], out["desc_simple_ap"] = np.float64(ap.ap), np.float64(ap.simple_ap)
+        out["desc_cand_q"] = np.array([str(c.query_id) for c in cands])
+        out["desc_cand_r"] = np.array([str(c.ref_id) for c in cands])
+        out["desc_cand_s"] = np.array([c.score for c in cands], dtype=np.float32)
+        # 2. the matching baseline with score normalisation (vsc/baseline/sscd_baseline.py:185-231)
+        outdir = os.path.join(tmp, "out")
+        args = ref_sscd.parser.parse_args(["--query_features", qp, "--ref_features", rp, "--score_norm_features", npth,
+                                           "--output_path", outdir, "--ground_truth", gtp])
+        ref_sscd.main(args)
+        sn_cands = CandidatePair.read_csv(os.path.join(outdir, "candidates.csv"))
+        matches = Match.read_csv(os.path.join(outdir, "matches.csv"))
+        out["sn_cand_q"] = np.array([str(c.query_id) for c in sn_cands])
+        out["sn_cand_r"] = np.array([str(c.ref_id) for c in sn_cands])
+        out["sn_cand_s"] = np.array([c.score for c in sn_cands], dtype=np.float64)
+        for k, v in match_rows(matches).items():
+            out["sn_match_" + k] = v
+        gt_pairs = CandidatePair.from_matches(Match.read_csv(gtp, is_gt=True))
+        out["sn_uap"] = np.float64(average_precision(gt_pairs, sn_cands).ap)
+        out["sn_segment_ap"] = np.float64(evaluate_matching_track(gtp, os.path.join(outdir, "matches.csv")).segment_ap.ap)
+        # a sample of the score-normalised descriptors the reference stored (every 20th row)
+        for tag, ds in (("sn_queries", Dataset.QUERIES), ("sn_refs", Dataset.REFS)):
+            feats = np.concatenate([v.feature for v in load_features(os.path.join(outdir, tag + ".npz"), ds)])
+            out[tag + "_shape"] = np.array(feats.shape, dtype=np.int64)
+            out[tag + "_sample"] = feats[::20].astype(np.float32)
+        out["files"] = np.array(sorted(os.listdir(outdir)))
+    return "g8_config1_pipeline", out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--check", action="store_true")
     args = ap.parse_args()
     os.makedirs(GOLDEN, exist_ok=True)
-    fixtures = [gen_g1()] + gen_g2() + [gen_g3(), gen_g4()] + gen_g5() + [gen_g6(), gen_g7()]
+    fixtures = [gen_g1()] + gen_g2() + [gen_g3(), gen_g4()] + gen_g5() + [gen_g6(), gen_g7(), gen_g8()]
     bad = 0
     for name, arrays in fixtures:
         path = os.path.join(GOLDEN, name + ".npz")

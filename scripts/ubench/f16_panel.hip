@@ -417,9 +417,10 @@ int main(int argc, char** argv) {
     hipLaunchKernelGGL(to_fragment_major, dim3(8192), dim3(256), 0, 0, Rn, nr_pad, d, Rf);
     CK(hipDeviceSynchronize());
 
-    const bool pmc = argc > 3;  // profiling mode: only the panel kernel (PF=4), no candidates then bench-like density
+    const bool pmc = argc > 3 && argv[3][0] == 'p';
+    const bool one = argc > 3 && argv[3][0] == 'o';  // one <radius> <slice>: a single configuration  // profiling mode: only the panel kernel (PF=4), no candidates then bench-like density
     // ---- MFMA-only ceilings
-    if (!pmc) {
+    if (!pmc && !one) {
         float* out;
         CK(hipMalloc(&out, 256 * 512 * 4));
         hipEvent_t e0, e1;
@@ -459,6 +460,13 @@ int main(int argc, char** argv) {
     CK(hipMalloc(&a.ts, grid * 16 * 8));
     CK(hipMemset(a.ts, 0, grid * 16 * 8));
 
+    if (one) {
+        a.radius = atof(argv[4]);
+        a.slice = atoi(argv[5]);
+        run_panel<8, true>("panel PF=8 steal", a, grid, 3);
+        run_panel<8, false>("panel PF=8 static", a, grid, 3);
+        return 0;
+    }
     if (pmc) {
         a.radius = 0.165f;
         run_panel<8, true>("panel PF=8 steal density 1e-4", a, grid, 2);

@@ -35,3 +35,29 @@ def flatten_pairmatches(pms):
     return (np.array([str(pm.query_id) for pm in pms]), np.array([str(pm.ref_id) for pm in pms]),
             np.array([len(pm.matches) for pm in pms], dtype=np.int64),
             np.array(rows, dtype=np.float64).reshape(-1, 5), np.array([r[4] for r in rows], dtype=np.float32))
+
+
+# ---- fixture g8 (BASELINE configs[0] shape): inputs are regenerated from the seed, the fixture holds their digest
+G8 = dict(seed=80, n_query=50, n_ref=50, dim=512, q_frames=(20, 20), r_frames=(20, 20), planted_frac=0.2, noise=0.05,
+          copy_len=(8, 20))
+G8_NOISE = dict(seed=81, n_videos=30, frames=(20, 20))
+
+
+def g8_inputs():
+    """(queries, refs, noise, gts) exactly as oracle/gen_golden.py:g8_inputs builds them."""
+    import hashlib
+
+    from vsc2022_amd import synth
+
+    q, r, gts = synth.make_dataset(**G8)
+    noise = synth.make_videos(np.random.default_rng(G8_NOISE["seed"]), G8_NOISE["n_videos"], G8["dim"],
+                              G8_NOISE["frames"], "R")
+    for k, v in enumerate(noise):
+        v.video_id = f"R{900000 + k:06d}"
+    h = hashlib.sha256()
+    for vids in (q, r, noise):
+        for v in vids:
+            h.update(str(v.video_id).encode())
+            h.update(np.ascontiguousarray(v.feature, dtype=np.float32).tobytes())
+            h.update(np.ascontiguousarray(v.timestamps, dtype=np.float32).tobytes())
+    return q, r, noise, gts, h.hexdigest()

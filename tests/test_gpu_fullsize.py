@@ -80,3 +80,47 @@ def test_fullsize_pipeline_finds_the_planted_copies(fullsize):
         for b in range(nbox[p]):
             x1, y1, x2, y2 = boxes[p, b]
             assert 0 <= x1 < x2 < qf and 0 <= y1 < y2 < rf
+
+
+def test_fullsize_knn_properties(fullsize, orc):
+    """Brute-force cosine k-NN at BASELINE configs[1]'s literal shape (200k x 2M x 512, k = 1 and 20) through the
+    faiss-like surface (`index.search(x, k)`, vsc/index.py:167-177, vsc/baseline/score_normalization.py:96):
+    per-row order, completeness and scores on sampled rows against the oracle, k = 1 == first column of k = 20,
+    idempotence."""
+    import torch
+
+    m, queries, refs, gt, (n_qv, qf, n_rv, rf, dim) = fullsize
+    nq, nr = n_qv * qf, n_rv * rf
+    D20, I20 = m.index.search(queries, 20)
+    assert D20.shape == (nq, 20) and I20.shape == (nq, 20)
+    assert np.all(D20[:, :-1] >= D20[:, 1:])
+    tie = D20[:, :-1] == D20[:, 1:]
+    assert np.all(I20[:, :-1][tie] < I20[:, 1:][tie])          # ties: lower reference row first
+    assert I20.min() >= 0 and I20.max() < nr
+    srt = np.sort(I20, axis=1)
+    assert np.all(srt[:, :-1] != srt[:, 1:])                    # no reference twice in a row's list
+    D1, I1 = m.index.search(queries, 1)
+    assert np.array_equal(D1[:, 0].view(np.uint32), D20[:, 0].view(np.uint32)) and np.array_equal(I1[:, 0], I20[:, 0])
+    # sampled rows: every listed score is the oracle's fp32 chain bit for bit, and nothing in a 200k-row slice of
+    # the references beats a row's 20th score without being listed
+    rng = np.random.default_rng(3)
+    rows = rng.choice(nq, 16, replace=False)
+    qs = queries[torch.from_numpy(rows).long().to(queries.device)].cpu().numpy()
+    lo = int(rng.integers(0, nr - 200000))
+    sub = orc.scores(qs, refs[lo : lo + 200000].cpu().numpy())
+    for a, row in enumerate(rows):
+        listed = refs[torch.from_numpy(I20[row]).long().to(refs.device)].cpu().numpy()
+        exact = np.array([orc.scores(qs[a : a + 1], listed[b : b + 1])[0, 0] for b in range(20)], dtype=np.float32)
+        assert np.array_equal(exact.view(np.uint32), D20[row].view(np.uint32)), row
+        better = np.nonzero(sub[a] > D20[row, -1])[0] + lo
+        assert set(better.tolist()) <= set(I20[row].tolist()), row
+        equal = np.nonzero(sub[a] == D20[row, -1])[0] + lo       # ties with the 20th: only lower ids may be listed before it
+        assert all(int(e) in set(I20[row].tolist()) or e > I20[row, -1] for e in equal)
+    # planted copies: the copied frames find their source video
+    row2r = np.repeat(np.arange(n_rv), rf)
+    planted = dict(gt)
+    hit = sum(1 for qv, rv in planted.items() if rv in set(row2r[I1[qv * qf : (qv + 1) * qf, 0]].tolist()))
+    assert hit >= 0.99 * len(planted)
+    # idempotence
+    D20b, I20b = m.index.search(queries, 20)
+    assert np.array_equal(D20b.view(np.uint32), D20.view(np.uint32)) and np.array_equal(I20b, I20)

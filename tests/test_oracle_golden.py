@@ -123,3 +123,23 @@ def test_score_norm_algebra(orc):
         D, _ = orc.knn(q, n, 1)
         assert np.allclose(fx[f"{tag}_q"][:, -1], -beta * D[:, 0], atol=2e-6)
         assert np.all(fx[f"{tag}_r"][:, -1] == 1.0)
+
+
+def test_oracle_reproduces_config1_descriptor_track(orc):
+    """Fixture g8 (the reference's evaluate_descriptor_track on BASELINE configs[0]'s shape): the C oracle's
+    search + pair-max gives the same 1250 candidates, scores bit for bit."""
+    from helpers import g8_inputs
+
+    fx = load("g8_config1_pipeline")
+    q, r, noise, gts, digest = g8_inputs()
+    assert digest == str(fx["digest"])
+    Q = np.concatenate([v.feature for v in q])
+    R = np.concatenate([v.feature for v in r])
+    row2q = np.repeat(np.arange(len(q), dtype=np.int32), [len(v.feature) for v in q])
+    row2r = np.repeat(np.arange(len(r), dtype=np.int32), [len(v.feature) for v in r])
+    i, j, s = orc.global_threshold_search(Q, R, 1200 * len(q))
+    pq, pr, ps, _ = orc.pair_max(i, j, s, row2q, row2r)
+    n = 25 * len(q)
+    assert [q[k].video_id for k in pq[:n]] == list(fx["desc_cand_q"])
+    assert [r[k].video_id for k in pr[:n]] == list(fx["desc_cand_r"])
+    assert np.array_equal(ps[:n].view(np.uint32), fx["desc_cand_s"].view(np.uint32))
