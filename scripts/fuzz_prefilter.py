@@ -58,9 +58,9 @@ while time.time() < t_end:
     if style == 2 and nr > 20:  # duplicates -> exact ties
         r[rng.integers(0, nr, nr // 5)] = r[int(rng.integers(0, nr))]
         q[rng.integers(0, nq, max(1, nq // 7))] = r[int(rng.integers(0, nr))]
-    if style == 3:  # widely different norms
-        q *= rng.uniform(0.01, 20.0, (nq, 1)).astype(np.float32)
-        r *= rng.uniform(0.01, 20.0, (nr, 1)).astype(np.float32)
+    if style == 3:  # widely different norms, log-uniform from 1e-5 (fp16-subnormal elements) to 20
+        q *= np.exp(rng.uniform(np.log(1e-5), np.log(20.0), (nq, 1))).astype(np.float32)
+        r *= np.exp(rng.uniform(np.log(1e-5), np.log(20.0), (nr, 1))).astype(np.float32)
     if os.environ.get("FUZZ_VERBOSE"):
         print(f"case {n_cases}: d={d} nq={nq} nr={nr} style={style}", flush=True)
     cut = int(rng.integers(0, nr + 1))

@@ -197,3 +197,44 @@ def test_parity_suites_with_forced_prefilter():
                         "tests/test_gpu_edge_cases.py", "tests/test_gpu_golden.py", "tests/test_gpu_sharded.py"],
                        cwd=ROOT, env=env, capture_output=True, text=True, timeout=1200)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+
+
+@pytest.mark.parametrize("case", ["refs_subnormal", "both_subnormal", "mixed_elements", "mixed_rows"])
+def test_fp16_subnormal_rows_next_to_the_radius(gpu, orc, case):
+    """The error bound of the pre-filter (api.hip: c2 = 2^-25 sqrt(D) per unit of norm) assumes GRADUAL underflow
+    in fp16: elements below 6.1e-5 keep an absolute error of 2^-25.  If v_mfma_f32_32x32x16_f16 flushed fp16
+    subnormal inputs to zero the error would be the whole product (2^-14 sqrt(D) per unit of norm) and true hits
+    would be filtered out.  Rows whose elements lie in [6e-8, 6e-5], K chosen so that the radius falls INTO their
+    score range, pre-filter forced on every batch, hits bit-identical to the oracle."""
+    rng = np.random.default_rng(len(case))
+    d, nq, nr = 512, 192, 1500
+    q, r = unit(rng, nq, d), unit(rng, nr, d)
+    tiny = np.float32(3e-4)  # unit-row elements ~ 0.044 -> ~1.3e-5: deep in the fp16 subnormal range
+    if case == "refs_subnormal":
+        r *= tiny
+    elif case == "both_subnormal":
+        q *= tiny
+        r *= tiny
+    elif case == "mixed_elements":
+        r[:, ::2] *= tiny       # every other coordinate subnormal, the rest normal
+        q[:, 1::3] *= tiny
+    else:
+        r[::2] *= tiny          # subnormal and normal rows side by side in every tile
+        q[::3] *= tiny
+    h = r.astype(np.float16)
+    sub = (np.abs(h) < 6.1e-5) & (h != 0)
+    assert sub.mean() > 0.2, sub.mean()
+    K = int(0.3 * nq * nr)      # the K-th best score sits inside the bulk of the (tiny) scores
+    want = orc.global_threshold_search(q, r, K)
+    got = run_topk(q, r, K, "2")
+    assert got[4] > 0           # candidates went through the fp16 stage
+    assert_same(got, want)
+    # and the k-NN through per-row thresholds
+    from vsc2022_amd.vsc.index import FlatIndex
+
+    with prefilter_mode("2"):
+        idx = FlatIndex(d)
+    idx.add(r)
+    D, I = idx.search(q, 7)
+    Do, Io = orc.knn(q, r, 7)
+    assert np.array_equal(I, Io) and np.array_equal(bits(D), bits(Do))
