@@ -13,8 +13,11 @@ multi-GPU: one process per GPU (torchrun), queries sharded (weak scaling: every 
            (vsc2022_amd/dist.py).
 
 Prints ONE JSON line on rank 0 (see the driver contract in the task statement); adds
-"roofline" (the dominant kernel, measured live with HIP events on the engine's stream) and, at
-N=1, "cpu_baseline" (the C oracle on the host cores, bounded sample).
+"roofline" (the dominant kernel, measured live with HIP events on the engine's stream), "kernels"
+(every kernel class of a step: ms, achieved TFLOP/s or GB/s against its peak) and, at N=1,
+"extra" (untimed legs after the headline measurement: the 200k x 2M k-NN of configs[1] as written,
+query-set upload, score normalisation against 2M noise rows, one search on the all-fp32 route) and
+"cpu_baseline" (the C oracle on the host cores, bounded sample).
 """
 import argparse
 import json
@@ -42,6 +45,7 @@ def parse():
     ap.add_argument("--ref-frames", type=int, default=50)
     ap.add_argument("--dim", type=int, default=512)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="skip the untimed k-NN / score-norm / all-fp32 legs")
     ap.add_argument("--seed", type=int, default=1)
     return ap.parse_args()
 
@@ -128,6 +132,109 @@ def cpu_baseline(args):
     }
 
 
+HBM_PEAK_GBS = 8000.0  # same guide: HBM3E peak (6.3 TB/s is what a copy kernel achieves)
+
+
+def _aux(cls):
+    """(ms, calls, bytes) of the process-wide accounting: 0 = pair-max, 1 = Temporal Network."""
+    import ctypes
+
+    from vsc2022_amd import _lib
+
+    ms, n, by = ctypes.c_double(0), ctypes.c_int64(0), ctypes.c_double(0)
+    _lib.check(_lib.lib().vsc_aux_profile_read(cls, ctypes.byref(ms), ctypes.byref(n), ctypes.byref(by), 1))
+    return ms.value, n.value, by.value
+
+
+def _rate(work, ms, scale):
+    return (work / scale) / (ms / 1e3) if ms > 0 else 0.0
+
+
+def extra_legs(args, torch, dev, matcher, queries, n_qv, qf, n_rv, rf, dim):
+    """Untimed legs of the single-GPU run (after the headline measurement, bounded to a few seconds each): every
+    figure DESIGN.md quotes comes from here or from a tracked profile."""
+    import time as _t
+
+    from vsc2022_amd import _lib
+    from vsc2022_amd.engine import DeviceScoreNormalizer
+    from vsc2022_amd.vsc.index import FlatIndex
+
+    out = {}
+    nq, nr = n_qv * qf, n_rv * rf
+    idx = matcher.index
+    # ---- BASELINE configs[1] as written: brute-force cosine k-NN 200k x 2M (index.search, results to the host)
+    knn = {}
+    for k in (20, 1):
+        idx.search(queries[:4096], k)  # warm-up (buffers)
+        idx.profile_read(reset=True)
+        torch.cuda.synchronize()
+        t0 = _t.perf_counter()
+        D, I = idx.search(queries, k)
+        dt = _t.perf_counter() - t0
+        p = idx.profile_read(reset=True)
+        knn[f"k{k}"] = {
+            "ms": 1e3 * dt, "query_rows_per_s": nq / dt, "algorithmic_tflops": 2.0 * nq * nr * dim / dt / 1e12,
+            "kernel_ms": {"exact_fp32_subset_pass": p["sim_ms"], "fp16_prefilter": p["f16_ms"],
+                          "exact_rescore": p["rescore_ms"]},
+            "prefilter_tflops": _rate(p["f16_flops"], p["f16_ms"], 1e12), "candidates": p["candidates"],
+        }
+        del D, I
+    out["knn_200k_x_2M"] = knn
+    # ---- per query set: upload + packing of a fresh query batch (outside the headline's timed region)
+    q_off = np.arange(n_qv + 1, dtype=np.int64) * qf
+    torch.cuda.synchronize()
+    t0 = _t.perf_counter()
+    matcher.set_queries(queries, q_off)
+    torch.cuda.synchronize()
+    out["set_queries_ms"] = 1e3 * (_t.perf_counter() - t0)
+    # ---- score normalisation of this query set against a 2M-row noise set (config 4's extra stage)
+    g = torch.Generator(device=dev)
+    g.manual_seed(args.seed + 77)
+    noise = torch.randn((nr, dim), generator=g, device=dev, dtype=torch.float32)
+    noise /= noise.norm(dim=1, keepdim=True)
+    norm = DeviceScoreNormalizer(noise, beta=1.2)
+    del noise
+    norm.queries(queries[:4096])
+    torch.cuda.synchronize()
+    t0 = _t.perf_counter()
+    qn = norm.queries(queries)
+    torch.cuda.synchronize()
+    out["score_normalize_queries_ms"] = 1e3 * (_t.perf_counter() - t0)
+    out["score_normalize_note"] = (f"{nq} query rows: drop the low-variance dim, row-L2, 1-NN against {nr} noise rows "
+                                   "(pre-filtered exact k-NN), beta 1.2; noise index resident")
+    del qn, norm
+    torch.cuda.empty_cache()
+    # ---- the all-fp32 route (VSC_PREFILTER=0): one search of the same shape on the exact fp32 MFMA kernel alone
+    old = os.environ.get("VSC_PREFILTER")
+    os.environ["VSC_PREFILTER"] = "0"
+    try:
+        exact = FlatIndex(dim, _lib.METRIC_INNER_PRODUCT, dev.index)
+    finally:
+        if old is None:
+            os.environ.pop("VSC_PREFILTER", None)
+        else:
+            os.environ["VSC_PREFILTER"] = old
+    exact.add(matcher.ref_feats)
+    exact.profile(True)
+    exact.profile_read(reset=True)
+    torch.cuda.synchronize()
+    t0 = _t.perf_counter()
+    hits = exact.global_topk(queries, 1200 * n_qv, device_out=True)
+    torch.cuda.synchronize()
+    dt = _t.perf_counter() - t0
+    p = exact.profile_read(reset=True)
+    ach = _rate(p["sim_flops"], p["sim_ms"], 1e12)
+    out["roofline_fp32_route"] = {
+        "kernel": "sim_thresh_kernel (fp32 MFMA 32x32x2 similarity + fused threshold compaction), VSC_PREFILTER=0",
+        "bound": "mfma", "achieved": ach, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+        "frac": ach / FP32_MFMA_PEAK_TFLOPS, "launches": p["sim_launches"], "kernel_ms": p["sim_ms"],
+        "search_ms": 1e3 * dt, "hits": int(hits[2].numel()),
+    }
+    del exact, hits
+    torch.cuda.empty_cache()
+    return out
+
+
 def main():
     args = parse()
     import torch
@@ -151,7 +258,18 @@ def main():
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        # self-check of the process group before any work: every rank must see `world` ranks of the expected
+        # backend, one per device (a mis-launched job would otherwise time collectives out minutes later)
+        assert dist.get_world_size() == world and dist.get_rank() == rank
+        seen = torch.zeros(world, dtype=torch.int64, device="cpu" if share_gpu else dev)
+        seen[rank] = 1 + local_rank
+        dist.all_reduce(seen)
+        assert int((seen > 0).sum()) == world, f"rank {rank}: only {int((seen > 0).sum())} of {world} ranks answered"
+        if not share_gpu:
+            assert dist.get_backend() == "nccl" and len(set(seen.tolist())) == world, \
+                f"ranks do not sit on distinct devices of this node: {seen.tolist()}"
 
+    from vsc2022_amd import _lib
     from vsc2022_amd.engine import DeviceMatcher
 
     n_qv, qf, n_rv, rf, dim = args.query_videos, args.query_frames, args.ref_videos, args.ref_frames, args.dim
@@ -176,6 +294,8 @@ def main():
         res = matcher.match(**kw)
     matcher.index.profile(True)
     matcher.index.profile_read(reset=True)
+    _lib.check(_lib.lib().vsc_aux_profile(1))
+    _aux(0), _aux(1)
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -183,21 +303,37 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     prof = matcher.index.profile_read(reset=True)
+    pm_ms, pm_calls, pm_bytes = _aux(0)
+    tn_ms, tn_calls, tn_bytes = _aux(1)
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device="cpu" if share_gpu else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+        # every rank must hold the same global candidate table (the sharded merge is deterministic)
+        h = torch.stack([res.cand_q.to(torch.int64).sum(), res.cand_r.to(torch.int64).sum(),
+                         res.cand_score.contiguous().view(torch.int32).to(torch.int64).sum()])
+        hs = [torch.zeros_like(h) for _ in range(world)] if not share_gpu else None
+        if share_gpu:
+            hc = h.cpu()
+            hs = [torch.zeros_like(hc) for _ in range(world)]
+            dist.all_gather(hs, hc)
+        else:
+            dist.all_gather(hs, h)
+        assert all(torch.equal(x, hs[0]) for x in hs), "candidate tables differ between ranks"
     if rank == 0:
-        # HBM bytes per launch of the dominant kernel come from the committed PMC passes
+        # HBM-side bytes per launch of the dominant kernel come from the committed PMC passes
         # (FETCH_SIZE / WRITE_SIZE cannot be sampled from inside the process)
-        traffic = None
-        try:
-            with open(os.path.join(ROOT, "profiles", "r01_roofline.json")) as fh:
-                traffic = float(json.load(fh)["hbm_bytes_per_launch"])
-        except Exception:
-            traffic = None
+        traffic, traffic_src = None, None
+        for name in ("r02_roofline.json", "r01_roofline.json"):
+            try:
+                with open(os.path.join(ROOT, "profiles", name)) as fh:
+                    traffic = float(json.load(fh)["hbm_bytes_per_launch"])
+                traffic_src = "profiles/" + name
+                break
+            except Exception:
+                continue
         total_videos = n_qv * world * args.steps
-        # Dominant kernel: the fp16 pre-filter GEMM (csrc/sim_f16.hip) when the engine uses it, else
+        # Dominant kernel: the fp16 pre-filter GEMM (csrc/sim_f16p.hip) when the engine uses it, else
         # the exact fp32 similarity kernel.  achieved = algorithmic flops (2 * rows * refs * dim of the
         # launches) / their HIP-event time on the engine's stream.
         use_f16 = prof.get("f16_ms", 0.0) > prof["sim_ms"]
@@ -205,6 +341,38 @@ def main():
                                      else (prof["sim_ms"], prof["sim_flops"], prof["sim_launches"]))
         peak = FP16_MFMA_PEAK_TFLOPS if use_f16 else FP32_MFMA_PEAK_TFLOPS
         achieved = (k_flops / 1e12) / (k_ms / 1e3) if k_ms > 0 else 0.0
+        steps = args.steps
+        dpad_bytes = 8 * ((dim + 63) // 64 * 64)  # two packed fp32 rows per re-scored candidate
+        cand = prof.get("candidates", 0)
+        kernels = {
+            "sim_f16p_kernel (fp16 MFMA pre-filter)": {
+                "ms_per_step": prof.get("f16_ms", 0.0) / steps, "achieved": _rate(prof.get("f16_flops", 0.0), prof.get("f16_ms", 0.0), 1e12),
+                "peak": FP16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "bound": "mfma"},
+            "sim_thresh_kernel (exact fp32 MFMA, dense early batches)": {
+                "ms_per_step": prof["sim_ms"] / steps, "achieved": _rate(prof["sim_flops"], prof["sim_ms"], 1e12),
+                "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "bound": "mfma"},
+            "rescore_kernel (exact fp32 chain of the candidates)": {
+                "ms_per_step": prof.get("rescore_ms", 0.0) / steps,
+                "achieved": _rate(float(cand) * dpad_bytes * steps, prof.get("rescore_ms", 0.0), 1e9),
+                "peak": HBM_PEAK_GBS, "unit": "GB/s", "bound": "hbm",
+                "note": f"{cand} candidates of the last search x {dpad_bytes} B (two fp32 rows each)"},
+            "select_* (radix select + compaction of the re-thresholds)": {
+                "ms_per_step": prof.get("select_ms", 0.0) / steps, "launch_groups_per_step": prof.get("select_launches", 0) / steps},
+            "final ordering of the kept hits (radix sorts)": {
+                "ms_per_step": prof.get("sort_ms", 0.0) / steps,
+                "achieved": _rate(prof.get("sort_flops", 0.0), prof.get("sort_ms", 0.0), 1e9), "peak": HBM_PEAK_GBS,
+                "unit": "GB/s", "bound": "hbm", "note": "algorithmic bytes = 12 B per kept hit in; ~20 passes inside"},
+            "pair_max (sort by pair + segmented max + rank sort)": {
+                "ms_per_step": pm_ms / steps, "achieved": _rate(pm_bytes, pm_ms, 1e9), "peak": HBM_PEAK_GBS,
+                "unit": "GB/s", "bound": "hbm"},
+            "tn_pair_kernel (Temporal Network, one pair per wavefront)": {
+                "ms_per_step": tn_ms / steps, "achieved": _rate(tn_bytes, tn_ms, 1e9), "peak": HBM_PEAK_GBS,
+                "unit": "GB/s", "bound": "hbm (latency-bound in practice)",
+                "note": "algorithmic bytes = 4 * dim * (Lq + Lr) per pair + boxes"},
+        }
+        for v in kernels.values():
+            if "achieved" in v and v.get("peak"):
+                v["frac"] = v["achieved"] / v["peak"]
         out = {
             "metric": "query-videos localized/sec @ 512-d SSCD",
             "value": total_videos / dt,
@@ -216,7 +384,7 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "fp32",
+            "dtype": "fp32 results; fp16 MFMA pre-filter",
             "dtype_note": "every reported score is the exact fp32 fma chain (bit-identical to the all-fp32 "
                           "path); fp16 MFMA only pre-filters pairs, with a rigorous error bound",
             "data": "synthetic",
@@ -229,31 +397,29 @@ def main():
                 "parallelism": f"query-sharded x{world}" if world > 1 else "single GPU",
             },
             "roofline": {
-                "kernel": ("sim_f16_kernel (fp16 MFMA pre-filter of the thresholded search; exact fp32 "
-                           "re-scoring of its candidates follows)") if use_f16 else
+                "kernel": ("sim_f16p_kernel (panel-stationary fp16 MFMA pre-filter of the thresholded search; exact "
+                           "fp32 re-scoring of its candidates follows)") if use_f16 else
                           "sim_thresh_kernel (fp32 MFMA similarity + fused threshold compaction)",
                 "bound": "mfma",
                 "achieved": achieved,
                 "peak": peak,
                 "unit": "TFLOP/s",
                 "frac": achieved / peak,
-                # what the matrix pipes sustain on this part with everything but the MFMAs compiled out of the
-                # same kernel (the clock drops under matrix load): profiles/r01_ablation_sim_f16.md
-                "peak_sustained_measured": 1625.0 if use_f16 else 155.0,
-                "frac_of_sustained": achieved / (1625.0 if use_f16 else 155.0),
                 "traffic": traffic,
-                "traffic_unit": "bytes/launch (PMC FETCH_SIZE x2 + WRITE_SIZE, profiles/r01_pmc_prefilter.md)",
+                "traffic_unit": f"bytes/launch (PMC FETCH_SIZE x2 + WRITE_SIZE, {traffic_src})",
                 "launches": k_launches,
                 "kernel_ms_per_step": k_ms / args.steps,
-                "other_kernels_ms_per_step": {
-                    "exact_fp32_similarity": prof["sim_ms"] / args.steps if use_f16 else 0.0,
-                    "exact_rescore_of_candidates": prof.get("rescore_ms", 0.0) / args.steps,
-                },
-                "prefilter_candidates_last_search": prof.get("candidates", 0),
+                "prefilter_candidates_last_search": cand,
             },
+            "kernels": kernels,
         }
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args)
+        if world == 1:
+            if not args.no_extra:
+                out["extra"] = extra_legs(args, torch, dev, matcher, queries, n_qv, qf, n_rv, rf, dim)
+                ms_fresh = out["ms_per_step"] + out["extra"]["set_queries_ms"]
+                out["extra"]["value_with_fresh_query_set"] = n_qv / (ms_fresh / 1e3)
+            if not args.no_cpu_baseline:
+                out["cpu_baseline"] = cpu_baseline(args)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

@@ -191,9 +191,17 @@ int vsc_index_profile_read(vsc_index_t* idx, double* sim_ms, int64_t* sim_launch
                            int reset);
 /* Same accounting per kernel class: 0 = exact fp32 similarity kernels (what vsc_index_profile_read
  * reports), 1 = fp16 pre-filter GEMM (work = algorithmic flops 2*nq*nr*dim), 2 = exact re-scoring of
- * the pre-filter's candidates (work unused). */
+ * the pre-filter's candidates (work unused), 3 = re-threshold kernels of the search schedule (radix select +
+ * compaction; work unused), 4 = final ordering of the kept hits (work = bytes of the hit triples read). */
 int vsc_index_profile_read_class(vsc_index_t* idx, int cls, double* ms, int64_t* launches, double* work,
                                  int reset);
+/* Process-wide accounting of the entry points that own no index handle, same method (HIP events on the
+ * stream the kernels run on): cls 0 = vsc_pair_max (vsc/candidates.py:24-40 on device hits), cls 1 = the
+ * Temporal-Network launches of vsc_tn_localize / vsc_tn_forward_sim (vcsl.vta TN.forward_sim).
+ * bytes = algorithmic bytes of the calls (4*dim*(Lq+Lr) per pair + boxes; 12 B per hit
+ * + 20 B per pair).  bench.py only. */
+int vsc_aux_profile(int enable);
+int vsc_aux_profile_read(int cls, double* ms, int64_t* calls, double* bytes, int reset);
 /* Counters of the last thresholded search on this handle: pairs the fp16 pre-filter passed on to
  * the exact stage, and (reserved) hits. */
 int vsc_index_search_stats(vsc_index_t* idx, int64_t* candidates, int64_t* hits);

@@ -137,13 +137,14 @@ struct vsc_index {
     Workspace ws;
     int64_t hit_cap_user = 0;
     // kernel-time accounting (HIP events on the handle's stream), per kernel class:
-    // 0 = exact fp32 similarity kernels, 1 = fp16 pre-filter, 2 = exact re-scoring of candidates
+    // 0 = exact fp32 similarity kernels, 1 = fp16 pre-filter, 2 = exact re-scoring of candidates,
+    // 3 = re-threshold (radix select + compaction) kernels, 4 = final ordering of the kept hits
     bool prof = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
     std::vector<int> ev_class;
     size_t ev_used = 0;
-    double prof_ms[3] = {0, 0, 0}, prof_work[3] = {0, 0, 0}, pending_work[3] = {0, 0, 0};
-    int64_t prof_launches[3] = {0, 0, 0};
+    double prof_ms[5] = {}, prof_work[5] = {}, pending_work[5] = {};
+    int64_t prof_launches[5] = {};
 };
 
 static int prof_begin(vsc_index* idx, hipEvent_t* stop_out, int cls = 0) {
@@ -177,7 +178,7 @@ static int prof_collect(vsc_index* idx) {
         idx->prof_ms[idx->ev_class[e]] += ms;
         idx->prof_launches[idx->ev_class[e]] += 1;
     }
-    for (int c = 0; c < 3; ++c) {
+    for (int c = 0; c < 5; ++c) {
         idx->prof_work[c] += idx->pending_work[c];
         idx->pending_work[c] = 0.0;
     }
@@ -185,7 +186,58 @@ static int prof_collect(vsc_index* idx) {
     return VSC_OK;
 }
 
+// Process-wide kernel-time accounting of the entry points that own no index handle (HIP events on the stream
+// the kernels run on; read after the call's own stream sync): 0 = vsc_pair_max, 1 = Temporal-Network launches.
+struct AuxProf {
+    bool on = false;
+    std::mutex mu;
+    double ms[2] = {}, bytes[2] = {};
+    int64_t n[2] = {};
+};
+static AuxProf g_aux;
+struct AuxTimer {
+    hipEvent_t a = nullptr, b = nullptr;
+    int cls = 0;
+    double bytes = 0.0;
+    void begin(int c, hipStream_t s) {
+        cls = c;
+        if (!g_aux.on) return;
+        if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) { a = b = nullptr; return; }
+        (void)hipEventRecord(a, s);
+    }
+    void end(double by, hipStream_t s) {
+        if (a && b) { (void)hipEventRecord(b, s); bytes += by; }
+    }
+    void collect() {  // after the stream has been synchronised
+        if (!a || !b) return;
+        float t = 0.0f;
+        if (hipEventElapsedTime(&t, a, b) == hipSuccess) {
+            std::lock_guard<std::mutex> lk(g_aux.mu);
+            g_aux.ms[cls] += t;
+            g_aux.bytes[cls] += bytes;
+            g_aux.n[cls] += 1;
+        }
+        (void)hipEventDestroy(a);
+        (void)hipEventDestroy(b);
+        a = b = nullptr;
+    }
+};
+
 extern "C" {
+
+int vsc_aux_profile(int enable) {
+    g_aux.on = enable != 0;
+    return VSC_OK;
+}
+int vsc_aux_profile_read(int cls, double* ms, int64_t* calls, double* bytes, int reset) {
+    if (cls < 0 || cls > 1) return VSC_ERR_INVALID;
+    std::lock_guard<std::mutex> lk(g_aux.mu);
+    if (ms) *ms = g_aux.ms[cls];
+    if (calls) *calls = g_aux.n[cls];
+    if (bytes) *bytes = g_aux.bytes[cls];
+    if (reset) { g_aux.ms[cls] = 0.0; g_aux.bytes[cls] = 0.0; g_aux.n[cls] = 0; }
+    return VSC_OK;
+}
 
 const char* vsc_last_error(void) { return g_err.c_str(); }
 int vsc_version(void) { return 100; }
@@ -584,10 +636,13 @@ int vsc_index_global_topk(vsc_index_t* idx, const float* q, int64_t nq, int q_me
             const bool f16 = idx->prefilter_force ||
                              (idx->prefilter && i0 > 0 && (double)K < idx->prefilter_density * (double)i0 * (double)idx->ntotal);
             VSC_TRY(enqueue_batch(idx, qp, i0, i1, cap, f16));
+            hipEvent_t stop;
+            VSC_TRY(prof_begin(idx, &stop, 3));
             VSC_TRY(enqueue_rethreshold(ctl, idx->ws.hA[0].as<int32_t>(), idx->ws.hA[1].as<int32_t>(),
                                         idx->ws.hA[2].as<float>(), idx->ws.hB[0].as<int32_t>(),
                                         idx->ws.hB[1].as<int32_t>(), idx->ws.hB[2].as<float>(),
                                         (unsigned long long)K, idx->stream));
+            VSC_TRY(prof_end(idx, stop, 0.0, 3));
             if (bs < 20000) bs *= 2;
             i0 = i1;
         }
@@ -624,15 +679,19 @@ int vsc_index_global_topk(vsc_index_t* idx, const float* q, int64_t nq, int q_me
         ds = idx->ws.out[2].as<float>();
     }
     int64_t mm = 0;
+    hipEvent_t sort_stop;
+    VSC_TRY(prof_begin(idx, &sort_stop, 4));
     VSC_TRY(sort_hits_topk(idx->ws.hA[0].as<int32_t>(), idx->ws.hA[1].as<int32_t>(), idx->ws.hA[2].as<float>(),
                            n, K, nq, idx->ws.w0, idx->ws.w1, idx->ws.w2, idx->ws.w3, idx->ws.tmp, di, dj, ds,
                            ip ? 0 : 1, &mm, idx->stream));
+    VSC_TRY(prof_end(idx, sort_stop, 12.0 * (double)n, 4));  // (row, ref, score) of every kept hit in
     if (out_mem == VSC_MEM_HOST && mm > 0) {
         VSC_HIP(hipMemcpyAsync(out_i, di, (size_t)mm * 4, hipMemcpyDeviceToHost, idx->stream));
         VSC_HIP(hipMemcpyAsync(out_j, dj, (size_t)mm * 4, hipMemcpyDeviceToHost, idx->stream));
         VSC_HIP(hipMemcpyAsync(out_s, ds, (size_t)mm * 4, hipMemcpyDeviceToHost, idx->stream));
     }
     VSC_HIP(hipStreamSynchronize(idx->stream));
+    VSC_TRY(prof_collect(idx));
     *n_out = mm;
     return VSC_OK;
 }
@@ -890,7 +949,7 @@ int vsc_index_profile(vsc_index_t* idx, int enable) {
 
 int vsc_index_profile_read_class(vsc_index_t* idx, int cls, double* ms, int64_t* launches, double* work,
                                  int reset) {
-    if (!idx || cls < 0 || cls > 2) return VSC_ERR_INVALID;
+    if (!idx || cls < 0 || cls > 4) return VSC_ERR_INVALID;
     if (ms) *ms = idx->prof_ms[cls];
     if (launches) *launches = idx->prof_launches[cls];
     if (work) *work = idx->prof_work[cls];
@@ -989,9 +1048,12 @@ int vsc_pair_max(const int32_t* hit_i, const int32_t* hit_j, const float* hit_s,
         of = ws.out[3].as<int64_t>();
     }
     int64_t np = 0;
+    AuxTimer tm;
+    tm.begin(0, c->stream);
     VSC_TRY(pair_max_device((const int32_t*)di, (const int32_t*)dj, (const float*)ds, n, (const int32_t*)dq,
                             (const int32_t*)dr, 0, ws.w0, ws.w1, ws.w2, ws.w3, ws.tmp, ws.cnt, oq, orr, os, of,
                             ocap, &np, c->stream));
+    tm.end(12.0 * (double)n + 20.0 * (double)np, c->stream);  // hits in, (q, r, score, first hit) per pair out
     *n_pairs = np;
     if (out_mem == VSC_MEM_HOST) {
         if (np > cap) {
@@ -1004,6 +1066,7 @@ int vsc_pair_max(const int32_t* hit_i, const int32_t* hit_j, const float* hit_s,
         if (out_first) VSC_HIP(hipMemcpyAsync(out_first, of, (size_t)np * 8, hipMemcpyDeviceToHost, c->stream));
     }
     VSC_HIP(hipStreamSynchronize(c->stream));
+    tm.collect();
     return VSC_OK;
 }
 
@@ -1093,8 +1156,20 @@ static int tn_run_buckets(TnPairArgs base, const std::vector<int32_t>& lqs, cons
         a.lds_tile_floats = tile_floats;
         a.slab = slab.as<float>();
         a.slab_floats = slab_floats;
+        // algorithmic bytes of the launch: the descriptor rows of every pair once (fused) or its matrix (forward_sim),
+        // + the boxes out
+        double bytes = 0.0;
+        for (int32_t p : B.work) {
+            const double lq = lqs[(size_t)p], lr = lrs[(size_t)p];
+            bytes += fused ? 4.0 * base.dpad * (lq + lr) : 4.0 * lq * lr;
+            bytes += 4.0 + 20.0 * VSC_TN_MAX_BOXES;
+        }
+        AuxTimer tm;
+        tm.begin(1, stream);
         VSC_TRY(launch_tn_pairs(a, lds, stream));
+        tm.end(bytes, stream);
         VSC_HIP(hipStreamSynchronize(stream));  // B.work (host) and the slab are reused
+        tm.collect();
         woff += (int64_t)B.work.size();
     }
     return VSC_OK;

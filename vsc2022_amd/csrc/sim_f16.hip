@@ -453,13 +453,12 @@ int sim_f16_grid(int tq, int tr) {
 }
 
 int launch_sim_f16(const SimF16Args& a, hipStream_t stream) {
-    static bool attr_done = false;
-    if (!attr_done) {
+    static PerDeviceOnce once;
+    if (once.first()) {
         VSC_HIP(hipFuncSetAttribute((const void*)sim_f16_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                     f16::LDS_BYTES));
         VSC_HIP(hipFuncSetAttribute((const void*)sim_f16_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                     f16::LDS_BYTES));
-        attr_done = true;
     }
     if ((int64_t)a.tq * a.tr >= 0x7fffffffLL) {
         set_error("sim_f16: more than 2^31 output tiles in one launch");

@@ -317,14 +317,10 @@ void sim_f16p_plan(int64_t nq, int64_t nr, int* npanel, int* nsteps, int* slice,
 template <int NKC>
 static int launch_nkc(const SimF16PArgs& a, int grid, hipStream_t stream) {
     const int lds = NKC * 32768;
-    // (per device, not per process: a handle on a second device needs its own attribute)
-    static bool attr_done[64] = {};
-    int dev = 0;
-    VSC_HIP(hipGetDevice(&dev));
-    if (dev < 0 || dev >= 64 || !attr_done[dev]) {
+    static PerDeviceOnce once;
+    if (once.first()) {
         VSC_HIP(hipFuncSetAttribute((const void*)sim_f16p_kernel<NKC, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         VSC_HIP(hipFuncSetAttribute((const void*)sim_f16p_kernel<NKC, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        if (dev >= 0 && dev < 64) attr_done[dev] = true;
     }
     if (a.row_thr)
         hipLaunchKernelGGL((sim_f16p_kernel<NKC, true>), dim3((unsigned)grid), dim3(512), lds, stream, a);

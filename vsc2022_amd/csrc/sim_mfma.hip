@@ -563,12 +563,11 @@ int launch_sim_knn(const SimKnnArgs& a, hipStream_t stream) {
     const int64_t grid = (int64_t)a.tq * a.nchunk;
     if (grid <= 0) return VSC_OK;
     const size_t lds = knn_lds_bytes(a.k);
-    static bool attr_set = false;
-    if (!attr_set) {
+    static PerDeviceOnce once;
+    if (once.first()) {
         // the kernel also owns a few hundred bytes of static LDS (__syncthreads_or)
         VSC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(sim_knn_kernel),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024));
-        attr_set = true;
     }
     hipLaunchKernelGGL(sim_knn_kernel, dim3((unsigned)grid), dim3(256), lds, stream, a);
     VSC_HIP(hipGetLastError());
@@ -583,11 +582,10 @@ int launch_knn_merge(const KnnMergeArgs& a, hipStream_t stream) {
 }
 
 int set_thresh_kernel_attrs() {
-    static bool done = false;
-    if (!done) {
+    static PerDeviceOnce once;
+    if (once.first()) {
         VSC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(sim_thresh_kernel),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS));
-        done = true;
     }
     return VSC_OK;
 }

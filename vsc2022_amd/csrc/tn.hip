@@ -526,11 +526,10 @@ size_t tn_state_bytes_host(int max_lq, int top_cap, int ms) {
 
 int launch_tn_pairs(const TnPairArgs& a, size_t lds_bytes, hipStream_t stream) {
     if (a.n_work <= 0) return VSC_OK;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static PerDeviceOnce once;
+    if (once.first()) {
         VSC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(tn_pair_kernel),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024));
-        attr_set = true;
     }
     hipLaunchKernelGGL(tn_pair_kernel, dim3((unsigned)a.n_work), dim3(64), lds_bytes, stream, a);
     VSC_HIP(hipGetLastError());

@@ -73,6 +73,19 @@ __host__ __device__ inline float key2f(uint32_t k) {
 // instead of passing on zero-filled fresh pages (tests/test_gpu_smoke.py).  Defined in api.hip.
 bool poison_mode();
 
+// Kernel attributes (the > 64 KiB dynamic-LDS opt-in) are per DEVICE, not per process: a process that creates
+// handles on a second device must set them there too.  true exactly once per (call site, current device).
+struct PerDeviceOnce {
+    bool done[64] = {};
+    bool first() {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return true;  // unknown device: always set
+        if (done[dev]) return false;
+        done[dev] = true;
+        return true;
+    }
+};
+
 // growable device buffer
 struct DevBuf {
     void* p = nullptr;
