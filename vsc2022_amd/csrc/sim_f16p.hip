@@ -32,7 +32,12 @@ namespace f16p {
 
 constexpr int PR = F16P_PANEL_ROWS;  // 128
 constexpr int CSW = F16P_COL_STEP;   // 512
-constexpr int PF = 8;                // register ring: k-steps (7 in flight = 14 KiB per wave)
+#ifndef VSC_F16P_PF
+#define VSC_F16P_PF 4
+#endif
+constexpr int PF = VSC_F16P_PF;      // register ring: k-steps (PF - 1 in flight, 2 KiB each per wave).  Measured in the
+                                     // product build: 4 beats 8 (1314 vs 1284 TFLOP/s thresholded, 1178 vs 1031 k-NN):
+                                     // with 8 the register file is full and the compiler shortens the LDS read pipeline
 
 __device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rsrc, int voff, char* lds) {
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)lds, 16, voff, 0, 0, 0);
@@ -236,10 +241,11 @@ __global__ __launch_bounds__(512) void sim_f16p_kernel(SimF16PArgs a) {
                     v0 = fminf(v0, __shfl_xor(v0, off));
                     v1 = fminf(v1, __shfl_xor(v1, off));
                 }
-                rtmin[0] = __shfl(v0, 0);
-                rtmin[1] = __shfl(v0, 32);
-                rtmin[2] = __shfl(v1, 0);
-                rtmin[3] = __shfl(v1, 32);
+                // (wave-uniform: kept in scalar registers, the vector file is full)
+                rtmin[0] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v0), 0));
+                rtmin[1] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v0), 32));
+                rtmin[2] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v1), 0));
+                rtmin[3] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v1), 32));
             }
             cur_panel = panel;
         }
