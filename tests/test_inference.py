@@ -1,4 +1,6 @@
 """Frame inference: model contract on CPU, device hand-off on GPU."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -61,3 +63,141 @@ def test_packed_inference_equals_per_video_cpu():
         assert desc.shape == a[idx].shape and torch.allclose(desc, a[idx], atol=1e-5)
     c = dict(run_inference_packed(model, src, "cpu", batch_size=6, rank=1, world_size=3, channels_last=False))
     assert sorted(c) == [1, 4] and torch.allclose(c[4], a[4], atol=1e-5)
+
+
+# ---------------------------------------------------------------- transforms / CLI of inference_cli.py
+@pytest.mark.parametrize("shape", [(360, 640), (480, 270), (320, 320)])
+def test_device_transforms_match_pil(shape):
+    """The three InferenceTransforms (inference_impl.py:39-69) as tensor ops == what torchvision does to the
+    decoded PIL frame: PIL bilinear (antialiased) resize of the short edge / to a square, centre crop, /255,
+    Normalize.  Resized levels may differ by one rounding step of the 0..255 value."""
+    from PIL import Image
+
+    from vsc2022_amd.vsc.baseline.inference import IMAGENET_MEAN, IMAGENET_STD
+    from vsc2022_amd.vsc.baseline.inference_cli import InferenceTransforms, device_transform
+
+    rng = np.random.default_rng(shape[0])
+    h, w = shape
+    # smooth image + some noise (pure noise makes every resampling-kernel difference visible)
+    yy, xx = np.mgrid[0:h, 0:w]
+    img = np.stack([127 + 120 * np.sin(xx / 37.0 + c) * np.cos(yy / 23.0) for c in range(3)], axis=2)
+    img = np.clip(img + rng.normal(0, 6, img.shape), 0, 255).astype(np.uint8)
+    pil = Image.fromarray(img)
+    x = torch.from_numpy(img).permute(2, 0, 1)
+    mean, std = np.array(IMAGENET_MEAN, np.float32), np.array(IMAGENET_STD, np.float32)
+
+    def ref(im):
+        a = np.asarray(im, dtype=np.float32) / 255.0
+        return ((a - mean) / std).transpose(2, 0, 1)
+
+    def short_edge(size):
+        return (size, int(size * w / h)) if h <= w else (int(size * h / w), size)
+
+    th, tw = short_edge(288)
+    want = {InferenceTransforms.RESIZE_288: ref(pil.resize((tw, th), Image.BILINEAR)),
+            InferenceTransforms.RESIZE_224_SQUARE: ref(pil.resize((224, 224), Image.BILINEAR))}
+    th, tw = short_edge(320)
+    big = pil.resize((tw, th), Image.BILINEAR)
+    top, left = int(round((th - 320) / 2.0)), int(round((tw - 320) / 2.0))
+    want[InferenceTransforms.RESIZE_320_CENTER] = ref(big.crop((left, top, left + 320, top + 320)))
+    for t, expect in want.items():
+        got = device_transform(x, t)[0].numpy()
+        assert got.shape == expect.shape, (t, got.shape, expect.shape)
+        step = 1.0 / 255.0 / std.min()          # one 0..255 level after Normalize
+        diff = np.abs(got - expect)
+        assert diff.max() <= 2.01 * step and (diff > 1.01 * step).mean() < 1e-3, (t, diff.max() / step)
+
+
+class _TinyNet(torch.nn.Module):
+    """Stand-in for the SSCD TorchScript file: [B, 3, H, W] -> [B, 16]."""
+
+    def __init__(self):
+        super().__init__()
+        torch.manual_seed(0)
+        self.conv = torch.nn.Conv2d(3, 8, 5, stride=4)
+        self.fc = torch.nn.Linear(8, 16)
+
+    def forward(self, x):
+        return self.fc(torch.relu(self.conv(x)).mean(dim=(2, 3)))
+
+
+def _make_dataset(d, n=5):
+    rng = np.random.default_rng(1)
+    lens = []
+    for v in range(n):
+        k = int(rng.integers(2, 6))
+        lens.append(k)
+        np.save(d / f"Q{v:06d}.npy", rng.integers(0, 256, (k, 72, 96, 3), dtype=np.uint8))
+    return lens
+
+
+def test_inference_cli_torchscript_processes_and_merge(tmp_path):
+    """The reference's flow (inference.py:93-158) on `.npy` frame stacks: TorchScript model file, per-rank .npz
+    files, merge; 2 worker processes == 1 process; --store_fp16; externally launched ranks write their own file."""
+    from vsc2022_amd.vsc.baseline import inference_cli as cli
+    from vsc2022_amd.vsc.storage import load_features
+
+    data = tmp_path / "videos"
+    data.mkdir()
+    lens = _make_dataset(data)
+    model_path = str(tmp_path / "tiny.torchscript.pt")
+    torch.jit.script(_TinyNet()).save(model_path)
+    base = ["--torchscript_path", model_path, "--dataset_path", str(data), "--video_extensions", "npy",
+            "--video_reader", "NPY", "--transforms", "RESIZE_224_SQUARE", "--batch_size", "3", "--fps", "2"]
+    p = cli.build_parser()
+    cli.main(p.parse_args(base + ["--output_file", str(tmp_path / "one" / "q.npz")]))
+    one = load_features(str(tmp_path / "one" / "q.npz"))
+    assert [v.video_id for v in one] == [f"Q{v:06d}" for v in range(5)]
+    assert [len(v) for v in one] == lens and one[0].feature.shape[1] == 16 and one[0].feature.dtype == np.float32
+    assert np.allclose(one[1].timestamps, np.stack([np.arange(lens[1]) / 2.0, (np.arange(lens[1]) + 1) / 2.0], 1))
+    # eager model on the same transform == the CLI's descriptors
+    frames = torch.from_numpy(np.load(data / "Q000002.npy")).permute(0, 3, 1, 2)
+    with torch.no_grad():
+        direct = _TinyNet()(cli.device_transform(frames, cli.InferenceTransforms.RESIZE_224_SQUARE)).numpy()
+    assert np.allclose(direct, one[2].feature, atol=1e-5)
+    # two spawned workers + merge: the same videos (order: rank 0's, then rank 1's), the same descriptors
+    cli.main(p.parse_args(base + ["--processes", "2", "--scratch_path", str(tmp_path / "scratch"),
+                                  "--output_file", str(tmp_path / "two" / "q.npz")]))
+    two = {v.video_id: v for v in load_features(str(tmp_path / "two" / "q.npz"))}
+    assert sorted(two) == [v.video_id for v in one]
+    assert sorted(os.listdir(tmp_path / "scratch")) == ["0.npz", "1.npz"]
+    assert [v.video_id for v in load_features(str(tmp_path / "scratch" / "1.npz"))] == ["Q000001", "Q000003"]
+    for v in one:
+        assert np.array_equal(two[v.video_id].feature, v.feature) and np.array_equal(two[v.video_id].timestamps, v.timestamps)
+    # an externally launched rank writes its own share to --output_file; fp16 storage
+    cli.main(p.parse_args(base + ["--distributed_rank", "2", "--distributed_size", "3", "--store_fp16",
+                                  "--output_file", str(tmp_path / "r2.npz")]))
+    r2 = load_features(str(tmp_path / "r2.npz"))
+    assert [v.video_id for v in r2] == ["Q000002"]
+    assert np.allclose(r2[0].feature, one[2].feature, atol=2e-3, rtol=2e-3)
+    with pytest.raises(Exception):
+        cli.main(p.parse_args(base + ["--processes", "2", "--distributed_size", "2", "--output_file", str(tmp_path / "x.npz")]))
+    with pytest.raises(FileNotFoundError):  # no ffmpeg binary here: the FFMPEG reader must say so, not return nothing
+        cli.main(p.parse_args(["--dataset_path", str(data), "--video_extensions", "npy", "--ffmpeg_path",
+                               "/nonexistent/ffmpeg", "--torchscript_path", model_path,
+                               "--output_file", str(tmp_path / "y.npz")]))
+
+
+@pytest.mark.gpu
+def test_inference_cli_on_the_gpu(gpu, tmp_path):
+    """--accelerator cuda: the SSCD-shaped network (scripted to a TorchScript file, loaded by the CLI) on the
+    device transform RESIZE_320_CENTER; descriptors equal the eager network's."""
+    from vsc2022_amd.vsc.baseline import inference_cli as cli
+    from vsc2022_amd.vsc.baseline.inference import build_sscd_model
+    from vsc2022_amd.vsc.storage import load_features
+
+    data = tmp_path / "videos"
+    data.mkdir()
+    lens = _make_dataset(data, n=3)
+    model = build_sscd_model(device="cuda", channels_last=False)
+    path = str(tmp_path / "sscd_random.torchscript.pt")
+    torch.jit.trace(model, torch.zeros(2, 3, 320, 320, device="cuda")).save(path)
+    cli.main(cli.build_parser().parse_args(
+        ["--torchscript_path", path, "--accelerator", "cuda", "--dataset_path", str(data), "--video_extensions", "npy",
+         "--video_reader", "NPY", "--output_file", str(tmp_path / "q.npz")]))
+    vfs = load_features(str(tmp_path / "q.npz"))
+    assert [len(v) for v in vfs] == lens and vfs[0].feature.shape[1] == 512
+    frames = torch.from_numpy(np.load(data / "Q000001.npy")).permute(0, 3, 1, 2).cuda()
+    with torch.no_grad():
+        direct = model(cli.device_transform(frames, cli.InferenceTransforms.RESIZE_320_CENTER)).cpu().numpy()
+    assert np.allclose(direct, vfs[1].feature, rtol=1e-3, atol=1e-4)
