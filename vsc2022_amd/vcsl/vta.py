@@ -64,10 +64,28 @@ class TN:
         return list(zip(names, unpack_boxes(nbox, boxes)))
 
 
-def build_vta_model(method: str = "TN", concurrency: int = 1, **config):
-    if method != "TN":
-        raise NotImplementedError(
-            f"alignment model {method!r}: only the Temporal Network ('TN') is implemented "
-            "(the only model the reference requests)"
-        )
-    return TN(concurrency=concurrency, **config)
+_REGISTRY = {}
+
+
+def register_vta_model(name: str, factory):
+    """Plug another aligner in behind `build_vta_model(name, **kwargs)`: `factory(concurrency=..., **kwargs)` must
+    return an object with `forward_sim([(name, sims), ...]) -> [(name, [[q_lo, r_lo, q_hi, r_hi], ...]), ...]`
+    (VCSL's DTW / DP / HV / SPD have that shape).  Such models run on the reference's route of
+    `VCSLLocalization.localize_all`: similarity matrices from the GPU, alignment by the model, `score()` per box."""
+    _REGISTRY[str(name)] = factory
+
+
+def build_vta_model(method="TN", concurrency: int = 1, **config):
+    if not isinstance(method, str):
+        if not hasattr(method, "forward_sim"):
+            raise TypeError("an alignment model object must provide forward_sim(data)")
+        return method  # a ready-made aligner
+    if method == "TN":
+        return TN(concurrency=concurrency, **config)
+    if method in _REGISTRY:
+        return _REGISTRY[method](concurrency=concurrency, **config)
+    raise NotImplementedError(
+        f"alignment model {method!r}: only the Temporal Network ('TN') ships with this package (the only model the "
+        "reference requests; the VCSL source of DTW / DP / HV / SPD is not part of the reference checkout) -- "
+        "register another aligner with vsc2022_amd.vcsl.vta.register_vta_model"
+    )
