@@ -1,5 +1,7 @@
 """GPU: edge cases of the public surface -- empty and ragged inputs, degenerate sizes, argument
 errors (the reference's convention: asserts / exceptions)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -138,3 +140,51 @@ def test_score_normalize_edge_cases(gpu):
     assert np.all(ar[0].feature[:, -1] == 1.0) and np.all(aq[0].feature[:, -1] <= 1.2 + 1e-6)
     aq2, ar2 = score_normalize([], r, n)
     assert aq2 == [] and len(ar2) == 1
+
+
+def test_tn_rejects_more_paths_than_boxes(gpu):
+    """max_path >= VSC_TN_MAX_BOXES would drop boxes silently; it is an explicit error instead."""
+    from vsc2022_amd import _lib
+    from vsc2022_amd.vcsl.vta import build_vta_model
+
+    sims = np.random.default_rng(0).random((12, 14)).astype(np.float32)
+    assert build_vta_model("TN", max_path=_lib.TN_MAX_BOXES - 1).forward_sim([("a", sims)])[0][0] == "a"
+    with pytest.raises(_lib.VscError):
+        build_vta_model("TN", max_path=_lib.TN_MAX_BOXES).forward_sim([("a", sims)])
+
+
+def test_sharded_code_path_over_rccl_world1(gpu):
+    """The RCCL ("nccl") branch of vsc2022_amd/dist.py -- device tensors straight into the collectives, no host
+    staging -- as far as one GPU allows: a world of one rank, the sharded pipeline forced on."""
+    import subprocess
+    import sys
+
+    code = r'''
+import os, sys, numpy as np, torch, torch.distributed as dist
+sys.path.insert(0, os.getcwd())
+os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29871", VSC_FORCE_SHARDED="1")
+from vsc2022_amd import synth, dist as vdist
+from vsc2022_amd.engine import DeviceMatcher
+dev = torch.device("cuda", 0); torch.cuda.set_device(dev)
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+assert dist.get_backend() == "nccl"
+q, r, _ = synth.make_dataset(seed=5, n_query=40, n_ref=60, dim=64, q_frames=(8, 20), r_frames=(8, 30), planted_frac=0.3)
+pack = lambda v: (np.concatenate([x.feature for x in v]).astype(np.float32), np.r_[0, np.cumsum([len(x.feature) for x in v])].astype(np.int64))
+(qf, qoff), (rf, roff) = pack(q), pack(r)
+m = DeviceMatcher(rf, roff, 0); m.set_queries(qf, qoff)
+a = m.match()
+t = torch.zeros(4, device=dev); assert not vdist._via_host(t, None)
+b = m.match(n_qvid_global=len(q), qvid_base=0, row_base=0)
+assert torch.equal(a.cand_q, b.cand_q) and torch.equal(a.cand_r, b.cand_r) and torch.equal(a.cand_score, b.cand_score)
+assert (a.n_hits, a.n_candidates, a.n_localized, a.n_matches) == (b.n_hits, b.n_candidates, b.n_localized, b.n_matches)
+n = a.n_localized
+assert torch.equal(a.nbox[:n], b.nbox[:n]) and torch.equal(a.boxes[:n], b.boxes[:n])
+# the collectives themselves on device tensors
+x = torch.arange(10, device=dev, dtype=torch.float32).flip(0)
+assert vdist.distributed_prefix_select(x, 4)[0] == 4
+assert torch.equal(vdist.all_gather_varlen(torch.arange(5, device=dev)), torch.arange(5, device=dev))
+dist.destroy_process_group(); print("rccl-world1-ok")
+'''
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", code], cwd=root, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "rccl-world1-ok" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]

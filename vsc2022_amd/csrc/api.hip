@@ -1257,8 +1257,11 @@ int vsc_tn_localize(vsc_tn_ctx_t* c, const int32_t* pair_q, const int32_t* pair_
     }
     if (n_pairs == 0) return VSC_OK;
     if (params->tn_top_k < 1 || params->tn_top_k > 16 || params->tn_max_step < 1 || params->tn_max_step > 64 ||
-        params->max_path < 0) {
-        set_error("vsc_tn_localize: unsupported TN parameters (tn_top_k 1..16, tn_max_step 1..64)");
+        params->max_path < 0 || params->max_path >= VSC_TN_MAX_BOXES) {
+        // max_path + 1 extractions can accept max_path + 1 boxes: more than the output holds would silently change
+        // the IoU-suppression history
+        set_error("vsc_tn_localize: unsupported TN parameters (tn_top_k 1..16, tn_max_step 1..64, max_path 0..%d)",
+                  VSC_TN_MAX_BOXES - 1);
         return VSC_ERR_INVALID;
     }
     VSC_HIP(hipSetDevice(c->device));
@@ -1332,8 +1335,11 @@ int vsc_tn_forward_sim(const float* sims, const int64_t* sims_off, const int32_t
     }
     if (n_pairs == 0) return VSC_OK;
     if (params->tn_top_k < 1 || params->tn_top_k > 16 || params->tn_max_step < 1 || params->tn_max_step > 64 ||
-        params->max_path < 0) {
-        set_error("vsc_tn_forward_sim: unsupported TN parameters (tn_top_k 1..16, tn_max_step 1..64)");
+        params->max_path < 0 || params->max_path >= VSC_TN_MAX_BOXES) {
+        // max_path + 1 extractions can accept max_path + 1 boxes: more than the output holds would silently change
+        // the IoU-suppression history
+        set_error("vsc_tn_forward_sim: unsupported TN parameters (tn_top_k 1..16, tn_max_step 1..64, max_path 0..%d)",
+                  VSC_TN_MAX_BOXES - 1);
         return VSC_ERR_INVALID;
     }
     VSC_TRY(check_device(device));
