@@ -42,8 +42,12 @@ constexpr int PF = VSC_F16P_PF;      // register ring: k-steps (PF - 1 in flight
 __device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rsrc, int voff, char* lds) {
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)lds, 16, voff, 0, 0, 0);
 }
+// cache policy of the reference stream (aux bits of the buffer load: 1 = sc0, 2 = nt, 16 = sc1)
+#ifndef VSC_F16P_AUX
+#define VSC_F16P_AUX 0
+#endif
 __device__ __forceinline__ f16x8 bload(__amdgpu_buffer_rsrc_t rs, int voff, int soff) {
-    return __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, 0));
+    return __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, VSC_F16P_AUX));
 }
 __device__ __forceinline__ const char* uniform_ptr(const char* p) {
     const uint64_t v = reinterpret_cast<uint64_t>(p);
