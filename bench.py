@@ -235,6 +235,41 @@ def extra_legs(args, torch, dev, matcher, queries, n_qv, qf, n_rv, rf, dim):
     return out
 
 
+def cpu_baseline_blas(args):
+    """What the reference's CPU FAISS path spends most of its time in: sgemm of the score matrix (numpy ->
+    the host BLAS, all cores) + the strict radius test of `range_search`, on a bounded sample.  Scores come out of a
+    BLAS summation order, so this leg checks nothing -- it only says how fast the host cores multiply."""
+    try:
+        from threadpoolctl import threadpool_info
+
+        nth = max([p.get("num_threads", 1) for p in threadpool_info()] + [1])
+    except Exception:
+        nth = os.cpu_count() or 1
+    rng = np.random.default_rng(args.seed)
+    dim, qf = args.dim, args.query_frames
+    n_qv = 512
+    n_r = max(1, args.ref_videos * args.ref_frames // 10)
+    q = rng.standard_normal((n_qv * qf, dim)).astype(np.float32)
+    r = rng.standard_normal((n_r, dim)).astype(np.float32)
+    q /= np.linalg.norm(q, axis=1, keepdims=True)
+    r /= np.linalg.norm(r, axis=1, keepdims=True)
+    (q[:64] @ r[:1024].T).sum()  # BLAS thread pool warm-up
+    radius = np.float32(0.18)    # ~ the final radius of the full-size search (K = 1200 per video over 2M refs)
+    t0 = time.perf_counter()
+    hits = 0
+    for i0 in range(0, len(q), 2048):
+        s = q[i0 : i0 + 2048] @ r.T
+        hits += int(np.count_nonzero(s > radius))
+    dt = time.perf_counter() - t0
+    scale = n_r / float(args.ref_videos * args.ref_frames)
+    return {
+        "value": (n_qv / dt) * scale, "unit": "query-videos/s (search stage only)", "cores": nth, "kind": "port",
+        "sgemm_tflops": 2.0 * len(q) * n_r * dim / dt / 1e12,
+        "sample": f"{n_qv} query videos x {qf} frames vs {n_r} ref frames ({dim}-d): numpy sgemm + threshold in {dt:.2f} s "
+                  f"on {nth} BLAS threads, {hits} hits; rate scaled by {scale:.3f}; no aggregation / localisation",
+    }
+
+
 def main():
     args = parse()
     import torch
@@ -420,6 +455,7 @@ def main():
                 out["extra"]["value_with_fresh_query_set"] = n_qv / (ms_fresh / 1e3)
             if not args.no_cpu_baseline:
                 out["cpu_baseline"] = cpu_baseline(args)
+                out["cpu_baseline_blas_search_only"] = cpu_baseline_blas(args)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
