@@ -158,6 +158,10 @@ int vsc_tn_create(const float* qfeat, const int64_t* q_off, int64_t n_qvid, cons
                   const int64_t* r_off, int64_t n_rvid, int dim, int feat_mem, int device,
                   vsc_tn_ctx_t** out);
 int vsc_tn_destroy(vsc_tn_ctx_t* ctx);
+/* Replace the QUERY side of a context (a new query batch against the same, resident references: the per-query-set
+ * step of vsc/baseline/sscd_baseline.py:90-176 when many query sets meet one reference set).  The reference rows
+ * stay packed in HBM; only the nq query rows are uploaded and packed.  Same argument meaning as vsc_tn_create. */
+int vsc_tn_set_queries(vsc_tn_ctx_t* ctx, const float* qfeat, const int64_t* q_off, int64_t n_qvid, int feat_mem);
 
 /* One localize_all batch.  pair_q/pair_r[n_pairs] are video ordinals.  Outputs (host or device):
  *   out_nbox[n_pairs]                       number of boxes (<= VSC_TN_MAX_BOXES)

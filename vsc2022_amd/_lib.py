@@ -37,7 +37,7 @@ EXPORTS = (
     "vsc_index_create", "vsc_index_destroy", "vsc_index_add", "vsc_index_ntotal", "vsc_index_dim",
     "vsc_index_metric", "vsc_index_set_hit_capacity", "vsc_index_sync", "vsc_index_knn",
     "vsc_index_range_search", "vsc_index_global_topk", "vsc_index_candidates", "vsc_pair_max", "vsc_row_normalize",
-    "vsc_tn_create", "vsc_tn_destroy", "vsc_tn_localize", "vsc_tn_forward_sim", "vsc_tn_similarity",
+    "vsc_tn_create", "vsc_tn_set_queries", "vsc_tn_destroy", "vsc_tn_localize", "vsc_tn_forward_sim", "vsc_tn_similarity",
     "vsc_index_profile", "vsc_index_profile_read", "vsc_index_profile_read_class", "vsc_index_search_stats",
     "vsc_aux_profile", "vsc_aux_profile_read",
 )
@@ -140,6 +140,7 @@ def lib():
                                    i32, pi64, i32]
         L.vsc_row_normalize.argtypes = [vp, i64, i32, i32, vp, i32, i32]
         L.vsc_tn_create.argtypes = [vp, vp, i64, vp, vp, i64, i32, i32, i32, ctypes.POINTER(vp)]
+        L.vsc_tn_set_queries.argtypes = [vp, vp, vp, i64, i32]
         L.vsc_tn_destroy.argtypes = [vp]
         L.vsc_tn_localize.argtypes = [vp, vp, vp, i64, i32, ctypes.POINTER(TNParams), f32, vp, vp, vp, i32]
         L.vsc_tn_forward_sim.argtypes = [vp, vp, vp, vp, i64, ctypes.POINTER(TNParams), vp, vp, vp, i32]

@@ -1235,6 +1235,24 @@ int vsc_tn_create(const float* qfeat, const int64_t* q_off, int64_t n_qvid, cons
     return VSC_OK;
 }
 
+int vsc_tn_set_queries(vsc_tn_ctx_t* c, const float* qfeat, const int64_t* q_off, int64_t n_qvid, int feat_mem) {
+    if (!c || n_qvid < 0 || !q_off || (n_qvid > 0 && q_off[n_qvid] > 0 && !qfeat)) {
+        set_error("vsc_tn_set_queries: invalid argument");
+        return VSC_ERR_INVALID;
+    }
+    VSC_HIP(hipSetDevice(c->device));
+    c->n_qvid = n_qvid;
+    c->q_off.assign(q_off, q_off + n_qvid + 1);
+    const int64_t nq = c->q_off.back();
+    const int64_t q_rows = round_up64(nq + 32, ROW_PAD);  // (+32: see vsc_tn_create)
+    VSC_TRY(c->qfeat.reserve((size_t)q_rows * c->dpad * 4));
+    VSC_TRY(pack_into(qfeat, nq, c->dim, feat_mem, c->qfeat.as<float>(), q_rows, c->dpad, c->ws, c->stream));
+    VSC_TRY(c->d_qoff.reserve((size_t)(n_qvid + 1) * 8));
+    VSC_HIP(hipMemcpyAsync(c->d_qoff.p, c->q_off.data(), (size_t)(n_qvid + 1) * 8, hipMemcpyHostToDevice, c->stream));
+    VSC_HIP(hipStreamSynchronize(c->stream));
+    return VSC_OK;
+}
+
 int vsc_tn_destroy(vsc_tn_ctx_t* c) {
     if (!c) return VSC_OK;
     (void)hipSetDevice(c->device);

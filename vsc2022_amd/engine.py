@@ -150,10 +150,12 @@ class DeviceMatcher:
         self.q_feats = self._as_dev(q_feats)
         lens = torch.from_numpy(np.diff(self.q_off)).to(self.tdev)
         self.row2q = torch.repeat_interleave(torch.arange(self.n_qvid, dtype=torch.int32, device=self.tdev), lens)
-        if self._tn is not None:
-            _lib.lib().vsc_tn_destroy(self._tn)
-            self._tn = None
         torch.cuda.synchronize(self.tdev)
+        if self._tn is not None:
+            # the references stay packed in the Temporal-Network context: only the query side is replaced
+            _lib.check(_lib.lib().vsc_tn_set_queries(self._tn, _dev_ptr(self.q_feats), self.q_off.ctypes.data,
+                                                     self.n_qvid, _lib.MEM_DEVICE))
+            return
         ctx = ctypes.c_void_p()
         _lib.check(_lib.lib().vsc_tn_create(
             _dev_ptr(self.q_feats), self.q_off.ctypes.data, self.n_qvid, _dev_ptr(self.ref_feats),
