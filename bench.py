@@ -389,9 +389,12 @@ def main():
                 "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "bound": "mfma"},
             "rescore_kernel (exact fp32 chain of the candidates)": {
                 "ms_per_step": prof.get("rescore_ms", 0.0) / steps,
-                "achieved": _rate(float(cand) * dpad_bytes * steps, prof.get("rescore_ms", 0.0), 1e9),
-                "peak": HBM_PEAK_GBS, "unit": "GB/s", "bound": "hbm",
-                "note": f"{cand} candidates of the last search x {dpad_bytes} B (two fp32 rows each)"},
+                # HBM/fabric side: one REFERENCE row per candidate (a random 2 KB read of the 4 GB image; the query rows
+                # of a segment are one 128-row panel and stay in L2).  l2_to_cu counts both rows.
+                "achieved": _rate(float(cand) * (dpad_bytes // 2) * steps, prof.get("rescore_ms", 0.0), 1e9),
+                "l2_to_cu_GBs": _rate(float(cand) * dpad_bytes * steps, prof.get("rescore_ms", 0.0), 1e9),
+                "peak": HBM_PEAK_GBS, "unit": "GB/s", "bound": "hbm / fabric gather",
+                "note": f"{cand} candidates of the last search x {dpad_bytes // 2} B reference row (+ as many query-row bytes from L2)"},
             "select_* (radix select + compaction of the re-thresholds)": {
                 "ms_per_step": prof.get("select_ms", 0.0) / steps, "launch_groups_per_step": prof.get("select_launches", 0) / steps},
             "final ordering of the kept hits (radix sorts)": {
