@@ -169,29 +169,71 @@ __global__ __launch_bounds__(64) void tn_pair_kernel(TnPairArgs a) {
     __threadfence_block();
     __syncthreads();
 
-    // ---- 2. per-row top-k by (sim desc, ref asc): `top` rounds of wave arg-best ----
-    for (int q = 0; q < lq; ++q) {
-        const float* row = sims + (int64_t)q * lr;
-        float prev_s = INFINITY;
-        int prev_r = -1;
-        for (int e = 0; e < top; ++e) {
-            float bs = 0.0f;
-            int br = -1;
-            for (int r = lane; r < lr; r += 64) {
-                const float s = row[r];
-                const bool after = (s < prev_s) || (s == prev_s && r > prev_r);
-                if (after && (br < 0 || s > bs)) {  // r ascends per lane: first max kept
-                    bs = s;
-                    br = r;
+    // ---- 2. per-row top-k by (sim desc, ref asc) ----
+    // Two equivalent methods.  Lane per ROW (top_k <= 8, enough rows to fill lanes): every lane walks its row once,
+    // ascending r, keeping a sorted top-8 in registers (strict '>' on insertion: of equal sims the lower ref index
+    // stays ahead) -- lr steps for 64 rows instead of `top` wave reductions per row.  Otherwise: `top` rounds of
+    // wave arg-best per row (few long rows).
+    if (top_cap <= 8 && (lq >= 16 || lr <= 128)) {
+        for (int q0 = 0; q0 < lq; q0 += 64) {
+            const int q = q0 + lane;
+            float ts[8];
+            int ti[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                ts[e] = -INFINITY;
+                ti[e] = -1;
+            }
+            if (q < lq) {
+                const float* row = sims + (int64_t)q * lr;
+                for (int r = 0; r < lr; ++r) {
+                    const float sv = row[r];
+                    if (!(sv > ts[7]) && ti[7] >= 0) continue;  // (an unfilled slot accepts anything, -inf included)
+#pragma unroll
+                    for (int e = 7; e >= 1; --e) {
+                        const bool empty_above = ti[e - 1] < 0;
+                        const bool up = empty_above || sv > ts[e - 1];  // belongs above slot e-1: that one moves down
+                        const bool here = !up && (ti[e] < 0 || sv > ts[e]);
+                        ts[e] = up ? ts[e - 1] : (here ? sv : ts[e]);
+                        ti[e] = up ? ti[e - 1] : (here ? r : ti[e]);
+                    }
+                    if (ti[0] < 0 || sv > ts[0]) {
+                        ts[0] = sv;
+                        ti[0] = r;
+                    }
                 }
+#pragma unroll
+                for (int e = 0; e < 8; ++e)
+                    if (e < top) {
+                        tidx[q * top + e] = (short)ti[e];
+                        tsim[q * top + e] = ts[e];
+                    }
             }
-            wave_first_max(bs, br);
-            if (lane == 0) {
-                tidx[q * top + e] = (short)br;
-                tsim[q * top + e] = bs;
+        }
+    } else {
+        for (int q = 0; q < lq; ++q) {
+            const float* row = sims + (int64_t)q * lr;
+            float prev_s = INFINITY;
+            int prev_r = -1;
+            for (int e = 0; e < top; ++e) {
+                float bs = 0.0f;
+                int br = -1;
+                for (int r = lane; r < lr; r += 64) {
+                    const float s = row[r];
+                    const bool after = (s < prev_s) || (s == prev_s && r > prev_r);
+                    if (after && (br < 0 || s > bs)) {  // r ascends per lane: first max kept
+                        bs = s;
+                        br = r;
+                    }
+                }
+                wave_first_max(bs, br);
+                if (lane == 0) {
+                    tidx[q * top + e] = (short)br;
+                    tsim[q * top + e] = bs;
+                }
+                prev_s = bs;
+                prev_r = br;
             }
-            prev_s = bs;
-            prev_r = br;
         }
     }
     __syncthreads();
@@ -241,7 +283,52 @@ __global__ __launch_bounds__(64) void tn_pair_kernel(TnPairArgs a) {
         }
         __syncthreads();
         for (int qj = 0; qj < lq; ++qj) {
-            for (int b = 0; b < top; ++b) {
+            // The nodes of one query row depend on earlier rows only.  When a node's predecessor slots fit 32 lanes
+            // (the reference's tn_max_step = 5, top 5: 20), two nodes are evaluated per pass, one per half wave
+            // (xor shuffles with offsets <= 16 stay inside a half); the sink keeps the whole-wave path below.
+            int b_first = 0;
+            if (P <= 32) {
+                const int half = lane >> 5, o = lane & 31;
+                for (int b0 = 0; b0 < top; b0 += 2) {
+                    const int b = b0 + half;
+                    const int v = 1 + qj * top + b;
+                    const bool mine = b < top && v != g.sink;
+                    float c = 0.0f;
+                    int oo = -1;
+                    if (mine && o < P) {
+                        const int d = ms - 1 - o / top, aa = o % top;
+                        const int qi = qj - d;
+                        if (qi >= 0 && tn_edge_ok(g, qi, aa, d, b)) {
+                            const int bit = tn_edge_bit(g, qi, aa, d, b);
+                            const bool z = (zero[bit >> 5] >> (bit & 31)) & 1u;
+                            const float w = z ? 0.0f : tsim[qj * top + b];
+                            c = dist[1 + qi * top + aa] + w;
+                            oo = o;
+                        }
+                    }
+#pragma unroll
+                    for (int off = 16; off >= 1; off >>= 1) {  // (value, slot) first-max inside the half wave
+                        const float ov = __shfl_xor(c, off);
+                        const int o2 = __shfl_xor(oo, off);
+                        if (o2 >= 0 && (oo < 0 || ov > c || (ov == c && o2 < oo))) {
+                            c = ov;
+                            oo = o2;
+                        }
+                    }
+                    if (mine && o == 0) {
+                        if (oo < 0 || !(c >= 0.0f)) {
+                            dist[v] = 0.0f;
+                            par[v] = (short)v;
+                        } else {
+                            dist[v] = c;
+                            par[v] = (short)(1 + (qj - (ms - 1 - oo / top)) * top + oo % top);
+                        }
+                    }
+                }
+                // only the sink (last node of the last row) is left for the whole-wave path
+                b_first = (qj == lq - 1) ? top - 1 : top;
+            }
+            for (int b = b_first; b < top; ++b) {
                 const int v = 1 + qj * top + b;
                 const bool is_sink = (v == g.sink);
                 float best = 0.0f;
