@@ -98,13 +98,22 @@ __device__ __forceinline__ float candidate_edge(float t, float eps) { return (t 
 //   ROWTHR = false: thr[n] = edge of *radius for the lane's column of block column n (strict test)
 //   ROWTHR = true : rt = the panel's 128 row thresholds, rtmin[m] = smallest of row block m, eps[n] = the
 //                   lane's column bounds (non-strict test: k-NN ties must survive)
+// The lane id, recomputed where it is used (two VALU instructions).  The emission code must not keep per-lane
+// values (row / column offsets of the lane) alive across a tile: the register file is full, the compiler spills
+// them, and a scratch reload in the hit path costs an s_waitcnt vmcnt(0) that also waits for the acknowledgement
+// of every candidate store issued before it (~2 us per hit: half of a tile's time in the early, dense batches).
+__device__ __forceinline__ int lane_now() {
+    int l;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+    return l;
+}
+
 template <bool ROWTHR>
 __device__ __forceinline__ void emit_candidates(const SimF16PArgs& a, const bool (&all)[2], const float (&thr)[2],
                                                 const float (&eps)[2], const float* rt, const float (&rtmin)[4],
                                                 int row0, int col0, bool interior, const f32x16 (&acc)[4][2],
-                                                const float (&bm)[4][2], int lane, int64_t seg_base, int& count) {
+                                                const float (&bm)[4][2], int64_t seg_base, int& count) {
     // C layout of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
-    const int rl0 = 4 * (lane >> 5);
 #pragma unroll
     for (int m = 0; m < 4; ++m)
 #pragma unroll
@@ -113,18 +122,21 @@ __device__ __forceinline__ void emit_candidates(const SimF16PArgs& a, const bool
             if (!__any(blk)) continue;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int rl = rl0 + m * 32 + (r & 3) + 8 * (r >> 2);
+                const int rb = m * 32 + (r & 3) + 8 * (r >> 2);  // + 4 * (lane >> 5) = row inside the panel
                 bool cand;
                 if (ROWTHR)
-                    cand = acc[m][n][r] >= candidate_edge(rt[rl], eps[n]);
+                    cand = acc[m][n][r] >= candidate_edge(rt[rb + 4 * (lane_now() >> 5)], eps[n]);
                 else
                     cand = acc[m][n][r] > thr[n];
-                const unsigned long long hits = __ballot(all[n] || cand);
+                const bool hit = all[n] || cand;
+                const unsigned long long hits = __ballot(hit);
                 if (hits == 0ull) continue;
-                const int i = row0 + rl;
-                const int j = col0 + n * 32 + (lane & 31);
+                const int ln = lane_now();
+                const int i = row0 + rb + 4 * (ln >> 5);
+                const int j = col0 + n * 32 + (ln & 31);
                 // (tiles that reach past the batch or the references drop their padding rows / columns)
-                const unsigned long long ok = interior ? hits : __ballot(((hits >> lane) & 1ull) && i < a.nq && j < a.nr);
+                const bool mine = hit && (interior || (i < a.nq && j < a.nr));
+                const unsigned long long ok = interior ? hits : __ballot(mine);
                 if (ok == 0ull) continue;
                 const int total = __popcll(ok);
                 int64_t pos;
@@ -134,16 +146,16 @@ __device__ __forceinline__ void emit_candidates(const SimF16PArgs& a, const bool
                 } else {
                     // segment full (candidates are not spread evenly): shared tail behind the segments
                     unsigned long long base = 0;
-                    if (lane == 0) base = atomicAdd(a.tail_count, (unsigned long long)total);
+                    if (ln == 0) base = atomicAdd(a.tail_count, (unsigned long long)total);
                     base = __shfl(base, 0);
                     if ((long long)(base + total) > a.tail_cap) {
-                        if (lane == 0) atomicOr(a.overflow, 1);
+                        if (ln == 0) atomicOr(a.overflow, 1);
                         continue;
                     }
                     pos = a.tail_base + (int64_t)base;
                 }
-                if ((ok >> lane) & 1ull) {
-                    pos += __popcll(ok & ((1ull << lane) - 1));
+                if (mine) {
+                    pos += __builtin_amdgcn_mbcnt_hi((unsigned)(ok >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)ok, 0u));
                     a.out_i[pos] = a.i0 + i;
                     a.out_j[pos] = j;
                 }
@@ -303,7 +315,7 @@ __global__ __launch_bounds__(512) void sim_f16p_kernel(SimF16PArgs a) {
             }
             if (__any(any_blk))
                 emit_candidates<ROWTHR>(a, all, thr, eps, rt_sh, rtmin, panel * PR, col0,
-                                        panel * PR + PR <= a.nq && col0 + 64 <= a.nr, acc, bm, lane, seg_base, count);
+                                        panel * PR + PR <= a.nq && col0 + 64 <= a.nr, acc, bm, seg_base, count);
         }
     }
     if (lane == 0) a.seg_count[seg] = count;
