@@ -120,18 +120,21 @@ __device__ __forceinline__ void emit_candidates(const SimF16PArgs& a, const bool
         for (int n = 0; n < 2; ++n) {
             const bool blk = all[n] || (ROWTHR ? bm[m][n] >= candidate_edge(rtmin[m], eps[n]) : bm[m][n] > thr[n]);
             if (!__any(blk)) continue;
+            // k-NN: the row thresholds of the lane's 16 rows of this block are looked up by row index: the lane id
+            // is taken once per flagged block (live inside the block only)
+            const int ln_blk = ROWTHR ? lane_now() : 0;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int rb = m * 32 + (r & 3) + 8 * (r >> 2);  // + 4 * (lane >> 5) = row inside the panel
                 bool cand;
                 if (ROWTHR)
-                    cand = acc[m][n][r] >= candidate_edge(rt[rb + 4 * (lane_now() >> 5)], eps[n]);
+                    cand = acc[m][n][r] >= candidate_edge(rt[rb + 4 * (ln_blk >> 5)], eps[n]);
                 else
                     cand = acc[m][n][r] > thr[n];
                 const bool hit = all[n] || cand;
                 const unsigned long long hits = __ballot(hit);
                 if (hits == 0ull) continue;
-                const int ln = lane_now();
+                const int ln = ROWTHR ? ln_blk : lane_now();
                 const int i = row0 + rb + 4 * (ln >> 5);
                 const int j = col0 + n * 32 + (ln & 31);
                 // (tiles that reach past the batch or the references drop their padding rows / columns)

@@ -8,14 +8,13 @@
 //                    because the list is score-descending the first hit of a pair carries its max,
 //                    and first-appearance order IS the stable descending order of the pair scores.
 //
-// HBM-bound plumbing on <= 2K hits (12-16 B each); the device-wide radix sort is rocPRIM's
-// (AMD's native primitive library) -- it is not on the critical path.
+// HBM-bound plumbing on <= 2K hits (12-16 B each) over the stable LSD radix sort of radix.h.
 #include <cfloat>
 #include <cstring>
-
-#include <rocprim/rocprim.hpp>
+#include <utility>
 
 #include "kernels.h"
+#include "radix.h"
 
 namespace vscmi {
 
@@ -67,14 +66,14 @@ int sort_hits_topk(const int32_t* hi, const int32_t* hj, const float* hs, int64_
     hipLaunchKernelGGL(pack_hits_kernel, dim3(grid_for(n)), dim3(256), 0, stream, hi, hj, hs, n, k64a, k32a);
     VSC_HIP(hipGetLastError());
     const int end_bit = 32 + bits_for((uint64_t)(max_i > 0 ? max_i : 1));
-    size_t need1 = 0, need2 = 0;
-    VSC_HIP(rocprim::radix_sort_pairs(nullptr, need1, k64a, k64b, k32a, k32b, (size_t)n, 0, end_bit, stream));
-    VSC_HIP(rocprim::radix_sort_pairs_desc(nullptr, need2, k32b, k32a, k64b, k64a, (size_t)n, 0, 32, stream));
-    VSC_TRY(tmp.reserve(need1 > need2 ? need1 : need2));
-    size_t tb = tmp.bytes;
-    VSC_HIP(rocprim::radix_sort_pairs(tmp.p, tb, k64a, k64b, k32a, k32b, (size_t)n, 0, end_bit, stream));
-    tb = tmp.bytes;
-    VSC_HIP(rocprim::radix_sort_pairs_desc(tmp.p, tb, k32b, k32a, k64b, k64a, (size_t)n, 0, 32, stream));
+    VSC_TRY(tmp.reserve(radix_tmp_bytes(n)));
+    // (row, ref) ascending, then -- stably -- score descending
+    int w = radix_sort_pairs<uint64_t, uint32_t>(k64a, k64b, k32a, k32b, n, 0, end_bit, false, tmp.p, stream);
+    if (w < 0) { set_error("radix sort launch failed"); return VSC_ERR_HIP; }
+    if (w) { std::swap(k64a, k64b); std::swap(k32a, k32b); }  // sorted pairs now in (k64a, k32a)
+    w = radix_sort_pairs<uint32_t, uint64_t>(k32a, k32b, k64a, k64b, n, 0, 32, true, tmp.p, stream);
+    if (w < 0) { set_error("radix sort launch failed"); return VSC_ERR_HIP; }
+    if (w) { std::swap(k64a, k64b); std::swap(k32a, k32b); }
     hipLaunchKernelGGL(unpack_hits_kernel, dim3(grid_for(m)), dim3(256), 0, stream, k64a, k32a, m, out_i, out_j, out_s, negate);
     VSC_HIP(hipGetLastError());
     return VSC_OK;
@@ -152,13 +151,12 @@ int pair_max_device(const int32_t* hi, const int32_t* hj, const float* hs, int64
     uint32_t* rb = w3.as<uint32_t>();
     hipLaunchKernelGGL(pair_key_kernel, dim3(grid_for(n)), dim3(256), 0, stream, hi, hj, n, row2q, row2r, ka, ra);
     VSC_HIP(hipGetLastError());
-    size_t need = 0;
-    VSC_HIP(rocprim::radix_sort_pairs(nullptr, need, ka, kb, ra, rb, (size_t)n, 0, 64, stream));
-    VSC_TRY(tmp.reserve(need));
-    size_t tb = tmp.bytes;
-    VSC_HIP(rocprim::radix_sort_pairs(tmp.p, tb, ka, kb, ra, rb, (size_t)n, 0, 64, stream));
+    VSC_TRY(tmp.reserve(radix_tmp_bytes(n)));
+    int w = radix_sort_pairs<uint64_t, uint32_t>(ka, kb, ra, rb, n, 0, 64, false, tmp.p, stream);
+    if (w < 0) { set_error("radix sort launch failed"); return VSC_ERR_HIP; }
+    if (!w) { std::swap(ka, kb); std::swap(ra, rb); }  // sorted pairs in (kb, rb); (ka, ra) are free
     VSC_HIP(hipMemsetAsync(cnt.p, 0, sizeof(unsigned long long), stream));
-    // heads compacted into (ra, ka) -- both free again after the sort
+    // heads compacted into (ra, ka)
     hipLaunchKernelGGL(pair_heads_kernel, dim3(grid_for(n)), dim3(256), 0, stream, kb, rb, n, ra, ka,
                        cnt.as<unsigned long long>());
     VSC_HIP(hipGetLastError());
@@ -170,12 +168,11 @@ int pair_max_device(const int32_t* hi, const int32_t* hj, const float* hs, int64
         set_error("pair_max: output capacity %lld < %llu pairs", (long long)cap, np);
         return VSC_ERR_CAPACITY;
     }
-    size_t need2 = 0;
-    VSC_HIP(rocprim::radix_sort_pairs(nullptr, need2, ra, rb, ka, kb, (size_t)np, 0, 32, stream));
-    VSC_TRY(tmp.reserve(need2));
-    tb = tmp.bytes;
-    VSC_HIP(rocprim::radix_sort_pairs(tmp.p, tb, ra, rb, ka, kb, (size_t)np, 0, 32, stream));
-    hipLaunchKernelGGL(pair_out_kernel, dim3(grid_for((int64_t)np)), dim3(256), 0, stream, rb, kb, hs,
+    // first-appearance order = ascending rank of the heads (4 passes: the result is back in (ra, ka))
+    w = radix_sort_pairs<uint32_t, uint64_t>(ra, rb, ka, kb, (int64_t)np, 0, 32, false, tmp.p, stream);
+    if (w < 0) { set_error("radix sort launch failed"); return VSC_ERR_HIP; }
+    if (w) { std::swap(ka, kb); std::swap(ra, rb); }
+    hipLaunchKernelGGL(pair_out_kernel, dim3(grid_for((int64_t)np)), dim3(256), 0, stream, ra, ka, hs,
                        (int64_t)np, out_q, out_r, out_s, out_first);
     VSC_HIP(hipGetLastError());
     return VSC_OK;
@@ -229,18 +226,18 @@ int knn_from_hits(const int32_t* hi, const int32_t* hj, const float* hs, int64_t
     if (n > 0) {
         hipLaunchKernelGGL(knn_keys_kernel, dim3(grid_for(n)), dim3(256), 0, stream, hi, hs, n, ka);
         VSC_HIP(hipGetLastError());
-        const uint32_t* refs_in = reinterpret_cast<const uint32_t*>(hj);
+        // the sort ping-pongs between its buffers: work on a copy of the refs, the hit list stays intact
+        VSC_HIP(hipMemcpyAsync(ra, hj, (size_t)n * 4, hipMemcpyDeviceToDevice, stream));
         const int end_bit = 32 + bits_for((uint64_t)(nq > 0 ? nq : 1));
-        size_t need1 = 0, need2 = 0;
-        VSC_HIP(rocprim::radix_sort_pairs(nullptr, need1, refs_in, rb, ka, kb, (size_t)n, 0, 32, stream));
-        VSC_HIP(rocprim::radix_sort_pairs(nullptr, need2, kb, ka, rb, ra, (size_t)n, 0, end_bit, stream));
-        VSC_TRY(tmp.reserve(need1 > need2 ? need1 : need2));
-        size_t tb = tmp.bytes;
+        VSC_TRY(tmp.reserve(radix_tmp_bytes(n)));
         // 1. refs ascending (payload: the row/score key) ...
-        VSC_HIP(rocprim::radix_sort_pairs(tmp.p, tb, refs_in, rb, ka, kb, (size_t)n, 0, 32, stream));
-        tb = tmp.bytes;
+        int w = radix_sort_pairs<uint32_t, uint64_t>(ra, rb, ka, kb, n, 0, 32, false, tmp.p, stream);
+        if (w < 0) { set_error("radix sort launch failed"); return VSC_ERR_HIP; }
+        if (w) { std::swap(ka, kb); std::swap(ra, rb); }
         // 2. ... then, stably, row ascending / score descending
-        VSC_HIP(rocprim::radix_sort_pairs(tmp.p, tb, kb, ka, rb, ra, (size_t)n, 0, end_bit, stream));
+        w = radix_sort_pairs<uint64_t, uint32_t>(ka, kb, ra, rb, n, 0, end_bit, false, tmp.p, stream);
+        if (w < 0) { set_error("radix sort launch failed"); return VSC_ERR_HIP; }
+        if (w) { std::swap(ka, kb); std::swap(ra, rb); }
     }
     hipLaunchKernelGGL(knn_cut_kernel, dim3(grid_for(nq * k)), dim3(256), 0, stream, ka, ra, n, nq, k, out_s, out_j);
     VSC_HIP(hipGetLastError());
@@ -277,12 +274,11 @@ int sort_hits_rowcol(const int32_t* hi, const int32_t* hj, const float* hs, int6
     uint32_t* k32b = w3.as<uint32_t>();
     hipLaunchKernelGGL(pack_hits_kernel, dim3(grid_for(n)), dim3(256), 0, stream, hi, hj, hs, n, k64a, k32a);
     VSC_HIP(hipGetLastError());
-    size_t need = 0;
-    VSC_HIP(rocprim::radix_sort_pairs(nullptr, need, k64a, k64b, k32a, k32b, (size_t)n, 0, 64, stream));
-    VSC_TRY(tmp.reserve(need));
-    size_t tb = tmp.bytes;
-    VSC_HIP(rocprim::radix_sort_pairs(tmp.p, tb, k64a, k64b, k32a, k32b, (size_t)n, 0, 64, stream));
-    hipLaunchKernelGGL(unpack_hits_kernel, dim3(grid_for(n)), dim3(256), 0, stream, k64b, k32b, n, out_i, out_j, out_s, negate);
+    VSC_TRY(tmp.reserve(radix_tmp_bytes(n)));
+    const int w = radix_sort_pairs<uint64_t, uint32_t>(k64a, k64b, k32a, k32b, n, 0, 64, false, tmp.p, stream);
+    if (w < 0) { set_error("radix sort launch failed"); return VSC_ERR_HIP; }
+    if (w) { std::swap(k64a, k64b); std::swap(k32a, k32b); }
+    hipLaunchKernelGGL(unpack_hits_kernel, dim3(grid_for(n)), dim3(256), 0, stream, k64a, k32a, n, out_i, out_j, out_s, negate);
     VSC_HIP(hipGetLastError());
     return VSC_OK;
 }
