@@ -85,7 +85,8 @@ int vsc_index_sync(vsc_index_t* idx);
 /* Replaces faiss index.search(x, k) (vsc/index.py:174; vsc/baseline/score_normalization.py:96).
  * Per query row the k best refs ordered by (score desc, ref asc) [L2: (dist asc, ref asc)].
  * out_s[nq*k] fp32, out_j[nq*k] int64 (faiss idx_t); missing slots hold -1 and -/+FLT_MAX.
- * k <= 64. */
+ * k <= 4096; k <= 64 runs on the MFMA kernels (fp16 pre-filter + exact stage for large problems), larger k on an
+ * explicit score matrix (same fp32 chains, same order; O(k * nr) per row). */
 int vsc_index_knn(vsc_index_t* idx, const float* q, int64_t nq, int q_mem, int k, float* out_s,
                   int64_t* out_j, int out_mem);
 

@@ -188,3 +188,20 @@ dist.destroy_process_group(); print("rccl-world1-ok")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, "-c", code], cwd=root, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "rccl-world1-ok" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+
+
+def test_knn_with_more_than_64_neighbours(gpu, orc):
+    """faiss accepts any k; k > 64 takes the explicit-matrix route (same fp32 chains, same order)."""
+    from vsc2022_amd.vsc.index import FlatIndex
+
+    rng = np.random.default_rng(4)
+    q, r = unit(rng, 50, 48), unit(rng, 700, 48)
+    r[100:110] = r[5:15]  # ties
+    idx = FlatIndex(48)
+    idx.add(r)
+    for k in (65, 200, 700):
+        D, I = idx.search(q, k)
+        Do, Io = orc.knn(q, r, k)
+        assert np.array_equal(I, Io) and np.array_equal(D.view(np.uint32), Do.view(np.uint32)), k
+    with pytest.raises(ValueError):
+        idx.search(q, 5000)

@@ -884,8 +884,8 @@ static int knn_prefiltered(vsc_index* idx, const float* qp, int64_t nq, int k, f
 
 int vsc_index_knn(vsc_index_t* idx, const float* q, int64_t nq, int q_mem, int k, float* out_s,
                   int64_t* out_j, int out_mem) {
-    if (!idx || nq < 0 || k <= 0 || k > 64 || (nq > 0 && (!q || !out_s || !out_j))) {
-        set_error("vsc_index_knn: invalid argument (k must be in 1..64, got %d)", k);
+    if (!idx || nq < 0 || k <= 0 || k > 4096 || (nq > 0 && (!q || !out_s || !out_j))) {
+        set_error("vsc_index_knn: invalid argument (k must be in 1..4096, got %d)", k);
         return VSC_ERR_INVALID;
     }
     if (nq == 0) return VSC_OK;
@@ -898,7 +898,10 @@ int vsc_index_knn(vsc_index_t* idx, const float* q, int64_t nq, int q_mem, int k
     const int64_t nr = idx->ntotal;
     // The pre-filtered route pays off once the matrix is large (it adds sorts and an exact pass over 1/16 of
     // the references); VSC_PREFILTER=2 forces it for the tests.
-    const bool pre = ip && idx->prefilter && nr >= k &&
+    // k > 64 (the wavefront-sorted lists of the MFMA kernels hold one entry per lane): explicit score matrix in row
+    // chunks + k rounds of wave arg-best -- the same fp32 chains, API completeness rather than speed
+    const bool wide = k > 64;
+    const bool pre = !wide && ip && idx->prefilter && nr >= k &&
                      (idx->prefilter_force || ((double)nq * (double)nr >= 4e9 && nr >= 65536));
     float* qp = nullptr;
     VSC_TRY(pack_queries(idx, q, nq, q_mem, &qp, pre));
@@ -910,7 +913,7 @@ int vsc_index_knn(vsc_index_t* idx, const float* q, int64_t nq, int q_mem, int k
         ds = idx->ws.out[0].as<float>();
         dj = idx->ws.out[1].as<int64_t>();
     }
-    if (ip && nr > 0) {
+    if (ip && nr > 0 && !wide) {
         int rc = pre ? knn_prefiltered(idx, qp, nq, k, ds, dj) : VSC_ERR_OVERFLOW;
         if (rc == VSC_ERR_OVERFLOW) rc = knn_exact_ip(idx, qp, nq, nr, k, ds, dj);
         VSC_TRY(rc);
