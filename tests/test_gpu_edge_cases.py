@@ -51,7 +51,7 @@ def test_empty_and_degenerate_searches(gpu, orc):
     with pytest.raises(ValueError):
         idx.add(np.zeros((3, 15), np.float32))
     with pytest.raises(ValueError):
-        idx.search(q, 65)
+        idx.search(q, 4097)
     with pytest.raises(NotImplementedError):
         VideoIndex(16, "IVF64,Flat")
     # VideoIndex with nothing to say
