@@ -850,8 +850,9 @@ static int knn_prefiltered(vsc_index* idx, const float* qp, int64_t nq, int k, f
     const int64_t nr = idx->ntotal;
     // Subset size: the exact pass costs ~2*dim*S / 1e14 s per row, every later hit (k * nr / S per row)
     // ~3 ns of re-scoring and sorting: the sum is smallest near S = sqrt(300 * k * nr) for dim = 512.
+    static const double subset_factor = getenv("VSC_KNN_SUBSET") ? atof(getenv("VSC_KNN_SUBSET")) : 300.0;
     const int64_t S = std::min<int64_t>(
-        nr, round_up64(std::max<int64_t>((int64_t)std::sqrt(300.0 * k * (double)nr), 4096), ROW_PAD));
+        nr, round_up64(std::max<int64_t>((int64_t)std::sqrt(subset_factor * k * (double)nr), 4096), ROW_PAD));
     if (S < k) return VSC_ERR_OVERFLOW;
     VSC_TRY(knn_exact_ip(idx, qp, nq, S, k, ds, dj));
     const int64_t rows_h = round_up64(nq, ROW_PAD_H) + ROW_PAD_H;
