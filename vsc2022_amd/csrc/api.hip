@@ -433,8 +433,10 @@ static int ensure_hit_buffers(vsc_index* idx, int64_t cap, int64_t ccap = -1, bo
 // with score > *radius -- or, when `row_thr` (one threshold per query row, padded like the fp16 query
 // image) is given, with score >= row_thr[row].
 static int enqueue_f16(vsc_index* idx, const float* qpacked, int64_t i0, int64_t i1, int64_t cap,
-                       const float* row_thr, int64_t ccap = -1) {
+                       const float* row_thr, int64_t ccap = -1, int64_t nr_limit = -1) {
     if (ccap < 0) ccap = cap;  // capacity of the candidate list (cap: of the hit list)
+    // nr_limit: search only the first nr_limit reference rows (threshold refinement of the k-NN)
+    const int64_t nrefs = nr_limit >= 0 ? std::min<int64_t>(nr_limit, idx->ntotal) : idx->ntotal;
     SelectCtl* ctl = idx->ws.ctl.as<SelectCtl>();
     const int nqb = (int)(i1 - i0);
     {
@@ -457,7 +459,7 @@ static int enqueue_f16(vsc_index* idx, const float* qpacked, int64_t i0, int64_t
         if (idx->frag) {
             // panel-stationary kernel (sim_f16p.hip): LDS-resident query panels x the fragment-major reference image
             SimF16PArgs f;
-            sim_f16p_plan(nqb, idx->ntotal, &f.npanel, &f.nsteps, &f.slice, &grid);
+            sim_f16p_plan(nqb, nrefs, &f.npanel, &f.nsteps, &f.slice, &grid);
             VSC_TRY(idx->ws.slices.reserve((size_t)f.npanel * sizeof(int)));
             f.Q = idx->ws.qh.as<_Float16>() + i0 * idx->dpadh;
             f.Rf = idx->refh.p;
@@ -466,7 +468,7 @@ static int enqueue_f16(vsc_index* idx, const float* qpacked, int64_t i0, int64_t
             f.dpadh = idx->dpadh;
             f.nq = nqb;
             f.i0 = (int)i0;
-            f.nr = (int)idx->ntotal;
+            f.nr = (int)nrefs;
             f.next_slice = idx->ws.slices.as<int>();
             f.c1 = c1; f.c2 = c2; f.c3 = c3;
             f.radius = &ctl->radius;
@@ -494,9 +496,9 @@ static int enqueue_f16(vsc_index* idx, const float* qpacked, int64_t i0, int64_t
             f.dpadh = idx->dpadh;
             f.nq = nqb;
             f.i0 = (int)i0;
-            f.nr = (int)idx->ntotal;
+            f.nr = (int)nrefs;
             f.tq = (nqb + 255) / 256;
-            f.tr = (int)((idx->ntotal + 255) / 256);
+            f.tr = (int)((nrefs + 255) / 256);
             f.c1 = c1; f.c2 = c2; f.c3 = c3;
             f.radius = &ctl->radius;
             f.row_thr = row_thr ? row_thr + i0 : nullptr;
@@ -515,7 +517,7 @@ static int enqueue_f16(vsc_index* idx, const float* qpacked, int64_t i0, int64_t
             VSC_TRY(prof_begin(idx, &stop, 1));
             VSC_TRY(launch_sim_f16(f, idx->stream));
         }
-        VSC_TRY(prof_end(idx, stop, 2.0 * (double)nqb * (double)idx->ntotal * (double)idx->dim, 1));
+        VSC_TRY(prof_end(idx, stop, 2.0 * (double)nqb * (double)nrefs * (double)idx->dim, 1));
         // 2. exact scores of the candidates; those above the radius join the kept hits
         RescoreArgs r;
         r.Q = qpacked;
@@ -846,32 +848,23 @@ static int knn_exact_ip(vsc_index* idx, const float* qp, int64_t nq, int64_t nr,
 // top-k included).  3. (row asc, score desc, ref asc) order, cut at k.  Same result as knn_exact_ip, at the
 // cost of one fp32 pass over 1/16 of the references plus one fp16 pass over all of them.
 // Returns VSC_ERR_OVERFLOW when the hit estimate was too small (the caller then runs the exact kernel).
-static int knn_prefiltered(vsc_index* idx, const float* qp, int64_t nq, int k, float* ds, int64_t* dj) {
-    const int64_t nr = idx->ntotal;
-    // Subset size: the exact pass costs ~2*dim*S / 1e14 s per row, every later hit (k * nr / S per row)
-    // ~3 ns of re-scoring and sorting: the sum is smallest near S = sqrt(300 * k * nr) for dim = 512.
-    static const double subset_factor = getenv("VSC_KNN_SUBSET") ? atof(getenv("VSC_KNN_SUBSET")) : 300.0;
-    const int64_t S = std::min<int64_t>(
-        nr, round_up64(std::max<int64_t>((int64_t)std::sqrt(subset_factor * k * (double)nr), 4096), ROW_PAD));
-    if (S < k) return VSC_ERR_OVERFLOW;
-    VSC_TRY(knn_exact_ip(idx, qp, nq, S, k, ds, dj));
-    const int64_t rows_h = round_up64(nq, ROW_PAD_H) + ROW_PAD_H;
-    VSC_TRY(idx->ws.rowthr.reserve((size_t)rows_h * 4));
-    VSC_TRY(launch_knn_row_thr(ds, nq, k, idx->ws.rowthr.as<float>(), rows_h, idx->stream));
-    // expected hits: k * nr / S per row (plus the filter's inflation); generous factor, bounded by the matrix
+// One thresholded pass of the pre-filtered k-NN: fp16 pre-filter + exact stage of all query rows against the first
+// `nrefs` references with the per-row thresholds in ws.rowthr, then (row asc, score desc, ref asc) order cut at k
+// -> ds / dj.  `per_row` = expected hits per query row.  VSC_ERR_OVERFLOW when the estimate was too small.
+static int knn_threshold_pass(vsc_index* idx, const float* qp, int64_t nq, int64_t nrefs, int k, double per_row, float* ds,
+                              int64_t* dj) {
     const int64_t step = 32768;
-    const double per_row = (double)k * ((double)nr / (double)S) * 4.0;
     int64_t cap = (int64_t)((double)nq * per_row) + (1 << 20);
-    cap = std::min<int64_t>(cap, nq * nr + 1024);
+    cap = std::min<int64_t>(cap, nq * nrefs + 1024);
     if (idx->hit_cap_user > 0) cap = idx->hit_cap_user;
     // the candidate list is consumed slab by slab, only the hits accumulate over the whole query set
     const int64_t slab_rows = std::min(nq, step);
-    int64_t ccap = std::min<int64_t>((int64_t)((double)slab_rows * per_row) + (1 << 20), slab_rows * nr + 1024);
+    int64_t ccap = std::min<int64_t>((int64_t)((double)slab_rows * per_row) + (1 << 20), slab_rows * nrefs + 1024);
     ccap = std::min(ccap, std::max<int64_t>(cap, 1024));
     VSC_TRY(ensure_hit_buffers(idx, cap, ccap, false));
     VSC_TRY(init_ctl(idx, 0.0f));
     for (int64_t i0 = 0; i0 < nq; i0 += step)
-        VSC_TRY(enqueue_f16(idx, qp, i0, std::min(nq, i0 + step), cap, idx->ws.rowthr.as<float>(), ccap));
+        VSC_TRY(enqueue_f16(idx, qp, i0, std::min(nq, i0 + step), cap, idx->ws.rowthr.as<float>(), ccap, nrefs));
     SelectCtl h;
     VSC_HIP(hipMemcpyAsync(&h, idx->ws.ctl.p, sizeof(h), hipMemcpyDeviceToHost, idx->stream));
     VSC_HIP(hipStreamSynchronize(idx->stream));
@@ -881,6 +874,56 @@ static int knn_prefiltered(vsc_index* idx, const float* qp, int64_t nq, int k, f
                           (int64_t)h.n, nq, k, idx->ws.w0, idx->ws.w1, idx->ws.w2, idx->ws.w3, idx->ws.tmp, ds, dj,
                           idx->stream));
     return VSC_OK;
+}
+
+// Pre-filtered exact k-NN (inner product).  Any lower bound T_i of a row's final k-th best score is a valid
+// threshold: the k-th best score against a SUBSET of the references is one.
+//   1. exact fp32 k-NN (sim_knn_kernel) against the first S0 references -> T_i(0);
+//   2. (large problems) the fp16 pre-filter + exact stage over the first S1 >> S0 references with T_i(0), cut at k
+//      -> the much tighter T_i(1): the exact kernel runs at 1/10 of the pre-filter's rate, so a small S0 and one
+//      cheap refinement pass beat a large S0;
+//   3. the pre-filter + exact stage over ALL references with the last T_i: every pair whose fp16 score + error bound
+//      reaches T_i goes to the exact stage, which keeps exact score >= T_i -- a superset of the final top-k of every
+//      row (the subset's own top-k included) --, then (row asc, score desc, ref asc) order, cut at k.
+// Same result as knn_exact_ip bit for bit.  Returns VSC_ERR_OVERFLOW when a hit estimate was too small (the caller
+// then runs the exact kernel).
+static int knn_prefiltered(vsc_index* idx, const float* qp, int64_t nq, int k, float* ds, int64_t* dj) {
+    const int64_t nr = idx->ntotal;
+    static const double subset_factor = getenv("VSC_KNN_SUBSET") ? atof(getenv("VSC_KNN_SUBSET")) : 300.0;
+    static const bool two_level = !(getenv("VSC_KNN_LEVELS") && getenv("VSC_KNN_LEVELS")[0] == '1');
+    // one level: S0 = sqrt(300 k nr) balances the exact pass (~2 dim S0 / 1e14 s per row) against the per-hit cost of
+    // the final pass (k nr / S0 hits per row, ~1 ns each).  Two levels: S0 = 16 k (k^2 nr^2 / 3e5)^(1/3) ... in
+    // practice S0 ~ S_one / 7 and S1 = 16 S0 sit on a flat optimum (measured at 200 k x 2 M, k = 1 and 20)
+    const int64_t S_one = std::min<int64_t>(
+        nr, round_up64(std::max<int64_t>((int64_t)std::sqrt(subset_factor * k * (double)nr), 4096), ROW_PAD));
+    // (VSC_PREFILTER=2, the tests' switch, also forces the refinement on small problems)
+    const int64_t S0_small = std::min<int64_t>(
+        nr, round_up64(std::max<int64_t>(S_one / 7, idx->prefilter_force ? (int64_t)k : 4096), ROW_PAD));
+    const bool refine = two_level && (idx->prefilter_force ? nr >= 2 * S0_small
+                                                           : (nr >= 8 * S_one && (double)nq * (double)nr >= 4e10));
+    const int64_t S0 = refine ? S0_small : S_one;
+    if (S0 < k) return VSC_ERR_OVERFLOW;
+    VSC_TRY(knn_exact_ip(idx, qp, nq, S0, k, ds, dj));
+    const int64_t rows_h = round_up64(nq, ROW_PAD_H) + ROW_PAD_H;
+    VSC_TRY(idx->ws.rowthr.reserve((size_t)rows_h * 4));
+    VSC_TRY(launch_knn_row_thr(ds, nq, k, idx->ws.rowthr.as<float>(), rows_h, idx->stream));
+    int64_t S_last = S0;
+    if (refine) {
+        const int64_t S1 = std::min<int64_t>(nr, round_up64((idx->prefilter_force ? 3 : 16) * S0, F16P_COL_STEP));
+        // expected hits per row: k * S1 / S0 (plus the filter's inflation); generous factor
+        int rc = knn_threshold_pass(idx, qp, nq, S1, k, (double)k * ((double)S1 / (double)S0) * 4.0, ds, dj);
+        if (rc == VSC_OK) {
+            VSC_TRY(launch_knn_row_thr(ds, nq, k, idx->ws.rowthr.as<float>(), rows_h, idx->stream));
+            S_last = S1;
+        } else if (rc != VSC_ERR_OVERFLOW) {
+            return rc;
+        } else {
+            // keep T_i(0): the thresholds in ws.rowthr are still the first level's (ds / dj were not touched
+            // before the overflow was detected)
+            VSC_TRY(launch_knn_row_thr(ds, nq, k, idx->ws.rowthr.as<float>(), rows_h, idx->stream));
+        }
+    }
+    return knn_threshold_pass(idx, qp, nq, nr, k, (double)k * ((double)nr / (double)S_last) * 4.0, ds, dj);
 }
 
 int vsc_index_knn(vsc_index_t* idx, const float* q, int64_t nq, int q_mem, int k, float* out_s,
