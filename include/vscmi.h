@@ -69,7 +69,10 @@ int vsc_device_count(void);
  * every batch / every k-NN regardless of size (tests); VSC_PREFILTER_DENSITY=<fraction> moves the hit
  * density below which a batch of the thresholded search is pre-filtered (default 0.02).  Tuning / debug
  * aids read per call: VSC_KNN_NCHUNK (runs per query tile of the exact k-NN), VSC_SIM_GRID (persistent grid
- * of the exact similarity kernel), VSC_POISON_ALLOC=1 (fresh device buffers filled with 0xFF). */
+ * of the exact similarity kernel), VSC_POISON_ALLOC=1 (fresh device buffers filled with 0xFF); A/B switches:
+ * VSC_F16_KERNEL=ring (handle creation: the 256x256 LDS-ring pre-filter instead of the panel-stationary one),
+ * VSC_KNN_LEVELS=1 (pre-filtered k-NN without the threshold-refinement pass), VSC_KNN_SUBSET=<factor> (size of its
+ * exact subset pass, default 300). */
 int vsc_index_create(int dim, int metric, int device, vsc_index_t** out);
 int vsc_index_destroy(vsc_index_t* idx);
 int vsc_index_add(vsc_index_t* idx, const float* x, int64_t n, int x_mem);
