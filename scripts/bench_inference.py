@@ -10,7 +10,7 @@ import time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 
-from vsc2022_amd.vsc.baseline.inference import (SyntheticVideos, build_sscd_model, run_inference,
+from vsc2022_amd.vsc.baseline.inference import (SyntheticVideos, build_sscd_model, fold_batchnorm, run_inference,
                                                 run_inference_packed)
 
 ap = argparse.ArgumentParser()
@@ -18,6 +18,7 @@ ap.add_argument("--videos", type=int, default=512)
 ap.add_argument("--frames", type=int, default=25)
 ap.add_argument("--batch", type=int, default=32)
 ap.add_argument("--packed-batch", type=int, default=128)
+ap.add_argument("--fold-bn", action="store_true", help="also time the network with its BatchNorms folded into the convolutions")
 args = ap.parse_args()
 dev = torch.device("cuda", 0)
 model = build_sscd_model(device=dev)
@@ -36,3 +37,18 @@ for name, dt in (("fp32", None), ("bf16-autocast", torch.bfloat16), ("fp16-autoc
         dtm = time.perf_counter() - t0
         print(f"{name:14s} {mode:9s} batch<={bs:4d}: {n} frames in {dtm:.2f} s = {n / dtm:8.1f} frames/s "
               f"{args.videos / dtm:7.1f} videos/s")
+if args.fold_bn:
+    fused = fold_batchnorm(model).to(memory_format=torch.channels_last)
+    for name, dt in (("bf16-autocast", torch.bfloat16), ("fp16-autocast", torch.float16)):
+        for bs in (128, 256):
+            for _ in run_inference_packed(fused, warm, dev, bs, dt):
+                pass
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            n = 0
+            for _, d in run_inference_packed(fused, src, dev, bs, dt):
+                n += d.shape[0]
+            torch.cuda.synchronize()
+            dtm = time.perf_counter() - t0
+            print(f"{name:14s} packed, BN folded, batch<={bs:4d}: {n} frames in {dtm:.2f} s = {n / dtm:8.1f} frames/s "
+                  f"{args.videos / dtm:7.1f} videos/s")

@@ -201,3 +201,23 @@ def test_inference_cli_on_the_gpu(gpu, tmp_path):
     with torch.no_grad():
         direct = model(cli.device_transform(frames, cli.InferenceTransforms.RESIZE_320_CENTER)).cpu().numpy()
     assert np.allclose(direct, vfs[1].feature, rtol=1e-3, atol=1e-4)
+
+
+def test_batchnorm_folding_keeps_the_function():
+    from vsc2022_amd.vsc.baseline.inference import build_sscd_model, fold_batchnorm
+
+    model = build_sscd_model(dims=64, seed=2, device="cpu", channels_last=False)
+    # non-trivial BN statistics
+    g = torch.Generator().manual_seed(0)
+    for mod in model.modules():
+        if isinstance(mod, torch.nn.BatchNorm2d):
+            mod.running_mean.copy_(torch.randn(mod.running_mean.shape, generator=g) * 0.1)
+            mod.running_var.copy_(torch.rand(mod.running_var.shape, generator=g) + 0.5)
+            mod.weight.data.copy_(torch.rand(mod.weight.shape, generator=g) + 0.5)
+            mod.bias.data.copy_(torch.randn(mod.bias.shape, generator=g) * 0.1)
+    fused = fold_batchnorm(model)
+    assert not any(isinstance(m, torch.nn.BatchNorm2d) for m in fused.modules())
+    x = torch.randn(3, 3, 96, 96, generator=g)
+    with torch.no_grad():
+        a, b = model(x), fused(x)
+    assert torch.allclose(a, b, rtol=1e-3, atol=1e-4), (a - b).abs().max()
