@@ -208,3 +208,55 @@ def test_dns_style_fine_similarity_and_custom_aligner_route(gpu):
     m2 = loc2.localize_all([cand])
     assert obj.seen == ["Q1-R1"] and len(m2) == 1 and (m2[0].query_start, m2[0].query_end) == (0.0, float(Lq))
     assert abs(m2[0].score - (qc @ rc.T)[: Lq - 1, : Lr - 1].max()) < 2e-6
+
+
+def test_over_long_videos_run_from_hbm_state(gpu, orc):
+    """Query videos whose working state exceeds the LDS, and references beyond 32767 frames (16-bit indices),
+    take the HBM-state route of the same kernel: boxes equal to the oracle, next to ordinary pairs in one call."""
+    from vsc2022_amd.vcsl.vta import build_vta_model
+
+    rng = np.random.default_rng(7)
+    data = []
+    for t, (lq, lr) in enumerate([(1500, 90), (30, 33000), (40, 60), (2200, 2100)]):
+        sims = rng.normal(0, 0.1, size=(lq, lr)).astype(np.float32)
+        n = min(lq, lr)
+        for k in range(n // 2):
+            sims[k + n // 4, k + n // 5] = 0.9
+        if t == 0:
+            sims = (np.round(sims * 8) / 8).astype(np.float32)   # exact ties: the lazy topological order runs
+        data.append((f"long{t}", sims))
+    for kw in (dict(tn_max_step=5, min_length=4), {}):
+        got = build_vta_model("TN", **kw).forward_sim(data)
+        for (name, sims), (_, boxes) in zip(data, got):
+            assert boxes == orc.tn(sims, **kw), (name, kw)
+        assert sum(len(b) for _, b in got) >= 3
+
+
+def test_fused_localize_over_long_video(gpu, orc):
+    """Fused route (descriptors -> sims -> TN) with a 1400-frame query video: HBM state + similarity slab."""
+    from vsc2022_amd.vsc.baseline.localization import VCSLLocalizationMaxSim
+    from vsc2022_amd.vsc.index import VideoFeature
+    from vsc2022_amd.vsc.metrics import CandidatePair
+
+    rng = np.random.default_rng(8)
+    d = 64
+    queries = _videos(rng, 1, d, 1400, 1400, VideoFeature, "Q") + _videos(rng, 2, d, 20, 40, VideoFeature, "QS")
+    refs = _videos(rng, 1, d, 900, 900, VideoFeature, "R") + _videos(rng, 2, d, 30, 50, VideoFeature, "RS")
+    seg = refs[0].feature[100:500] + 0.05 * rng.standard_normal((400, d)).astype(np.float32)
+    queries[0].feature[700:1100] = seg / np.linalg.norm(seg, axis=1, keepdims=True)
+    kw = dict(tn_max_step=5, min_length=4)
+    loc = VCSLLocalizationMaxSim(queries, refs, "TN", similarity_bias=0.5, **kw)
+    cands = [CandidatePair(q.video_id, r.video_id, 1.0) for q in queries for r in refs]
+    got = loc.localize_all(cands)
+    exp = []
+    for c in cands:
+        q, r = loc.queries[c.query_id], loc.refs[c.ref_id]
+        sims = orc.pair_sims(q.feature, r.feature, 0.5)
+        for (x1, y1, x2, y2) in orc.tn(sims, **kw):
+            exp.append((c.query_id, c.ref_id, np.float32(sims[x1:x2, y1:y2].max() - np.float32(0.5)),
+                        q.timestamps[x1][0], q.timestamps[x2][1], r.timestamps[y1][0], r.timestamps[y2][1]))
+    assert len(got) == len(exp) and len(exp) >= 1
+    for g, e in zip(got, exp):
+        assert (g.query_id, g.ref_id) == (e[0], e[1])
+        assert np.float32(g.score).view(np.uint32) == e[2].view(np.uint32)
+        assert (g.query_start, g.query_end, g.ref_start, g.ref_end) == e[3:]

@@ -1152,72 +1152,85 @@ int vsc_row_normalize(const float* x, int64_t n, int dim, int x_mem, float* out,
 // Split the pairs of one call into launches by LDS footprint and run them.  `base` carries
 // everything except the per-launch fields.  In forward_sim mode (base.sims_in set) tiles are read
 // in place; otherwise they live in LDS when they fit the launch's budget and spill to `slab`.
+// Pairs whose working state does not fit LDS, or whose node / frame indices do not fit 16 bits
+// (query videos beyond ~1000 frames at the default parameters, references beyond 32767), run
+// from an HBM state slab with 32-bit indices, in chunks of bounded memory.
 static int tn_run_buckets(TnPairArgs base, const std::vector<int32_t>& lqs, const std::vector<int32_t>& lrs,
                           DevBuf& d_work, DevBuf& slab, hipStream_t stream) {
     const int64_t n_pairs = (int64_t)lqs.size();
     const int ms = base.prm.tn_max_step > 1 ? base.prm.tn_max_step : 1;
     const int topc = base.prm.tn_top_k;
     const bool fused = base.sims_in == nullptr;
+    constexpr size_t LDS_STATE_MAX = 150 * 1024;
+    constexpr int64_t BIG_CHUNK_BYTES = (int64_t)4 << 30;  // state + similarity slab of one launch of the HBM route
     struct Bucket { int max_lq; int64_t max_tile; std::vector<int32_t> work; int seen_lq; int64_t seen_tile; };
-    Bucket buckets[3] = {{64, 4096, {}, 0, 0}, {256, 24576, {}, 0, 0}, {0x7fffffff, 0, {}, 0, 0}};
+    Bucket buckets[4] = {{64, 4096, {}, 0, 0}, {256, 24576, {}, 0, 0}, {0x7fffffff, 0, {}, 0, 0}, {0x7fffffff, 0, {}, 0, 0}};
     for (int64_t p = 0; p < n_pairs; ++p) {
         const int64_t lq = lqs[(size_t)p], lr = lrs[(size_t)p];
-        if (lq > 32000 || lr > 32000) {
-            set_error("TN: videos longer than 32000 frames are not supported");
+        if (lq * std::max<int64_t>(1, topc) * ms * topc > 0x7fff0000LL || lq * lr > ((int64_t)1 << 40)) {
+            set_error("TN: a %lld x %lld frame pair is beyond the supported size", (long long)lq, (long long)lr);
             return VSC_ERR_INVALID;
         }
         int b = 2;
-        if (lq <= 64 && (!fused || lq * lr <= 4096)) b = 0;
+        if (lq * topc + 1 > 32767 || lr > 32767 || tn_state_bytes_host((int)std::max<int64_t>(lq, 1), topc, ms) > LDS_STATE_MAX) b = 3;
+        else if (lq <= 64 && (!fused || lq * lr <= 4096)) b = 0;
         else if (lq <= 256 && (!fused || lq * lr <= 24576)) b = 1;
         buckets[b].work.push_back((int32_t)p);
         buckets[b].seen_lq = std::max<int>(buckets[b].seen_lq, (int)lq);
         buckets[b].seen_tile = std::max<int64_t>(buckets[b].seen_tile, lq * lr);
     }
     VSC_TRY(d_work.reserve((size_t)std::max<int64_t>(n_pairs, 1) * 4));
+    DevBuf big_state;  // HBM route only; released on return
+    struct Release { DevBuf& b; ~Release() { b.release(); } } release_big{big_state};
     int64_t woff = 0;
-    for (int b = 0; b < 3; ++b) {
+    for (int b = 0; b < 4; ++b) {
         Bucket& B = buckets[b];
         if (B.work.empty()) continue;
+        const bool big = b == 3;
         const int max_lq = std::max(1, B.seen_lq);
-        const size_t state = tn_state_bytes_host(max_lq, topc, ms);
-        if (state > 150 * 1024) {
-            set_error("TN: a %d-frame query video needs %zu B of LDS state (limit 150 KiB)", max_lq, state);
-            return VSC_ERR_INVALID;
-        }
+        const size_t state = tn_state_bytes_host(max_lq, topc, ms, big ? 4 : 2);
         int tile_floats = 0;
         int64_t slab_floats = 0;
         if (fused) {
             if (b < 2) tile_floats = (int)std::min<int64_t>(B.seen_tile, B.max_tile);
-            else {
-                slab_floats = (B.seen_tile + 63) / 64 * 64;
-                VSC_TRY(slab.reserve((size_t)slab_floats * 4 * B.work.size()));
+            else slab_floats = (B.seen_tile + 63) / 64 * 64;
+        }
+        // pairs per launch: everything, or as many as the HBM route's memory bound allows
+        int64_t per_launch = (int64_t)B.work.size();
+        if (big) per_launch = std::max<int64_t>(1, std::min<int64_t>(per_launch, BIG_CHUNK_BYTES / (int64_t)(state + (size_t)slab_floats * 4)));
+        if (slab_floats) VSC_TRY(slab.reserve((size_t)slab_floats * 4 * (size_t)per_launch));
+        if (big) VSC_TRY(big_state.reserve(state * (size_t)per_launch));
+        const size_t lds = big ? 0 : state + (size_t)tile_floats * 4;
+        for (int64_t c0 = 0; c0 < (int64_t)B.work.size(); c0 += per_launch) {
+            const int64_t cn = std::min<int64_t>(per_launch, (int64_t)B.work.size() - c0);
+            int32_t* dwork = d_work.as<int32_t>() + woff;
+            VSC_HIP(hipMemcpyAsync(dwork, B.work.data() + c0, (size_t)cn * 4, hipMemcpyHostToDevice, stream));
+            TnPairArgs a = base;
+            a.work = dwork;
+            a.n_work = (int)cn;
+            a.max_lq = max_lq;
+            a.lds_tile_floats = tile_floats;
+            a.slab = slab.as<float>();
+            a.slab_floats = slab_floats;
+            a.state = big ? big_state.as<char>() : nullptr;
+            a.state_bytes = (int64_t)state;
+            // algorithmic bytes of the launch: the descriptor rows of every pair once (fused) or its matrix
+            // (forward_sim), + the boxes out
+            double bytes = 0.0;
+            for (int64_t x = c0; x < c0 + cn; ++x) {
+                const int32_t p = B.work[(size_t)x];
+                const double lq = lqs[(size_t)p], lr = lrs[(size_t)p];
+                bytes += fused ? 4.0 * base.dpad * (lq + lr) : 4.0 * lq * lr;
+                bytes += 4.0 + 20.0 * VSC_TN_MAX_BOXES;
             }
+            AuxTimer tm;
+            tm.begin(1, stream);
+            VSC_TRY(launch_tn_pairs(a, lds, stream));
+            tm.end(bytes, stream);
+            VSC_HIP(hipStreamSynchronize(stream));  // B.work (host), the slab and the state are reused
+            tm.collect();
+            woff += cn;
         }
-        const size_t lds = state + (size_t)tile_floats * 4;
-        int32_t* dwork = d_work.as<int32_t>() + woff;
-        VSC_HIP(hipMemcpyAsync(dwork, B.work.data(), B.work.size() * 4, hipMemcpyHostToDevice, stream));
-        TnPairArgs a = base;
-        a.work = dwork;
-        a.n_work = (int)B.work.size();
-        a.max_lq = max_lq;
-        a.lds_tile_floats = tile_floats;
-        a.slab = slab.as<float>();
-        a.slab_floats = slab_floats;
-        // algorithmic bytes of the launch: the descriptor rows of every pair once (fused) or its matrix (forward_sim),
-        // + the boxes out
-        double bytes = 0.0;
-        for (int32_t p : B.work) {
-            const double lq = lqs[(size_t)p], lr = lrs[(size_t)p];
-            bytes += fused ? 4.0 * base.dpad * (lq + lr) : 4.0 * lq * lr;
-            bytes += 4.0 + 20.0 * VSC_TN_MAX_BOXES;
-        }
-        AuxTimer tm;
-        tm.begin(1, stream);
-        VSC_TRY(launch_tn_pairs(a, lds, stream));
-        tm.end(bytes, stream);
-        VSC_HIP(hipStreamSynchronize(stream));  // B.work (host) and the slab are reused
-        tm.collect();
-        woff += (int64_t)B.work.size();
     }
     return VSC_OK;
 }

@@ -79,6 +79,8 @@ struct TnPairArgs {
     int32_t* out_nbox; int32_t* out_boxes; float* out_boxmax;
     // forward_sim mode (sims_in != nullptr): precomputed matrices, pair p at sims_in + sims_off[p]
     const float* sims_in; const int64_t* sims_off; const int32_t* sims_lq; const int32_t* sims_lr;
+    // over-long videos: per-workgroup working state in HBM (state_bytes each) instead of LDS; nullptr = LDS
+    char* state; int64_t state_bytes;
 };
 struct TnSimsArgs { const float* qfeat; const float* rfeat; int64_t qrow0, rrow0; int lq, lr, dpad; float bias; float* out; };
 
@@ -109,7 +111,7 @@ int pair_max_device(const int32_t*, const int32_t*, const float*, int64_t, const
                     int64_t, int64_t*, hipStream_t);
 int launch_pack_rows(const float*, int64_t, int, float*, int64_t, int, hipStream_t);
 int launch_row_normalize(const float*, int64_t, int, float*, hipStream_t);
-size_t tn_state_bytes_host(int, int, int);
+size_t tn_state_bytes_host(int, int, int, int idx_bytes = 2);
 int launch_tn_pairs(const TnPairArgs&, size_t, hipStream_t);
 int launch_tn_sims(const TnSimsArgs&, hipStream_t);
 

@@ -28,20 +28,27 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 
-struct TnState {
+// IDX: type of the stored reference / node indices -- short while the working state lives in LDS (<= 32767 nodes
+// and frames), int for over-long videos whose state lives in an HBM slab
+template <class IDX>
+struct TnStateT {
     int lq, lr, top, ms, n_nodes, sink, sink_q, sink_r;
     float min_sim;
-    const short* tidx;
+    const IDX* tidx;
     const float* tsim;
-    const short* ilo;
-    const short* ihi;
+    const IDX* ilo;
+    const IDX* ihi;
 };
 
-__device__ __forceinline__ int tn_node_q(const TnState& g, int v) { return v == 0 ? -1 : (v - 1) / g.top; }
-__device__ __forceinline__ int tn_node_k(const TnState& g, int v) { return (v - 1) % g.top; }
-__device__ __forceinline__ int tn_node_r(const TnState& g, int v) { return v == 0 ? -1 : g.tidx[v - 1]; }
+template <class IDX>
+__device__ __forceinline__ int tn_node_q(const TnStateT<IDX>& g, int v) { return v == 0 ? -1 : (v - 1) / g.top; }
+template <class IDX>
+__device__ __forceinline__ int tn_node_k(const TnStateT<IDX>& g, int v) { return (v - 1) % g.top; }
+template <class IDX>
+__device__ __forceinline__ int tn_node_r(const TnStateT<IDX>& g, int v) { return v == 0 ? -1 : g.tidx[v - 1]; }
 
-__device__ __forceinline__ bool tn_edge_ok(const TnState& g, int qi, int a, int d, int b) {
+template <class IDX>
+__device__ __forceinline__ bool tn_edge_ok(const TnStateT<IDX>& g, int qi, int a, int d, int b) {
     const int qj = qi + d;
     const int ra = g.tidx[qi * g.top + a], rb = g.tidx[qj * g.top + b];
     const int rd = rb - ra;
@@ -51,13 +58,15 @@ __device__ __forceinline__ bool tn_edge_ok(const TnState& g, int qi, int a, int 
     return g.tsim[qj * g.top + b] >= g.min_sim;
 }
 
-__device__ __forceinline__ bool tn_sink_ok(const TnState& g, int u) {
+template <class IDX>
+__device__ __forceinline__ bool tn_sink_ok(const TnStateT<IDX>& g, int u) {
     if (u == g.sink) return false;
     const int qu = tn_node_q(g, u), ru = tn_node_r(g, u);
     return g.sink_q > qu && g.sink_r > ru && g.sink_q - qu <= g.ms && g.sink_r - ru <= g.ms;
 }
 
-__device__ __forceinline__ int tn_edge_bit(const TnState& g, int qi, int a, int d, int b) {
+template <class IDX>
+__device__ __forceinline__ int tn_edge_bit(const TnStateT<IDX>& g, int qi, int a, int d, int b) {
     return (((qi + d) * g.top + b) * g.ms + d) * g.top + a;
 }
 
@@ -75,8 +84,12 @@ __device__ __forceinline__ void wave_first_max(float& v, int& o) {
 }
 
 
+template <class IDX, bool GSTATE>
 __global__ __launch_bounds__(64) void tn_pair_kernel(TnPairArgs a) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
+    extern __shared__ __attribute__((aligned(16))) char smem_lds[];
+    // working state: LDS, or this workgroup's slice of the HBM state slab (over-long videos; a single wavefront per
+    // workgroup, so the workgroup barriers below order its accesses there as well)
+    char* const smem = GSTATE ? a.state + (int64_t)blockIdx.x * a.state_bytes : smem_lds;
     const int lane = threadIdx.x;
     if ((int)blockIdx.x >= a.n_work) return;
     const int pidx = a.work[blockIdx.x];
@@ -106,15 +119,15 @@ __global__ __launch_bounds__(64) void tn_pair_kernel(TnPairArgs a) {
 
     // ---- LDS carve (one dynamic array; offsets mirror tn_state_bytes) ----
     size_t off = 0;
-    short* tidx = reinterpret_cast<short*>(smem + off);
-    off += (size_t)a.max_lq * top_cap * 2;
+    IDX* tidx = reinterpret_cast<IDX*>(smem + off);
+    off += (size_t)a.max_lq * top_cap * sizeof(IDX);
     off = (off + 15) & ~(size_t)15;
     float* tsim = reinterpret_cast<float*>(smem + off);
     off += (size_t)a.max_lq * top_cap * 4;
-    short* ilo = reinterpret_cast<short*>(smem + off);
-    off += (size_t)a.max_lq * ms * 2;
-    short* ihi = reinterpret_cast<short*>(smem + off);
-    off += (size_t)a.max_lq * ms * 2;
+    IDX* ilo = reinterpret_cast<IDX*>(smem + off);
+    off += (size_t)a.max_lq * ms * sizeof(IDX);
+    IDX* ihi = reinterpret_cast<IDX*>(smem + off);
+    off += (size_t)a.max_lq * ms * sizeof(IDX);
     off = (off + 15) & ~(size_t)15;
     unsigned int* zero = reinterpret_cast<unsigned int*>(smem + off);
     const int zero_words = (lq * top * ms * top + 31) / 32;
@@ -122,12 +135,12 @@ __global__ __launch_bounds__(64) void tn_pair_kernel(TnPairArgs a) {
     off = (off + 15) & ~(size_t)15;
     float* dist = reinterpret_cast<float*>(smem + off);
     off += (size_t)(1 + a.max_lq * top_cap) * 4;
-    short* par = reinterpret_cast<short*>(smem + off);
-    off += (size_t)(1 + a.max_lq * top_cap) * 2;
-    short* order = reinterpret_cast<short*>(smem + off);
-    off += (size_t)(1 + a.max_lq * top_cap) * 2;
-    short* indeg = reinterpret_cast<short*>(smem + off);
-    off += (size_t)(1 + a.max_lq * top_cap) * 2;
+    IDX* par = reinterpret_cast<IDX*>(smem + off);
+    off += (size_t)(1 + a.max_lq * top_cap) * sizeof(IDX);
+    IDX* order = reinterpret_cast<IDX*>(smem + off);
+    off += (size_t)(1 + a.max_lq * top_cap) * sizeof(IDX);
+    IDX* indeg = reinterpret_cast<IDX*>(smem + off);
+    off += (size_t)(1 + a.max_lq * top_cap) * sizeof(IDX);
     off = (off + 15) & ~(size_t)15;
     int* boxes = reinterpret_cast<int*>(smem + off);
     off += (size_t)VSC_TN_MAX_BOXES * 16;
@@ -205,7 +218,7 @@ __global__ __launch_bounds__(64) void tn_pair_kernel(TnPairArgs a) {
 #pragma unroll
                 for (int e = 0; e < 8; ++e)
                     if (e < top) {
-                        tidx[q * top + e] = (short)ti[e];
+                        tidx[q * top + e] = (IDX)ti[e];
                         tsim[q * top + e] = ts[e];
                     }
             }
@@ -228,7 +241,7 @@ __global__ __launch_bounds__(64) void tn_pair_kernel(TnPairArgs a) {
                 }
                 wave_first_max(bs, br);
                 if (lane == 0) {
-                    tidx[q * top + e] = (short)br;
+                    tidx[q * top + e] = (IDX)br;
                     tsim[q * top + e] = bs;
                 }
                 prev_s = bs;
@@ -238,7 +251,7 @@ __global__ __launch_bounds__(64) void tn_pair_kernel(TnPairArgs a) {
     }
     __syncthreads();
 
-    TnState g;
+    TnStateT<IDX> g;
     g.lq = lq; g.lr = lr; g.top = top; g.ms = ms; g.n_nodes = n_nodes; g.sink = n_nodes - 1;
     g.sink_q = lq - 1;
     g.sink_r = tidx[(lq - 1) * top + top - 1];
@@ -249,8 +262,8 @@ __global__ __launch_bounds__(64) void tn_pair_kernel(TnPairArgs a) {
     for (int qi = lane; qi < lq; qi += 64) {
         int lo = 1, hi = 0;
         for (int d = 1; d < ms; ++d) {
-            ilo[qi * ms + d] = (short)lo;
-            ihi[qi * ms + d] = (short)hi;
+            ilo[qi * ms + d] = (IDX)lo;
+            ihi[qi * ms + d] = (IDX)hi;
             if (qi + d >= lq) continue;
             int nlo = lo, nhi = hi;
             for (int b = 0; b < top; ++b) {
@@ -318,10 +331,10 @@ __global__ __launch_bounds__(64) void tn_pair_kernel(TnPairArgs a) {
                     if (mine && o == 0) {
                         if (oo < 0 || !(c >= 0.0f)) {
                             dist[v] = 0.0f;
-                            par[v] = (short)v;
+                            par[v] = (IDX)v;
                         } else {
                             dist[v] = c;
-                            par[v] = (short)(1 + (qj - (ms - 1 - oo / top)) * top + oo % top);
+                            par[v] = (IDX)(1 + (qj - (ms - 1 - oo / top)) * top + oo % top);
                         }
                     }
                 }
@@ -384,10 +397,10 @@ __global__ __launch_bounds__(64) void tn_pair_kernel(TnPairArgs a) {
                 if (lane == 0) {
                     if (arg_node < 0 || !(best >= 0.0f)) {
                         dist[v] = 0.0f;
-                        par[v] = (short)v;
+                        par[v] = (IDX)v;
                     } else {
                         dist[v] = best;
-                        par[v] = (short)arg_node;
+                        par[v] = (IDX)arg_node;
                     }
                 }
             }
@@ -438,13 +451,13 @@ __global__ __launch_bounds__(64) void tn_pair_kernel(TnPairArgs a) {
                             }
                         }
                     }
-                    indeg[v] = (short)deg;
+                    indeg[v] = (IDX)deg;
                 }
                 __syncthreads();
                 if (lane == 0) {
                     int head = 0, tail = 0;
                     for (int v = 0; v < n_nodes; ++v)
-                        if (indeg[v] == 0) order[tail++] = (short)v;
+                        if (indeg[v] == 0) order[tail++] = (IDX)v;
                     while (head < tail) {
                         const int u = order[head++];
                         bool to_sink_regular = false;
@@ -455,11 +468,11 @@ __global__ __launch_bounds__(64) void tn_pair_kernel(TnPairArgs a) {
                                     if (tn_edge_ok(g, qi, aa, d, b)) {
                                         const int v = 1 + (qi + d) * top + b;
                                         if (v == g.sink) to_sink_regular = true;
-                                        if (--indeg[v] == 0) order[tail++] = (short)v;
+                                        if (--indeg[v] == 0) order[tail++] = (IDX)v;
                                     }
                         }
                         if (!to_sink_regular && tn_sink_ok(g, u))
-                            if (--indeg[g.sink] == 0) order[tail++] = (short)g.sink;
+                            if (--indeg[g.sink] == 0) order[tail++] = (IDX)g.sink;
                     }
                 }
                 have_order = true;
@@ -505,7 +518,7 @@ __global__ __launch_bounds__(64) void tn_pair_kernel(TnPairArgs a) {
                 // parent chain in place through `order`-independent scratch: reuse indeg[] as stack.
                 int plen = 0;
                 for (int v = vend;;) {
-                    indeg[plen++] = (short)v;
+                    indeg[plen++] = (IDX)v;
                     if (par[v] == v) break;
                     v = par[v];
                 }
@@ -571,7 +584,7 @@ __global__ __launch_bounds__(64) void tn_pair_kernel(TnPairArgs a) {
             // MaxSim box score: max of sims[q_lo:q_hi, r_lo:r_hi] (half-open, localization.py:91) - bias
             float m = -INFINITY;
             const int w = br1 - br0, h = bq1 - bq0;
-            for (int x = lane; x < w * h; x += 64) {
+            for (int64_t x = lane; x < (int64_t)w * h; x += 64) {
                 const float s = sims[(int64_t)(bq0 + x / w) * lr + br0 + x % w];
                 m = s > m ? s : m;
             }
@@ -593,18 +606,19 @@ __global__ __launch_bounds__(64) void tn_pair_kernel(TnPairArgs a) {
     if (lane == 0) *o_nbox = nbox;
 }
 
-size_t tn_state_bytes_host(int max_lq, int top_cap, int ms) {
+size_t tn_state_bytes_host(int max_lq, int top_cap, int ms, int idx_bytes) {
     const size_t n_nodes = 1 + (size_t)max_lq * top_cap;
+    const size_t ib = (size_t)idx_bytes;
     size_t b = 0;
-    b += (size_t)max_lq * top_cap * 2;
+    b += (size_t)max_lq * top_cap * ib;
     b = (b + 15) & ~(size_t)15;
     b += (size_t)max_lq * top_cap * 4;
-    b += (size_t)max_lq * ms * 2 * 2;
+    b += (size_t)max_lq * ms * ib * 2;
     b = (b + 15) & ~(size_t)15;
     b += ((size_t)max_lq * top_cap * ms * top_cap + 31) / 32 * 4;
     b = (b + 15) & ~(size_t)15;
     b += n_nodes * 4;
-    b += n_nodes * 2 * 3;
+    b += n_nodes * ib * 3;
     b = (b + 15) & ~(size_t)15;
     b += (size_t)VSC_TN_MAX_BOXES * 16;
     b = (b + 63) & ~(size_t)63;
@@ -614,11 +628,16 @@ size_t tn_state_bytes_host(int max_lq, int top_cap, int ms) {
 int launch_tn_pairs(const TnPairArgs& a, size_t lds_bytes, hipStream_t stream) {
     if (a.n_work <= 0) return VSC_OK;
     static PerDeviceOnce once;
+    if (a.state) {  // over-long videos: state in the HBM slab, 32-bit indices
+        hipLaunchKernelGGL((tn_pair_kernel<int, true>), dim3((unsigned)a.n_work), dim3(64), 0, stream, a);
+        VSC_HIP(hipGetLastError());
+        return VSC_OK;
+    }
     if (once.first()) {
-        VSC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(tn_pair_kernel),
+        VSC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&tn_pair_kernel<short, false>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024));
     }
-    hipLaunchKernelGGL(tn_pair_kernel, dim3((unsigned)a.n_work), dim3(64), lds_bytes, stream, a);
+    hipLaunchKernelGGL((tn_pair_kernel<short, false>), dim3((unsigned)a.n_work), dim3(64), lds_bytes, stream, a);
     VSC_HIP(hipGetLastError());
     return VSC_OK;
 }
