@@ -561,6 +561,11 @@ __device__ __forceinline__ void rescore_list(const RescoreArgs& a, float radius,
     }
 }
 
+#ifndef VSC_RESCORE_SHARE
+#define VSC_RESCORE_SHARE 4
+#endif
+constexpr int RESCORE_SHARE = VSC_RESCORE_SHARE;
+
 __global__ __launch_bounds__(256) void rescore_kernel(RescoreArgs a) {
     // After an overflow the candidate list has holes (a wave whose tail reservation did not fit skipped its
     // writes but the tail counter moved on): the host reruns the search with larger buffers, so do nothing
@@ -571,11 +576,14 @@ __global__ __launch_bounds__(256) void rescore_kernel(RescoreArgs a) {
     int pend = 0;
     const float radius = a.row_thr ? 0.0f : *a.radius;
     unsigned long long seen = 0;
-    for (int seg = blockIdx.x; seg < a.n_seg; seg += gridDim.x) {
+    // RESCORE_SHARE workgroups walk one segment together (the segments fill unevenly: more, smaller pieces balance
+    // better and keep more loads in flight)
+    {
+        const int seg = blockIdx.x / RESCORE_SHARE, part = blockIdx.x % RESCORE_SHARE;
         const int n = min(a.seg_count[seg], a.seg_cap);
-        seen += (unsigned long long)n;
+        if (part == 0) seen += (unsigned long long)n;
         rescore_list(a, radius, a.cand_i + (int64_t)seg * a.seg_cap, a.cand_j + (int64_t)seg * a.seg_cap, n,
-                     threadIdx.x, 256, buf, pend);
+                     part * 256 + threadIdx.x, 256 * RESCORE_SHARE, buf, pend);
     }
     // shared tail (normally empty)
     const unsigned long long nt_all = *a.tail_count;
@@ -593,7 +601,7 @@ __global__ void tail_reset_kernel(unsigned long long* tail_count) { *tail_count 
 
 int launch_rescore(const RescoreArgs& a, hipStream_t stream) {
     if (a.n_seg <= 0) return VSC_OK;
-    hipLaunchKernelGGL(rescore_kernel, dim3((unsigned)a.n_seg), dim3(256), 0, stream, a);
+    hipLaunchKernelGGL(rescore_kernel, dim3((unsigned)a.n_seg * RESCORE_SHARE), dim3(256), 0, stream, a);
     hipLaunchKernelGGL(tail_reset_kernel, dim3(1), dim3(1), 0, stream, a.tail_count);
     VSC_HIP(hipGetLastError());
     return VSC_OK;
