@@ -166,6 +166,87 @@ __device__ __forceinline__ void emit_candidates(const SimF16PArgs& a, const bool
         }
 }
 
+// The same, block at a time: every lane gathers the candidates among its 16 values of a flagged 32x32 block in a bit
+// mask, the wave takes an exclusive prefix sum of the per-lane counts (ballots of the counts' bit planes) and every
+// lane writes its own candidates behind it.  ~90 instructions per flagged block whatever it holds, against
+// 6 + ~35 per accumulator register with a candidate: 3-4x fewer in the early, dense batches of the schedule (a dozen
+// candidates per block), slightly fewer in the sparse steady state.
+template <bool ROWTHR>
+__device__ __forceinline__ void emit_candidates_blk(const SimF16PArgs& a, const bool (&all)[2], const float (&thr)[2],
+                                                    const float (&eps)[2], const float* rt, const float (&rtmin)[4],
+                                                    int row0, int col0, bool interior, const f32x16 (&acc)[4][2],
+                                                    const float (&bm)[4][2], int64_t seg_base, int& count) {
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int n = 0; n < 2; ++n) {
+            const bool blk = all[n] || (ROWTHR ? bm[m][n] >= candidate_edge(rtmin[m], eps[n]) : bm[m][n] > thr[n]);
+            if (!__any(blk)) continue;
+            const int ln = lane_now();  // (live inside the block only, see above)
+            const int hi4 = 4 * (ln >> 5);
+            const int j = col0 + n * 32 + (ln & 31);
+            unsigned mask = 0;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int rb = m * 32 + (r & 3) + 8 * (r >> 2);  // + hi4 = row inside the panel
+                bool cand;
+                if (ROWTHR)
+                    cand = acc[m][n][r] >= candidate_edge(rt[rb + hi4], eps[n]);
+                else
+                    cand = acc[m][n][r] > thr[n];
+                cand |= all[n];
+                // (tiles that reach past the batch or the references drop their padding rows / columns)
+                if (!interior) cand &= row0 + rb + hi4 < a.nq;
+                mask |= cand ? (1u << r) : 0u;
+            }
+            if (!interior && j >= a.nr) mask = 0;
+            const int cnt = __popc(mask);
+            unsigned long long pl = __ballot(cnt & 1);
+            int before = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(pl >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)pl, 0u));
+            int total = __popcll(pl);
+            if (__any(cnt > 1)) {
+#pragma unroll
+                for (int b = 1; b < 5; ++b) {
+                    pl = __ballot((cnt >> b) & 1);
+                    before += (int)__builtin_amdgcn_mbcnt_hi((unsigned)(pl >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)pl, 0u)) << b;
+                    total += __popcll(pl) << b;
+                }
+            }
+            if (total == 0) continue;
+            int64_t pos;
+            if (count + total <= a.seg_cap) {
+                pos = seg_base + count;
+                count += total;
+            } else {
+                // segment full (candidates are not spread evenly): shared tail behind the segments
+                unsigned long long base = 0;
+                if (ln == 0) base = atomicAdd(a.tail_count, (unsigned long long)total);
+                base = __shfl(base, 0);
+                if ((long long)(base + total) > a.tail_cap) {
+                    if (ln == 0) atomicOr(a.overflow, 1);
+                    continue;
+                }
+                pos = a.tail_base + (int64_t)base;
+            }
+            pos += before;
+            const int ibase = a.i0 + row0 + m * 32 + hi4;
+            while (mask) {
+                const int r = __ffs(mask) - 1;
+                mask &= mask - 1;
+                a.out_i[pos] = ibase + (r & 3) + 8 * (r >> 2);
+                a.out_j[pos] = j;
+                ++pos;
+            }
+        }
+}
+
+// 1: one ballot per accumulator register (emit_candidates), 2: block at a time, 0: block at a time for the radius
+// search, per register for the k-NN thresholds (the measured best of each: 317 -> 310 ms per bench step; k-NN k = 1
+// 348 against 354 ms)
+#ifndef VSC_F16P_EMIT
+#define VSC_F16P_EMIT 0
+#endif
+
 }  // namespace f16p
 
 template <int NKC, bool ROWTHR>
@@ -316,9 +397,15 @@ __global__ __launch_bounds__(512) void sim_f16p_kernel(SimF16PArgs a) {
                 const float x1 = fmaxf(fmaxf(bm[0][1], bm[1][1]), fmaxf(bm[2][1], bm[3][1]));
                 any_blk |= x0 > thr[0] || x1 > thr[1];
             }
-            if (__any(any_blk))
-                emit_candidates<ROWTHR>(a, all, thr, eps, rt_sh, rtmin, panel * PR, col0,
-                                        panel * PR + PR <= a.nq && col0 + 64 <= a.nr, acc, bm, seg_base, count);
+            if (__any(any_blk)) {
+                const bool interior = panel * PR + PR <= a.nq && col0 + 64 <= a.nr;
+                if (VSC_F16P_EMIT == 2 || (VSC_F16P_EMIT == 0 && !ROWTHR))
+                    emit_candidates_blk<ROWTHR>(a, all, thr, eps, rt_sh, rtmin, panel * PR, col0, interior, acc, bm,
+                                                seg_base, count);
+                else
+                    emit_candidates<ROWTHR>(a, all, thr, eps, rt_sh, rtmin, panel * PR, col0, interior, acc, bm,
+                                            seg_base, count);
+            }
         }
     }
     if (lane == 0) a.seg_count[seg] = count;
