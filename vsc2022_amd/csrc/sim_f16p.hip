@@ -240,11 +240,46 @@ __device__ __forceinline__ void emit_candidates_blk(const SimF16PArgs& a, const 
         }
 }
 
-// 1: one ballot per accumulator register (emit_candidates), 2: block at a time, 0: block at a time for the radius
-// search, per register for the k-NN thresholds (the measured best of each: 317 -> 310 ms per bench step; k-NN k = 1
-// 348 against 354 ms)
+// The radius search's fast path: interior tile, room for a whole tile (8192 entries) left in the wave's segment.  Then
+// nothing needs checking and the per-candidate code shrinks to: position = count + (lanes of this register's ballot
+// below me), two buffer stores with a 32-bit offset into the wave's own segment (rs_i / rs_j: buffer resources on the
+// segment, uniform per wave).  Per flagged block: 16 compares + lane id and column (5 VALU); per register that holds a
+// candidate: 4 VALU + 2 stores -- a third of the instructions of the other two forms.  Everything else (edge tiles,
+// segment nearly full, +inf error bounds, the k-NN thresholds) goes through emit_candidates.
+__device__ __forceinline__ void emit_candidates_seg(const SimF16PArgs& a, const float (&thr)[2], int row0, int col0,
+                                                    const f32x16 (&acc)[4][2], const float (&bm)[4][2],
+                                                    __amdgpu_buffer_rsrc_t rs_i, __amdgpu_buffer_rsrc_t rs_j, int& count) {
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int n = 0; n < 2; ++n) {
+            if (!__any(bm[m][n] > thr[n])) continue;
+            const int ln = lane_now();  // (live inside the block only, see above)
+            const int ibase = a.i0 + row0 + m * 32 + 4 * (ln >> 5);
+            const int j = col0 + n * 32 + (ln & 31);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const bool cand = acc[m][n][r] > thr[n];
+                const unsigned long long hits = __ballot(cand);
+                if (hits == 0ull) continue;
+                if (cand) {
+                    const int off = (count + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(hits >> 32),
+                                                                            __builtin_amdgcn_mbcnt_lo((unsigned)hits, 0u)))
+                                    << 2;
+                    __builtin_amdgcn_raw_buffer_store_b32(ibase + (r & 3) + 8 * (r >> 2), rs_i, off, 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b32(j, rs_j, off, 0, 0);
+                }
+                count += __popcll(hits);
+            }
+        }
+}
+
+// 1: one ballot per accumulator register everywhere (emit_candidates); 2: block at a time everywhere; 0: block at a
+// time for the radius search, per register for the k-NN thresholds; 3 (default): emit_candidates_seg on the fast path
+// of the radius search, per register elsewhere.  Pre-filter time of a bench step: 317 ms (1), 310 (0), 304 (3); the
+// k-NN (k = 1) 348 ms (1, 3) against 354 (2).
 #ifndef VSC_F16P_EMIT
-#define VSC_F16P_EMIT 0
+#define VSC_F16P_EMIT 3
 #endif
 
 }  // namespace f16p
@@ -273,6 +308,11 @@ __global__ __launch_bounds__(512) void sim_f16p_kernel(SimF16PArgs a) {
     const int seg = blockIdx.x * 8 + wave;  // this wave's private segment of the candidate list
     const int64_t seg_base = (int64_t)seg * a.seg_cap;
     int count = 0;
+    // the wave's segment of the two candidate arrays as buffer resources (emit_candidates_seg)
+    const __amdgpu_buffer_rsrc_t rs_ci = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)uniform_ptr(reinterpret_cast<const char*>(a.out_i + seg_base)), 0, a.seg_cap * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_cj = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)uniform_ptr(reinterpret_cast<const char*>(a.out_j + seg_base)), 0, a.seg_cap * 4, 0x00020000);
     const int nslice = (a.nsteps + a.slice - 1) / a.slice;
     int cur_panel = -1;
     float nq_max = 0.f;
@@ -399,7 +439,9 @@ __global__ __launch_bounds__(512) void sim_f16p_kernel(SimF16PArgs a) {
             }
             if (__any(any_blk)) {
                 const bool interior = panel * PR + PR <= a.nq && col0 + 64 <= a.nr;
-                if (VSC_F16P_EMIT == 2 || (VSC_F16P_EMIT == 0 && !ROWTHR))
+                if (VSC_F16P_EMIT == 3 && !ROWTHR && interior && !all[0] && !all[1] && count + 8192 <= a.seg_cap)
+                    emit_candidates_seg(a, thr, panel * PR, col0, acc, bm, rs_ci, rs_cj, count);
+                else if (VSC_F16P_EMIT == 2 || (VSC_F16P_EMIT == 0 && !ROWTHR))
                     emit_candidates_blk<ROWTHR>(a, all, thr, eps, rt_sh, rtmin, panel * PR, col0, interior, acc, bm,
                                                 seg_base, count);
                 else
