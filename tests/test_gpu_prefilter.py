@@ -238,3 +238,27 @@ def test_fp16_subnormal_rows_next_to_the_radius(gpu, orc, case):
     D, I = idx.search(q, 7)
     Do, Io = orc.knn(q, r, 7)
     assert np.array_equal(I, Io) and np.array_equal(bits(D), bits(Do))
+
+
+@pytest.mark.parametrize("seed,nq,nr,d,K", [(21, 3000, 20000, 64, 150000), (22, 2500, 33000, 128, 40000)])
+def test_fast_emission_path_matches_oracle(gpu, orc, seed, nq, nr, d, K):
+    """The radius search's lean emission (sim_f16p.hip emit_candidates_seg) runs only while a whole tile still fits
+    the wave's private segment of the candidate list, i.e. with large hit buffers: raise the capacity so that a
+    medium-sized search takes it (every batch through the pre-filter), planted near-copies make dense blocks."""
+    from vsc2022_amd.vsc.index import FlatIndex
+
+    rng = np.random.default_rng(seed)
+    q, r = unit(rng, nq, d), unit(rng, nr, d)
+    for row in rng.choice(nq, 60, replace=False):           # rows with hundreds of strong hits
+        tgt = rng.choice(nr, 300, replace=False)
+        r[tgt] = q[row] + 0.25 * rng.standard_normal((300, d)).astype(np.float32)
+        r[tgt] /= np.linalg.norm(r[tgt], axis=1, keepdims=True)
+    with prefilter_mode("2"):
+        idx = FlatIndex(d)
+    idx.set_hit_capacity(24_000_000)                        # 2048 segments of > 8192 entries
+    idx.add(r)
+    i, j, s, radius = idx.global_topk(q, K)
+    oi, oj, os_, info = orc.global_threshold_search(q, r, K, 0, return_info=True)
+    assert_same((i, j, s), (oi, oj, os_))
+    assert np.float32(radius) == np.float32(info["radius"])
+    assert search_stats(idx) >= len(os_)
