@@ -154,27 +154,46 @@ __global__ __launch_bounds__(64) void tn_pair_kernel(TnPairArgs a) {
     if (!a.sims_in) {
         const int hi = lane >> 5, l31 = lane & 31;
         const int nkg = a.dpad / 8;
+        // Two column blocks per pass share the A fragments: the phase waits on row loads (2 KB rows from HBM, one
+        // pair's 75 rows are read once), so what counts is the number of loads in flight per wave, not the MFMAs.
         for (int qb = 0; qb < lq; qb += 32)
-            for (int rb = 0; rb < lr; rb += 32) {
+            for (int rb = 0; rb < lr; rb += 64) {
                 // rows past the video end read the (padded) neighbour rows; their results are dropped
+                const bool two = rb + 32 < lr;
                 const float* ap = a.qfeat + (qrow0 + qb + l31) * a.dpad + hi * 4;
-                const float* bp = a.rfeat + (rrow0 + rb + l31) * a.dpad + hi * 4;
-                f32x16 acc;
+                const float* bp0 = a.rfeat + (rrow0 + rb + l31) * a.dpad + hi * 4;
+                const float* bp1 = bp0 + (two ? 32 * (int64_t)a.dpad : 0);
+                f32x16 acc0, acc1;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+                for (int r = 0; r < 16; ++r) acc0[r] = acc1[r] = 0.0f;
+                if (two) {
 #pragma unroll 4
-                for (int g = 0; g < nkg; ++g) {
-                    const f32x4 av = *reinterpret_cast<const f32x4*>(ap + g * 8);
-                    const f32x4 bv = *reinterpret_cast<const f32x4*>(bp + g * 8);
+                    for (int g = 0; g < nkg; ++g) {
+                        const f32x4 av = *reinterpret_cast<const f32x4*>(ap + g * 8);
+                        const f32x4 bv0 = *reinterpret_cast<const f32x4*>(bp0 + g * 8);
+                        const f32x4 bv1 = *reinterpret_cast<const f32x4*>(bp1 + g * 8);
 #pragma unroll
-                    for (int s = 0; s < 4; ++s)
-                        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s], bv[s], acc, 0, 0, 0);
+                        for (int s = 0; s < 4; ++s) {
+                            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s], bv0[s], acc0, 0, 0, 0);
+                            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s], bv1[s], acc1, 0, 0, 0);
+                        }
+                    }
+                } else {
+#pragma unroll 4
+                    for (int g = 0; g < nkg; ++g) {
+                        const f32x4 av = *reinterpret_cast<const f32x4*>(ap + g * 8);
+                        const f32x4 bv = *reinterpret_cast<const f32x4*>(bp0 + g * 8);
+#pragma unroll
+                        for (int s = 0; s < 4; ++s)
+                            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s], bv[s], acc0, 0, 0, 0);
+                    }
                 }
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int q = qb + (r & 3) + 8 * (r >> 2) + 4 * hi;
                     const int rr = rb + l31;
-                    if (q < lq && rr < lr) sims[(int64_t)q * lr + rr] = acc[r] + a.bias;
+                    if (q < lq && rr < lr) sims[(int64_t)q * lr + rr] = acc0[r] + a.bias;
+                    if (two && q < lq && rr + 32 < lr) sims[(int64_t)q * lr + rr + 32] = acc1[r] + a.bias;
                 }
             }
     }
