@@ -9,7 +9,10 @@ restated here are those used at vsc/index.py:11-13,79-82,145-154,169-174 and
 vsc/baseline/score_normalization.py:10,88-89.
 
 Scores come from oracle.scores (ascending-k fp32 fma chain) so that goldens are reproducible
-bit for bit by the HIP path; FAISS itself (BLAS sgemm) pins no summation order.
+bit for bit by the HIP path; FAISS itself (BLAS sgemm) pins no summation order.  `SCORE_MODE = "blas"`
+switches the inner-product scores to `x @ xb.T` (numpy -> the host BLAS sgemm, i.e. what a real FAISS
+flat index computes, in ITS summation order): oracle/eps_band.py runs the reference both ways and counts
+what moves (hard part 2).
 """
 import os
 import sys
@@ -23,6 +26,7 @@ import oracle as _orc  # noqa: E402
 
 METRIC_INNER_PRODUCT = 0
 METRIC_L2 = 1
+SCORE_MODE = "fma"  # "fma": the oracle's ascending-k fp32 fma chain; "blas": numpy sgemm (inner product only)
 
 
 class IndexFlat:
@@ -43,6 +47,8 @@ class IndexFlat:
     def _scores(self, x):
         x = np.ascontiguousarray(x, dtype=np.float32)
         assert x.ndim == 2 and x.shape[1] == self.d
+        if SCORE_MODE == "blas" and self.metric_type == METRIC_INNER_PRODUCT:
+            return np.ascontiguousarray(x @ self._xb.T, dtype=np.float32)
         m = _orc.METRIC_INNER_PRODUCT if self.metric_type == METRIC_INNER_PRODUCT else _orc.METRIC_L2
         return _orc.scores(x, self._xb, m)
 

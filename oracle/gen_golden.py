@@ -16,6 +16,9 @@ Fixtures
   g5_localization_*    VCSLLocalizationMaxSim / CandidateScore .localize_all -> Match rows
   g6_end_to_end        evaluate_descriptor_track-equivalent flow + matching flow: uAP, segment AP
   g7_metrics           random matches -> match_metric / average_precision values of vsc/metrics.py
+  g9_dns_*             VCSLLocalizationDnS (vsc/baseline/dns_baseline.py:108-163) imported from the reference with a seeded
+                       stand-in for the fine-grained student (tests/helpers.py:dns_standin), fg_type "att" and "bin":
+                       similarity matrices of every pair + Match rows of localize_all
   g8_config1_pipeline  BASELINE configs[0] shape (50 x 20 vs 50 x 20 rows, 512-d, K = 60 000), through FILES and
                        the reference's own entry points: evaluate_descriptor_track() and
                        sscd_baseline.main() WITH --score_norm_features (beta 1.2, bias 0.5, MaxSim TN) and
@@ -376,12 +379,46 @@ def gen_g8():
     return "g8_config1_pipeline", out
 
 
+def gen_g9():
+    import matplotlib
+
+    matplotlib.use("Agg")
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import helpers
+    from vsc.baseline.dns_baseline import VCSLLocalizationDnS
+
+    import vsc.baseline.dns_baseline as ref_dns
+    assert ref_dns.__file__.startswith(REFERENCE)
+    cases = []
+    for tag, fg_type, kw in (("att", "att", {}), ("bin", "bin", {}),
+                             ("att_plain", "att", dict(symmetric=False, geometric_mean=False))):
+        q, r, qfine, rfine = helpers.g9_inputs(fg_type)
+        qc, rc = vf(q), vf(r)
+        # the reference's callers pass the fine descriptors as Dict[str, VideoFeature] (dns_baseline.py:260-264)
+        qf = {v.video_id: VideoFeature(video_id=v.video_id, timestamps=v.timestamps, feature=f) for v, f in zip(qc, qfine)}
+        rf = {v.video_id: VideoFeature(video_id=v.video_id, timestamps=v.timestamps, feature=f) for v, f in zip(rc, rfine)}
+        loc = VCSLLocalizationDnS(helpers.dns_standin(fg_type), qf, rf, qc, rc, model_type="TN", tn_max_step=5,
+                                  min_length=4, concurrency=16, similarity_bias=0.5, device="cpu", **kw)
+        cands = [CandidatePair(a.video_id, b.video_id, float(np.float32(0.1 * k)))
+                 for k, (a, b) in enumerate((a, b) for a in qc for b in rc)]
+        sims = [np.asarray(loc.similarity(c), dtype=np.float32) for c in cands]
+        out = dict(fg_type=np.array(fg_type), symmetric=np.bool_(kw.get("symmetric", True)),
+                   geometric_mean=np.bool_(kw.get("geometric_mean", True)),
+                   cand_q=np.array([c.query_id for c in cands]), cand_r=np.array([c.ref_id for c in cands]),
+                   cand_s=np.array([c.score for c in cands], dtype=np.float32),
+                   sims=np.concatenate([x.ravel() for x in sims]),
+                   sim_shapes=np.array([x.shape for x in sims], dtype=np.int64))
+        out.update(match_rows(loc.localize_all(cands)))
+        cases.append((f"g9_dns_{tag}", out))
+    return cases
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--check", action="store_true")
     args = ap.parse_args()
     os.makedirs(GOLDEN, exist_ok=True)
-    fixtures = [gen_g1()] + gen_g2() + [gen_g3(), gen_g4()] + gen_g5() + [gen_g6(), gen_g7(), gen_g8()]
+    fixtures = [gen_g1()] + gen_g2() + [gen_g3(), gen_g4()] + gen_g5() + [gen_g6(), gen_g7(), gen_g8()] + gen_g9()
     bad = 0
     for name, arrays in fixtures:
         path = os.path.join(GOLDEN, name + ".npz")

@@ -61,3 +61,47 @@ def g8_inputs():
             h.update(np.ascontiguousarray(v.feature, dtype=np.float32).tobytes())
             h.update(np.ascontiguousarray(v.timestamps, dtype=np.float32).tobytes())
     return q, r, noise, gts, h.hexdigest()
+
+
+# ---- fixture g9 (DnS localisation): the stand-in for the fine-grained student, shared with oracle/gen_golden.py
+def dns_standin(fg_type):
+    """Chamfer-style region similarity: mean over the query regions of the best reference region.  `fg_type`
+    as the reference reads it (vsc/baseline/dns_baseline.py:134-137): "att" = real-valued region descriptors,
+    "bin" = binary ones (the caller rescales {0, 1} to {-1, +1}; the inner product is divided by the width)."""
+    import torch
+
+    class Chamfer(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.fg_type = fg_type
+            self.student_type = "fg"
+
+        def forward(self, a, b):
+            s = torch.einsum("ird,jsd->ijrs", a, b)
+            if "bin" in self.fg_type:
+                s = s / a.shape[-1]
+            return s.max(dim=3).values.mean(dim=2)
+
+    return Chamfer()
+
+
+G9 = dict(seed=90, n_query=6, n_ref=7, dim=64, q_frames=(12, 45), r_frames=(12, 50), planted_frac=1.0, noise=0.03,
+          copy_len=(8, 30))
+
+
+def g9_inputs(fg_type):
+    """(coarse queries, coarse refs, fine queries, fine refs): the fine descriptors are R = 4 regions x 16 dims per
+    frame, derived from the coarse ones so that planted copies show in both."""
+    from vsc2022_amd import synth
+
+    q, r, _ = synth.make_dataset(**G9)
+    rng = np.random.default_rng(G9["seed"] + 1)
+    proj = rng.standard_normal((4, G9["dim"], 16)).astype(np.float32)
+
+    def fine(v):
+        x = np.einsum("ld,rde->lre", v.feature, proj) + 0.05 * rng.standard_normal((len(v.feature), 4, 16)).astype(np.float32)
+        if "bin" in fg_type:
+            return x > 0
+        return (x / np.linalg.norm(x, axis=-1, keepdims=True)).astype(np.float32)
+
+    return q, r, [fine(v) for v in q], [fine(v) for v in r]

@@ -1,0 +1,225 @@
+"""int8 pre-filter (csrc/sim_i8p.hip + quant_i8.hip) must be INVISIBLE in the results, like the fp16 one.
+
+Batches whose hits are sparse run on v_mfma_i32_32x32x32_i8 over 8-bit images of the rows (one scale per
+reference row, one per 128-row query panel); a pair goes to the exact fp32 stage when its integer score exceeds
+a rigorous lower bound of (radius - eps) / (s_q s_r), eps built from the quantisation residuals that were
+actually produced.  Hits, order and fp32 bit patterns must equal the CPU oracle's (vsc/index.py:142-165 and
+:167-177 semantics) with the int8 kernel forced onto every pre-filtered batch (VSC_PREFILTER=2 VSC_I8=2),
+chosen by the density rule, or switched off (VSC_I8=0).
+"""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def unit(rng, n, d):
+    x = rng.standard_normal((n, d)).astype(np.float32)
+    return x / np.linalg.norm(x, axis=1, keepdims=True)
+
+
+def bits(x):
+    return np.ascontiguousarray(x, dtype=np.float32).view(np.uint32)
+
+
+class env:
+    """VSC_PREFILTER / VSC_I8 are read when an index handle is created."""
+
+    def __init__(self, **kv):
+        self.kv = kv
+
+    def __enter__(self):
+        self.old = {k: os.environ.get(k) for k in self.kv}
+        for k, v in self.kv.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+    def __exit__(self, *exc):
+        for k, v in self.old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
+def forced_index(d):
+    from vsc2022_amd.vsc.index import FlatIndex
+
+    with env(VSC_PREFILTER="2", VSC_I8="2"):
+        return FlatIndex(d)
+
+
+def i8_launches(idx):
+    return idx.profile_read(reset=True)["i8_launches"]
+
+
+def assert_same(a, b):
+    assert len(a[2]) == len(b[2]), (len(a[2]), len(b[2]))
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+    assert np.array_equal(bits(a[2]), bits(b[2]))
+
+
+def test_quantisation_bound_is_a_bound():
+    """The inequality the kernel relies on, checked in float64 on the quantisation the kernel applies:
+    |x.y - s_x s_y (q_x . q_y)| <= E_x N_y + (N_x + E_x) E_y with E = ||x - s q||, N = ||x||."""
+    rng = np.random.default_rng(0)
+    for d, scale in ((512, 1.0), (100, 30.0), (768, 1e-4)):
+        x = (rng.standard_normal((200, d)) * scale * rng.uniform(0.2, 3.0, (200, 1))).astype(np.float32)
+        y = (rng.standard_normal((300, d)) * scale).astype(np.float32)
+        sx = np.float32(np.abs(x).max() / 127.0)                     # one scale for the whole query panel
+        sy = (np.abs(y).max(1, keepdims=True) / 127.0).astype(np.float32)
+        qx = np.clip(np.rint(x / sx), -127, 127)
+        qy = np.clip(np.rint(y / sy), -127, 127)
+        x64, y64 = x.astype(np.float64), y.astype(np.float64)
+        ex = np.linalg.norm(x64 - np.float64(sx) * qx, axis=1)
+        ey = np.linalg.norm(y64 - sy.astype(np.float64) * qy, axis=1)
+        nx, ny = np.linalg.norm(x64, axis=1), np.linalg.norm(y64, axis=1)
+        err = np.abs(x64 @ y64.T - (np.float64(sx) * sy.astype(np.float64).T) * (qx @ qy.T))
+        bound = ex[:, None] * ny[None, :] + (nx + ex)[:, None] * ey[None, :]
+        assert (err <= bound * (1 + 1e-12)).all()
+        assert err.max() > 0.02 * bound.min()                         # and the bound is not absurdly loose
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("nq,nr,d,K", [(700, 3000, 128, 900), (300, 1000, 512, 200), (1100, 5000, 40, 3000),
+                                        (64, 257, 100, 50), (260, 1500, 768, 700), (200, 900, 1000, 400)])
+def test_topk_with_forced_int8_matches_oracle(gpu, orc, nq, nr, d, K):
+    rng = np.random.default_rng(nq + nr + d)
+    q, r = unit(rng, nq, d), unit(rng, nr, d)
+    idx = forced_index(d)
+    idx.profile(True)
+    idx.add(r[: nr // 3 + 7])      # incremental adds that end inside a 64-row tile of the int8 image
+    idx.add(r[nr // 3 + 7:])
+    i, j, s, radius = idx.global_topk(q, K)
+    oi, oj, os_, info = orc.global_threshold_search(q, r, K, 0, return_info=True)
+    assert_same((i, j, s), (oi, oj, os_))
+    assert np.float32(radius) == np.float32(info["radius"])
+    assert i8_launches(idx) > 0    # the int8 kernel really ran
+
+
+@pytest.mark.gpu
+def test_int8_with_ties_duplicates_and_extreme_rows(gpu, orc):
+    """Exact score ties on the re-threshold values; rows of very different norms inside one panel / tile; rows 8 bits
+    cannot tell from zero next to large ones; inf / NaN rows; an all-zero row."""
+    rng = np.random.default_rng(31)
+    r = unit(rng, 2000, 64)
+    r[100:400] = r[100]
+    q = unit(rng, 600, 64)
+    q[50:120] = q[50]
+    q[300:330] = r[100]
+    idx = forced_index(64)
+    idx.add(r)
+    assert_same(idx.global_topk(q, 1500)[:3], orc.global_threshold_search(q, r, 1500))
+
+    q = rng.standard_normal((400, 96)).astype(np.float32) * rng.uniform(0.01, 30.0, (400, 1)).astype(np.float32)
+    r = rng.standard_normal((1500, 96)).astype(np.float32) * rng.uniform(0.01, 30.0, (1500, 1)).astype(np.float32)
+    r[7] *= 1e-6
+    r[8, 3] = 1e6
+    q[9, 0] = 7e4
+    r[10, 5] = np.inf
+    q[11, 2] = np.nan
+    r[12] = 0.0
+    q[13] = 0.0
+    r[14] *= 1e-30                 # scale products far outside the normal range of their inverse
+    q[15] *= 1e-25
+    r[16] *= 1e25
+    idx = forced_index(96)
+    idx.add(r)
+    assert_same(idx.global_topk(q, 2500)[:3], orc.global_threshold_search(q, r, 2500))
+    idx = forced_index(96)         # the same with every row tiny: the radius sits among scores ~1e-50 (flushed to 0)
+    idx.add(r * np.float32(1e-20))
+    assert_same(idx.global_topk(q[16:] * np.float32(1e-20), 2500)[:3],
+                orc.global_threshold_search(q[16:] * np.float32(1e-20), r * np.float32(1e-20), 2500))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("nq,nr,d,k", [(300, 5000, 128, 1), (257, 3000, 512, 20), (64, 200, 40, 64), (1000, 9000, 64, 5),
+                                        (130, 2000, 768, 3)])
+def test_knn_with_forced_int8_matches_oracle(gpu, orc, nq, nr, d, k):
+    rng = np.random.default_rng(nq + nr + k)
+    q, r = unit(rng, nq, d), unit(rng, nr, d)
+    r[10:40] = r[10]               # ties: equal scores must come out in ascending ref order
+    q[5] = r[10]
+    idx = forced_index(d)
+    idx.profile(True)
+    idx.add(r)
+    D, I = idx.search(q, k)
+    oD, oI = orc.knn(q, r, k)
+    assert np.array_equal(I, oI)
+    assert np.array_equal(bits(D), bits(oD))
+    assert i8_launches(idx) > 0
+
+
+@pytest.mark.gpu
+def test_range_search_with_forced_int8(gpu, orc):
+    rng = np.random.default_rng(33)
+    q, r = unit(rng, 500, 128), unit(rng, 2100, 128)
+    idx = forced_index(128)
+    idx.add(r[:900])
+    idx.add(r[900:])
+    lims, D, I = idx.range_search(q, 0.25)
+    olims, oD, oI = orc.range_search(q, r, 0.25)
+    assert np.array_equal(lims, olims) and np.array_equal(I, oI)
+    assert np.array_equal(bits(D), bits(oD))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed,nq,nr,d,K", [(41, 3000, 20000, 64, 150000), (42, 2500, 33000, 128, 40000)])
+def test_int8_fast_emission_path_matches_oracle(gpu, orc, seed, nq, nr, d, K):
+    """emit_candidates_seg of sim_i8p.hip runs while a whole tile still fits the wave's segment (large hit buffers)."""
+    rng = np.random.default_rng(seed)
+    q, r = unit(rng, nq, d), unit(rng, nr, d)
+    for row in rng.choice(nq, 60, replace=False):
+        tgt = rng.choice(nr, 300, replace=False)
+        r[tgt] = q[row] + 0.25 * rng.standard_normal((300, d)).astype(np.float32)
+        r[tgt] /= np.linalg.norm(r[tgt], axis=1, keepdims=True)
+    idx = forced_index(d)
+    idx.set_hit_capacity(24_000_000)
+    idx.add(r)
+    i, j, s, radius = idx.global_topk(q, K)
+    oi, oj, os_, info = orc.global_threshold_search(q, r, K, 0, return_info=True)
+    assert_same((i, j, s), (oi, oj, os_))
+    assert np.float32(radius) == np.float32(info["radius"])
+
+
+@pytest.mark.gpu
+def test_int8_chosen_by_density_equals_fp16_and_fp32_routes(gpu):
+    """Large enough for the density rule to pick the int8 kernel for the late batches; the three device routes must
+    agree bit for bit (hits, order, radius)."""
+    from vsc2022_amd.vsc.index import FlatIndex
+
+    rng = np.random.default_rng(35)
+    q, r = unit(rng, 70000, 128), unit(rng, 120000, 128)
+    K = 300000
+    outs = []
+    for kv in (dict(VSC_I8=None, VSC_PREFILTER=None), dict(VSC_I8="0", VSC_PREFILTER=None), dict(VSC_I8="0", VSC_PREFILTER="0")):
+        with env(**kv):
+            idx = FlatIndex(128)
+        idx.profile(True)
+        idx.add(r)
+        out = idx.global_topk(q, K)
+        outs.append((out, idx.profile_read(reset=True)))
+    assert outs[0][1]["i8_launches"] > 0 and outs[1][1]["i8_launches"] == 0 and outs[1][1]["f16_launches"] > 0
+    assert outs[2][1]["f16_launches"] == 0
+    for other in outs[1:]:
+        assert_same(outs[0][0][:3], other[0][:3])
+        assert outs[0][0][3] == other[0][3]
+
+
+@pytest.mark.gpu
+def test_parity_suites_with_forced_int8():
+    """The search / candidate / golden / sharded / pre-filter parity suites again with the int8 kernel on every
+    pre-filtered batch."""
+    e = dict(os.environ, VSC_PREFILTER="2", VSC_I8="2")
+    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", "tests/test_gpu_search.py",
+                        "tests/test_gpu_edge_cases.py", "tests/test_gpu_golden.py", "tests/test_gpu_sharded.py",
+                        "tests/test_gpu_prefilter.py", "-k", "not forced_prefilter and not fp32_path_at_scale "
+                        "and not chosen_by_size"],
+                       cwd=ROOT, env=e, capture_output=True, text=True, timeout=1800)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]

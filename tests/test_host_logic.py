@@ -186,3 +186,20 @@ def test_install_aliases_reference_module_names():
     out = subprocess.run([sys.executable, "-c", code], cwd=ROOT, capture_output=True, text=True)
     assert out.returncode == 0, out.stderr
     assert out.stdout.split() == ["vsc2022_amd.vsc.index", "vsc2022_amd.vcsl.vta"]
+
+
+def test_install_aliases_the_dns_modules():
+    """`vsc.baseline.dns_baseline` / `dns_index` (reference module names) resolve to the mirrors and export the
+    reference's names (dns_baseline.py:52-290, dns_index.py:36-180)."""
+    import subprocess
+    import sys
+
+    code = ("import vsc2022_amd; vsc2022_amd.install();"
+            "import vsc.baseline.dns_baseline as a, vsc.baseline.dns_index as b;"
+            "assert {'VCSLLocalizationDnS','search','localize_and_verify','match','main','parser'} <= set(dir(a));"
+            "assert {'Accelerator','index_videos','main','parser'} <= set(dir(b));"
+            "assert b.Accelerator['CUDA'].get_device().type == 'cuda' and b.Accelerator['CPU'].get_device().type == 'cpu';"
+            "print(a.__name__, b.__name__)")
+    out = subprocess.run([sys.executable, "-c", code], cwd=ROOT, capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr
+    assert out.stdout.split() == ["vsc2022_amd.vsc.baseline.dns_baseline", "vsc2022_amd.vsc.baseline.dns_index"]

@@ -30,6 +30,8 @@ _ALIASES = {
     "vsc.baseline.score_normalization": "vsc2022_amd.vsc.baseline.score_normalization",
     "vsc.baseline.localization": "vsc2022_amd.vsc.baseline.localization",
     "vsc.baseline.sscd_baseline": "vsc2022_amd.vsc.baseline.sscd_baseline",
+    "vsc.baseline.dns_baseline": "vsc2022_amd.vsc.baseline.dns_baseline",
+    "vsc.baseline.dns_index": "vsc2022_amd.vsc.baseline.dns_index",
     "vcsl": "vsc2022_amd.vcsl",
     "vcsl.vta": "vsc2022_amd.vcsl.vta",
 }

@@ -65,9 +65,11 @@ struct Workspace {
     DevBuf ci, cj, segcnt;  // pre-filter candidates of one batch (per-wave segments + their fill levels)
     DevBuf rowthr;          // per-row thresholds of the pre-filtered k-NN
     DevBuf slices;          // per-panel slice counters of the panel-stationary pre-filter
+    DevBuf q8, pstat;       // int8 image + per-panel {1/s, E, N, s} of ONE launch's query rows (sim_i8p.hip)
     void release() {
         stage.release(); qbuf.release();
         qh.release(); qn.release(); ci.release(); cj.release(); segcnt.release(); rowthr.release(); slices.release();
+        q8.release(); pstat.release();
         for (auto& b : hA) b.release();
         for (auto& b : hB) b.release();
         ctl.release(); w0.release(); w1.release(); w2.release(); w3.release(); tmp.release(); cnt.release();
@@ -86,10 +88,15 @@ struct HalfImage {
     int dpadh = 0;
     bool frag = false;         // fragment-major reference image of the panel-stationary pre-filter (sim_f16p.hip)
     int64_t row0 = 0;          // fragment-major: absolute index of the first row written
+    // optional int8 image of the same rows (quant_i8.hip; fragment-major, same row0 / rows_out)
+    void* i8 = nullptr;        // base of the WHOLE int8 image
+    float4* i8meta = nullptr;  // first meta entry to write
+    int dpad8 = 0;
 };
 
 static int pack_half_any(const float* x, int64_t n, int dim, const HalfImage& h, int64_t r0, int64_t rows_out,
                          hipStream_t stream) {
+    if (h.i8) VSC_TRY(launch_quant_ref_frag(x, n, dim, h.i8, h.i8meta + r0, h.row0 + r0, rows_out, h.dpad8, stream));
     if (h.frag)
         return launch_pack_half_frag(x, n, dim, h.rows, h.norms + r0, h.row0 + r0, rows_out, h.dpadh, stream);
     return launch_pack_half(x, n, dim, h.rows + r0 * h.dpadh, h.norms + r0, rows_out, h.dpadh, stream);
@@ -129,6 +136,12 @@ struct vsc_index {
     DevBuf refh, refn;
     int dpadh = 0;
     bool frag = false;  // refh is fragment-major (dpadh <= 512: panel-stationary pre-filter), else natural
+    // int8 image (dpad8 bytes per row, fragment-major) + per-row {1/s, E, N, s}: the pre-filter of the batches
+    // whose hits are sparse (sim_i8p.hip).  i8_mode: 0 off, 1 chosen per batch by expected hit density, 2 every
+    // pre-filtered batch (tests)
+    DevBuf ref8, ref8m;
+    int dpad8 = 0, i8_mode = 0;
+    double i8_density = 2e-4;
     bool prefilter = false, prefilter_force = false;
     double prefilter_density = 0.02;  // expected hit density below which a batch goes through the pre-filter
     unsigned long long stat_candidates = 0, stat_hits = 0;  // last search (vsc_index_profile_read)
@@ -143,8 +156,9 @@ struct vsc_index {
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
     std::vector<int> ev_class;
     size_t ev_used = 0;
-    double prof_ms[5] = {}, prof_work[5] = {}, pending_work[5] = {};
-    int64_t prof_launches[5] = {};
+    // 5 = int8 pre-filter
+    double prof_ms[6] = {}, prof_work[6] = {}, pending_work[6] = {};
+    int64_t prof_launches[6] = {};
 };
 
 static int prof_begin(vsc_index* idx, hipEvent_t* stop_out, int cls = 0) {
@@ -178,7 +192,7 @@ static int prof_collect(vsc_index* idx) {
         idx->prof_ms[idx->ev_class[e]] += ms;
         idx->prof_launches[idx->ev_class[e]] += 1;
     }
-    for (int c = 0; c < 5; ++c) {
+    for (int c = 0; c < 6; ++c) {
         idx->prof_work[c] += idx->pending_work[c];
         idx->pending_work[c] = 0.0;
     }
@@ -276,6 +290,15 @@ int vsc_index_create(int dim, int metric, int device, vsc_index_t** out) {
         idx->prefilter_force = idx->prefilter && e && e[0] == '2';
         const char* d = getenv("VSC_PREFILTER_DENSITY");
         if (d && atof(d) > 0.0) idx->prefilter_density = atof(d);
+        // VSC_I8=0: no int8 image; VSC_I8=2: every pre-filtered batch goes through the int8 kernel (tests);
+        // VSC_I8_DENSITY: expected hit density below which a batch does (default 2e-4: the looser int8 bound
+        // brings ~4x the candidates, each ~0.44 ns of exact re-scoring, against 0.36 ps saved per pair)
+        idx->dpad8 = round_up(dim, 256);
+        const char* i8 = getenv("VSC_I8");
+        idx->i8_mode = (idx->prefilter && idx->dpad8 <= I8P_MAX_DPAD8 && !(i8 && i8[0] == '0')) ? 1 : 0;
+        if (idx->i8_mode && i8 && i8[0] == '2') idx->i8_mode = 2;
+        const char* dd = getenv("VSC_I8_DENSITY");
+        if (dd && atof(dd) > 0.0) idx->i8_density = atof(dd);
     }
     idx->device = device;
     hipError_t e = hipStreamCreateWithFlags(&idx->stream, hipStreamNonBlocking);
@@ -301,6 +324,8 @@ int vsc_index_destroy(vsc_index_t* idx) {
     idx->ref.release();
     idx->refh.release();
     idx->refn.release();
+    idx->ref8.release();
+    idx->ref8m.release();
     for (auto& b : idx->cand) b.release();
     idx->ws.release();
     for (auto& e : idx->ev_pool) {
@@ -348,11 +373,15 @@ int vsc_index_add(vsc_index_t* idx, const float* x, int64_t n, int x_mem) {
         // grow geometrically; keep the old rows
         int64_t cap = std::max<int64_t>(need_rows, idx->cap_rows + idx->cap_rows / 2);
         cap = round_up64(cap, ROW_PAD_REF);
-        DevBuf nb, nh, nn;
+        DevBuf nb, nh, nn, n8, n8m;
         VSC_TRY(nb.reserve((size_t)cap * idx->dpad * 4));
         if (idx->prefilter) {
             VSC_TRY(nh.reserve((size_t)cap * idx->dpadh * 2));
             VSC_TRY(nn.reserve((size_t)cap * 4));
+        }
+        if (idx->i8_mode) {
+            VSC_TRY(n8.reserve((size_t)cap * idx->dpad8));
+            VSC_TRY(n8m.reserve((size_t)cap * sizeof(float4)));
         }
         if (idx->ntotal > 0) {
             VSC_HIP(hipMemcpyAsync(nb.p, idx->ref.p, (size_t)idx->ntotal * idx->dpad * 4,
@@ -364,14 +393,24 @@ int vsc_index_add(vsc_index_t* idx, const float* x, int64_t n, int x_mem) {
                 VSC_HIP(hipMemcpyAsync(nn.p, idx->refn.p, (size_t)idx->ntotal * 4, hipMemcpyDeviceToDevice,
                                        idx->stream));
             }
+            if (idx->i8_mode) {
+                VSC_HIP(hipMemcpyAsync(n8.p, idx->ref8.p, (size_t)round_up64(idx->ntotal, 64) * idx->dpad8,
+                                       hipMemcpyDeviceToDevice, idx->stream));
+                VSC_HIP(hipMemcpyAsync(n8m.p, idx->ref8m.p, (size_t)idx->ntotal * sizeof(float4), hipMemcpyDeviceToDevice,
+                                       idx->stream));
+            }
             VSC_HIP(hipStreamSynchronize(idx->stream));
         }
         idx->ref.release();
         idx->refh.release();
         idx->refn.release();
+        idx->ref8.release();
+        idx->ref8m.release();
         idx->ref = nb;
         idx->refh = nh;
         idx->refn = nn;
+        idx->ref8 = n8;
+        idx->ref8m = n8m;
         idx->cap_rows = cap;
     }
     float* dst = idx->ref.as<float>() + idx->ntotal * idx->dpad;
@@ -383,6 +422,11 @@ int vsc_index_add(vsc_index_t* idx, const float* x, int64_t n, int x_mem) {
         h.norms = idx->refn.as<float>() + idx->ntotal;
         h.rows_out = need_rows - idx->ntotal;
         h.dpadh = idx->dpadh;
+        if (idx->i8_mode) {
+            h.i8 = idx->ref8.p;
+            h.i8meta = idx->ref8m.as<float4>() + idx->ntotal;
+            h.dpad8 = idx->dpad8;
+        }
     }
     VSC_TRY(pack_into(x, n, idx->dim, x_mem, dst, need_rows - idx->ntotal, idx->dpad, idx->ws, idx->stream, h));
     VSC_HIP(hipStreamSynchronize(idx->stream));
@@ -433,7 +477,7 @@ static int ensure_hit_buffers(vsc_index* idx, int64_t cap, int64_t ccap = -1, bo
 // with score > *radius -- or, when `row_thr` (one threshold per query row, padded like the fp16 query
 // image) is given, with score >= row_thr[row].
 static int enqueue_f16(vsc_index* idx, const float* qpacked, int64_t i0, int64_t i1, int64_t cap,
-                       const float* row_thr, int64_t ccap = -1, int64_t nr_limit = -1) {
+                       const float* row_thr, int64_t ccap = -1, int64_t nr_limit = -1, bool use_i8 = false) {
     if (ccap < 0) ccap = cap;  // capacity of the candidate list (cap: of the hit list)
     // nr_limit: search only the first nr_limit reference rows (threshold refinement of the k-NN)
     const int64_t nrefs = nr_limit >= 0 ? std::min<int64_t>(nr_limit, idx->ntotal) : idx->ntotal;
@@ -456,7 +500,44 @@ static int enqueue_f16(vsc_index* idx, const float* qpacked, int64_t i0, int64_t
         int64_t tail_base = 0;
         long long tail_cap = 0;
         hipEvent_t stop;
-        if (idx->frag) {
+        int pcls = 1;
+        if (use_i8 && idx->i8_mode) {
+            // int8 panel kernel (sim_i8p.hip): this launch's rows are quantised first, one scale per 128-row panel
+            SimI8PArgs f;
+            sim_f16p_plan(nqb, nrefs, &f.npanel, &f.nsteps, &f.slice, &grid);
+            VSC_TRY(idx->ws.slices.reserve((size_t)f.npanel * sizeof(int)));
+            VSC_TRY(idx->ws.q8.reserve((size_t)f.npanel * F16P_PANEL_ROWS * idx->dpad8));
+            VSC_TRY(idx->ws.pstat.reserve((size_t)f.npanel * sizeof(float4)));
+            VSC_TRY(prof_begin(idx, &stop, 5));
+            VSC_TRY(launch_quant_query_panels(qpacked + i0 * idx->dpad, idx->dpad, nqb, f.npanel, idx->ws.q8.p, idx->dpad8,
+                                              idx->ws.pstat.as<float4>(), idx->stream));
+            f.Q = idx->ws.q8.p;
+            f.pstat = idx->ws.pstat.as<float4>();
+            f.Rf = idx->ref8.p;
+            f.rmeta = idx->ref8m.as<float4>();
+            f.dpad8 = idx->dpad8;
+            f.nq = nqb;
+            f.i0 = (int)i0;
+            f.nr = (int)nrefs;
+            f.next_slice = idx->ws.slices.as<int>();
+            // the exact fp32 chain is within dpad 2^-24 |q||r| (1 + tiny) of the real inner product
+            f.c_acc = (float)(((double)idx->dpad + 2.0) * ldexp(1.0, -23));
+            f.radius = &ctl->radius;
+            f.row_thr = row_thr ? row_thr + i0 : nullptr;
+            f.out_i = cand_i;
+            f.out_j = cand_j;
+            seg_cap = (int)std::min<int64_t>(ccap / (grid * 8), 0x7fffffff);
+            tail_base = (int64_t)seg_cap * grid * 8;
+            tail_cap = 2 * ccap - tail_base;
+            f.seg_cap = seg_cap;
+            f.seg_count = idx->ws.segcnt.as<int>();
+            f.tail_base = tail_base;
+            f.tail_cap = tail_cap;
+            f.tail_count = &ctl->n_tail;
+            f.overflow = &ctl->overflow;
+            VSC_TRY(launch_sim_i8p(f, grid, idx->stream));
+            pcls = 5;
+        } else if (idx->frag) {
             // panel-stationary kernel (sim_f16p.hip): LDS-resident query panels x the fragment-major reference image
             SimF16PArgs f;
             sim_f16p_plan(nqb, nrefs, &f.npanel, &f.nsteps, &f.slice, &grid);
@@ -517,7 +598,7 @@ static int enqueue_f16(vsc_index* idx, const float* qpacked, int64_t i0, int64_t
             VSC_TRY(prof_begin(idx, &stop, 1));
             VSC_TRY(launch_sim_f16(f, idx->stream));
         }
-        VSC_TRY(prof_end(idx, stop, 2.0 * (double)nqb * (double)nrefs * (double)idx->dim, 1));
+        VSC_TRY(prof_end(idx, stop, 2.0 * (double)nqb * (double)nrefs * (double)idx->dim, pcls));
         // 2. exact scores of the candidates; those above the radius join the kept hits
         RescoreArgs r;
         r.Q = qpacked;
@@ -550,10 +631,10 @@ static int enqueue_f16(vsc_index* idx, const float* qpacked, int64_t i0, int64_t
 // Append every (row, ref) of query rows [i0, i1) with score > *radius (score space: IP as is, L2
 // negated) to the hit buffer A.
 static int enqueue_batch(vsc_index* idx, const float* qpacked, int64_t i0, int64_t i1, int64_t cap,
-                         bool use_f16 = false) {
+                         bool use_f16 = false, bool use_i8 = false) {
     SelectCtl* ctl = idx->ws.ctl.as<SelectCtl>();
     const int nqb = (int)(i1 - i0);
-    if (use_f16) return enqueue_f16(idx, qpacked, i0, i1, cap, nullptr);
+    if (use_f16) return enqueue_f16(idx, qpacked, i0, i1, cap, nullptr, -1, -1, use_i8);
     if (idx->metric == VSC_METRIC_INNER_PRODUCT) {
         SimThreshArgs a;
         a.Q = qpacked + i0 * idx->dpad;
@@ -637,7 +718,11 @@ int vsc_index_global_topk(vsc_index_t* idx, const float* q, int64_t nq, int q_me
             // (exact: ~7.5 ps per pair; re-scoring: ~0.5 ns per candidate; measured optimum near 2 %).
             const bool f16 = idx->prefilter_force ||
                              (idx->prefilter && i0 > 0 && (double)K < idx->prefilter_density * (double)i0 * (double)idx->ntotal);
-            VSC_TRY(enqueue_batch(idx, qp, i0, i1, cap, f16));
+            // ... and once it is low enough that the int8 kernel's 4-5x candidates cost less than the fp16 kernel's
+            // second half (the bound of 8-bit rows is ~16x looser), the batch runs on int8
+            const bool i8 = f16 && (idx->i8_mode == 2 ||
+                                    (idx->i8_mode == 1 && i0 > 0 && (double)K < idx->i8_density * (double)i0 * (double)idx->ntotal));
+            VSC_TRY(enqueue_batch(idx, qp, i0, i1, cap, f16, i8));
             hipEvent_t stop;
             VSC_TRY(prof_begin(idx, &stop, 3));
             VSC_TRY(enqueue_rethreshold(ctl, idx->ws.hA[0].as<int32_t>(), idx->ws.hA[1].as<int32_t>(),
@@ -771,7 +856,7 @@ int vsc_index_range_search(vsc_index_t* idx, const float* q, int64_t nq, int q_m
     // fixed radius: the pre-filter is used throughout (a radius so low that most pairs pass would
     // overflow the hit capacity on either route)
     for (int64_t i0 = 0; i0 < nq; i0 += step)
-        VSC_TRY(enqueue_batch(idx, qp, i0, std::min(nq, i0 + step), cap, idx->prefilter));
+        VSC_TRY(enqueue_batch(idx, qp, i0, std::min(nq, i0 + step), cap, idx->prefilter, idx->i8_mode == 2));
     SelectCtl h;
     VSC_HIP(hipMemcpyAsync(&h, ctl, sizeof(h), hipMemcpyDeviceToHost, idx->stream));
     VSC_HIP(hipStreamSynchronize(idx->stream));
@@ -852,19 +937,21 @@ static int knn_exact_ip(vsc_index* idx, const float* qp, int64_t nq, int64_t nr,
 // `nrefs` references with the per-row thresholds in ws.rowthr, then (row asc, score desc, ref asc) order cut at k
 // -> ds / dj.  `per_row` = expected hits per query row.  VSC_ERR_OVERFLOW when the estimate was too small.
 static int knn_threshold_pass(vsc_index* idx, const float* qp, int64_t nq, int64_t nrefs, int k, double per_row, float* ds,
-                              int64_t* dj) {
+                              int64_t* dj, bool use_i8 = false) {
     const int64_t step = 32768;
     int64_t cap = (int64_t)((double)nq * per_row) + (1 << 20);
     cap = std::min<int64_t>(cap, nq * nrefs + 1024);
     if (idx->hit_cap_user > 0) cap = idx->hit_cap_user;
     // the candidate list is consumed slab by slab, only the hits accumulate over the whole query set
     const int64_t slab_rows = std::min(nq, step);
-    int64_t ccap = std::min<int64_t>((int64_t)((double)slab_rows * per_row) + (1 << 20), slab_rows * nrefs + 1024);
-    ccap = std::min(ccap, std::max<int64_t>(cap, 1024));
+    // (the int8 bound is looser: ~4-5x the candidates per hit)
+    int64_t ccap = std::min<int64_t>((int64_t)((double)slab_rows * per_row * (use_i8 ? 4.0 : 1.0)) + (1 << 20),
+                                     slab_rows * nrefs + 1024);
+    if (!use_i8) ccap = std::min(ccap, std::max<int64_t>(cap, 1024));
     VSC_TRY(ensure_hit_buffers(idx, cap, ccap, false));
     VSC_TRY(init_ctl(idx, 0.0f));
     for (int64_t i0 = 0; i0 < nq; i0 += step)
-        VSC_TRY(enqueue_f16(idx, qp, i0, std::min(nq, i0 + step), cap, idx->ws.rowthr.as<float>(), ccap, nrefs));
+        VSC_TRY(enqueue_f16(idx, qp, i0, std::min(nq, i0 + step), cap, idx->ws.rowthr.as<float>(), ccap, nrefs, use_i8));
     SelectCtl h;
     VSC_HIP(hipMemcpyAsync(&h, idx->ws.ctl.p, sizeof(h), hipMemcpyDeviceToHost, idx->stream));
     VSC_HIP(hipStreamSynchronize(idx->stream));
@@ -889,6 +976,9 @@ static int knn_threshold_pass(vsc_index* idx, const float* qp, int64_t nq, int64
 // then runs the exact kernel).
 static int knn_prefiltered(vsc_index* idx, const float* qp, int64_t nq, int k, float* ds, int64_t* dj) {
     const int64_t nr = idx->ntotal;
+    // the thresholded passes run on the int8 kernel when the index keeps an int8 image (VSC_I8_KNN=0: fp16)
+    static const bool knn_i8_env = !(getenv("VSC_I8_KNN") && getenv("VSC_I8_KNN")[0] == '0');
+    const bool knn_i8 = idx->i8_mode == 2 || (idx->i8_mode == 1 && knn_i8_env);
     static const double subset_factor = getenv("VSC_KNN_SUBSET") ? atof(getenv("VSC_KNN_SUBSET")) : 300.0;
     static const bool two_level = !(getenv("VSC_KNN_LEVELS") && getenv("VSC_KNN_LEVELS")[0] == '1');
     // one level: S0 = sqrt(300 k nr) balances the exact pass (~2 dim S0 / 1e14 s per row) against the per-hit cost of
@@ -911,7 +1001,7 @@ static int knn_prefiltered(vsc_index* idx, const float* qp, int64_t nq, int k, f
     if (refine) {
         const int64_t S1 = std::min<int64_t>(nr, round_up64((idx->prefilter_force ? 3 : 16) * S0, F16P_COL_STEP));
         // expected hits per row: k * S1 / S0 (plus the filter's inflation); generous factor
-        int rc = knn_threshold_pass(idx, qp, nq, S1, k, (double)k * ((double)S1 / (double)S0) * 4.0, ds, dj);
+        int rc = knn_threshold_pass(idx, qp, nq, S1, k, (double)k * ((double)S1 / (double)S0) * 4.0, ds, dj, knn_i8);
         if (rc == VSC_OK) {
             VSC_TRY(launch_knn_row_thr(ds, nq, k, idx->ws.rowthr.as<float>(), rows_h, idx->stream));
             S_last = S1;
@@ -923,7 +1013,7 @@ static int knn_prefiltered(vsc_index* idx, const float* qp, int64_t nq, int k, f
             VSC_TRY(launch_knn_row_thr(ds, nq, k, idx->ws.rowthr.as<float>(), rows_h, idx->stream));
         }
     }
-    return knn_threshold_pass(idx, qp, nq, nr, k, (double)k * ((double)nr / (double)S_last) * 4.0, ds, dj);
+    return knn_threshold_pass(idx, qp, nq, nr, k, (double)k * ((double)nr / (double)S_last) * 4.0, ds, dj, knn_i8);
 }
 
 int vsc_index_knn(vsc_index_t* idx, const float* q, int64_t nq, int q_mem, int k, float* out_s,
@@ -996,7 +1086,7 @@ int vsc_index_profile(vsc_index_t* idx, int enable) {
 
 int vsc_index_profile_read_class(vsc_index_t* idx, int cls, double* ms, int64_t* launches, double* work,
                                  int reset) {
-    if (!idx || cls < 0 || cls > 4) return VSC_ERR_INVALID;
+    if (!idx || cls < 0 || cls > 5) return VSC_ERR_INVALID;
     if (ms) *ms = idx->prof_ms[cls];
     if (launches) *launches = idx->prof_launches[cls];
     if (work) *work = idx->prof_work[cls];

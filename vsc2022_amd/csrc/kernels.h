@@ -43,6 +43,22 @@ struct SimF16PArgs {
     int seg_cap; int* seg_count; int64_t tail_base; long long tail_cap; unsigned long long* tail_count;
     int* overflow;
 };
+// panel-stationary INT8 pre-filter (sim_i8p.hip; dims <= 1024): the query side is the launch's own int8 image with one
+// scale per 128-row panel (quant_query_panels), the reference side the fragment-major int8 image + per-row meta of
+// launch_quant_ref_frag (quant_i8.hip)
+constexpr int I8P_MAX_DPAD8 = 1024;    // the panel must fit the LDS: 128 rows x dpad8 B <= 128 KiB
+struct SimI8PArgs {
+    const void* Q; const float4* pstat;   // [npanel * 128][dpad8] int8; per panel {1 / s, max E, max N, s}
+    const void* Rf; const float4* rmeta;  // fragment-major int8 image; per reference row {1 / s, E, N, s}
+    int dpad8; int nq; int i0; int nr;
+    int npanel; int nsteps; int slice;     // work split (sim_f16p_plan)
+    int* next_slice;
+    float c_acc;                           // rounding of the exact fp32 chain per |q||r|
+    const float* radius; const float* row_thr;  // as in SimF16Args (row_thr indexed from the launch's first row)
+    int32_t* out_i; int32_t* out_j;
+    int seg_cap; int* seg_count; int64_t tail_base; long long tail_cap; unsigned long long* tail_count;
+    int* overflow;
+};
 struct RescoreArgs {
     const float* Q; const float* R; int dpad;  // packed fp32 images (exact arithmetic contract)
     const int32_t* cand_i; const int32_t* cand_j; int n_seg; int seg_cap; const int* seg_count;
@@ -90,6 +106,9 @@ int sim_f16_grid(int tq, int tr);
 int launch_rescore(const RescoreArgs&, hipStream_t);
 void sim_f16p_plan(int64_t nq, int64_t nr, int* npanel, int* nsteps, int* slice, int* grid);
 int launch_sim_f16p(const SimF16PArgs&, int grid, hipStream_t);
+int launch_sim_i8p(const SimI8PArgs&, int grid, hipStream_t);
+int launch_quant_ref_frag(const float*, int64_t, int, void*, float4*, int64_t, int64_t, int, hipStream_t);
+int launch_quant_query_panels(const float*, int, int, int, void*, int, float4*, hipStream_t);
 int launch_pack_half_frag(const float*, int64_t, int, _Float16*, float*, int64_t, int64_t, int, hipStream_t);
 int launch_pack_half(const float*, int64_t, int, _Float16*, float*, int64_t, int, hipStream_t);
 int launch_sim_knn(const SimKnnArgs&, hipStream_t);

@@ -1,0 +1,182 @@
+// int8 images for the int8 panel pre-filter (sim_i8p.hip), gfx950.  HBM-bound layout transforms.
+//
+// A row x is stored as integers q with x = s (q + e): s > 0 the scale, |q| <= 127, e the rounding / clamping
+// residual.  What the pre-filter's error bound needs from a row is exact bookkeeping, not a particular rounding:
+//     E >= || x - s q ||_2     (computed from the residuals that were actually produced)
+//     N >= || x ||_2
+// so that for two rows  | x . y - s_x s_y (q_x . q_y) | <= E_x N_y + (N_x + E_x) E_y   (Cauchy-Schwarz on
+// x . y - x~ . y~ = (x - x~) . y + x~ . (y - y~), x~ = s q).  Rows holding NaN / inf get N = +inf: the
+// pre-filter then hands every pair of that row to the exact stage.
+//
+//   quant_ref_frag    reference rows: one scale per ROW (max |x| / 127), fragment-major image (the B operand of one
+//                     v_mfma_i32_32x32x32_i8 -- lane l: row l & 31, k bytes 16 (l >> 5) .. + 15 -- is 1 KiB of
+//                     consecutive memory), meta[row] = {1 / s, E, N, s}
+//   quant_query_panels  query rows of ONE launch: one scale per 128-row PANEL (the kernel's epilogue compares the
+//                     integer accumulators of a whole panel against one threshold per reference column), natural
+//                     image [panel rows][dpad8], pstat[panel] = {1 / s, max E, max N, s}
+#include "kernels.h"
+
+namespace vscmi {
+
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+
+// squares below FLT_MIN may flush to zero inside the sums: each such residual is < 1.1e-19 in magnitude
+__device__ __forceinline__ float norm_up(float ss, int d) { return sqrtf(ss) * 1.001f + 2.2e-19f * sqrtf((float)d); }
+
+__device__ __forceinline__ int quant1(float x, float inv_s, float s, float& ss_e) {
+    float q = rintf(x * inv_s);
+    q = fminf(127.0f, fmaxf(-127.0f, q));
+    if (!(q == q)) q = 0.0f;               // NaN input (the row's N is +inf anyway)
+    const float d = __fmaf_rn(-s, q, x);   // the exact residual, rounded once
+    ss_e = __fmaf_rn(d, d, ss_e);
+    return (int)q;
+}
+
+// One wave per row, lane c holds k = 16 c .. 16 c + 15 (dims <= 1024).  `row0` = absolute index of the first row
+// written (incremental adds append to a partly filled 64-row tile); rows [row0 + n, row0 + rows_out) are zero rows.
+__global__ __launch_bounds__(256) void quant_ref_frag_kernel(const float* __restrict__ src, int64_t n, int dim,
+                                                             i32x4* __restrict__ image, float4* __restrict__ meta,
+                                                             int64_t row0, int64_t rows_out, int dpad8) {
+    const int lane = threadIdx.x & 63;
+    const int64_t rel = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (rel >= rows_out) return;
+    const int64_t row = row0 + rel;
+    const int npiece = dpad8 / 16, nks = dpad8 / 32;
+    const float* r = src + rel * dim;
+    float v[16];
+    float amax = 0.0f, ss_n = 0.0f;
+    bool bad = false;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        const int k = lane * 16 + e;
+        const float x = (rel < n && k < dim) ? r[k] : 0.0f;
+        v[e] = x;
+        bad |= !(fabsf(x) <= 3.0e38f);
+        amax = fmaxf(amax, fabsf(x));
+        ss_n = __fmaf_rn(x, x, ss_n);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        amax = fmaxf(amax, __shfl_xor(amax, off));
+        ss_n += __shfl_xor(ss_n, off);
+    }
+    bad = __any(bad);
+    float s = amax / 127.0f;
+    if (bad || !(s > 0.0f) || !(s < 3.0e38f)) s = 1.0f;
+    const float inv_s = 1.0f / s;
+    float ss_e = 0.0f;
+    int b[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) b[e] = bad ? 0 : quant1(v[e], inv_s, s, ss_e);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) ss_e += __shfl_xor(ss_e, off);
+    if (lane < npiece) {
+        i32x4 w;
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+            w[c] = (b[4 * c] & 255) | ((b[4 * c + 1] & 255) << 8) | ((b[4 * c + 2] & 255) << 16) | ((b[4 * c + 3] & 255) << 24);
+        const int ks = lane >> 1, hh = lane & 1;
+        image[((row >> 6) * nks + ks) * 128 + ((row >> 5) & 1) * 64 + hh * 32 + (row & 31)] = w;
+    }
+    if (lane == 0) {
+        float4 m;
+        m.x = inv_s;
+        m.y = bad ? INFINITY : norm_up(ss_e, dim);
+        m.z = bad ? INFINITY : norm_up(ss_n, dim);
+        m.w = s;
+        meta[rel] = m;
+    }
+}
+
+// image: base of the whole fragment-major image; meta: first entry to write (row0's)
+int launch_quant_ref_frag(const float* src, int64_t n, int dim, void* image, float4* meta, int64_t row0,
+                          int64_t rows_out, int dpad8, hipStream_t stream) {
+    if (rows_out <= 0) return VSC_OK;
+    hipLaunchKernelGGL(quant_ref_frag_kernel, dim3((unsigned)((rows_out + 3) / 4)), dim3(256), 0, stream, src, n, dim,
+                       reinterpret_cast<i32x4*>(image), meta, row0, rows_out, dpad8);
+    VSC_HIP(hipGetLastError());
+    return VSC_OK;
+}
+
+// One workgroup per 128-row panel of the launch's query rows; source = the PACKED fp32 image (vscmi_common.h:
+// dpad floats per row, inside every group of 8 the order [k0 k2 k4 k6 | k1 k3 k5 k7], zero padded rows and columns).
+// Thread t: row t >> 2, groups (t & 3), (t & 3) + 4, ...  Two passes over the panel (256 KiB at 512-d: L2-resident).
+__global__ __launch_bounds__(512) void quant_query_panels_kernel(const float* __restrict__ qpacked, int dpad, int nq,
+                                                                 int8_t* __restrict__ q8, int dpad8,
+                                                                 float4* __restrict__ pstat) {
+    __shared__ float red[8];
+    __shared__ unsigned int emax_sh, nmax_sh;
+    __shared__ int bad_sh;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int row = tid >> 2, part = tid & 3;
+    const int64_t grow = (int64_t)blockIdx.x * 128 + row;
+    const float4* src = reinterpret_cast<const float4*>(qpacked + grow * dpad);
+    const int ngroup = dpad / 8, ngroup8 = dpad8 / 8;
+    if (tid == 0) { emax_sh = 0u; nmax_sh = 0u; bad_sh = 0; }
+    float amax = 0.0f;
+    bool bad = false;
+    for (int g = part; g < ngroup; g += 4) {
+        const float4 a = src[2 * g], b = src[2 * g + 1];
+        const float m = fmaxf(fmaxf(fmaxf(fabsf(a.x), fabsf(a.y)), fmaxf(fabsf(a.z), fabsf(a.w))),
+                              fmaxf(fmaxf(fabsf(b.x), fabsf(b.y)), fmaxf(fabsf(b.z), fabsf(b.w))));
+        bad |= !(m <= 3.0e38f) || !(a.x == a.x) || !(a.y == a.y) || !(a.z == a.z) || !(a.w == a.w) || !(b.x == b.x) ||
+               !(b.y == b.y) || !(b.z == b.z) || !(b.w == b.w);
+        amax = fmaxf(amax, m);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) amax = fmaxf(amax, __shfl_xor(amax, off));
+    if (lane == 0) red[wave] = amax;
+    __syncthreads();
+    if (__any(bad) && lane == 0) atomicOr(&bad_sh, 1);
+    amax = fmaxf(fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])), fmaxf(fmaxf(red[4], red[5]), fmaxf(red[6], red[7])));
+    __syncthreads();
+    const bool panel_bad = bad_sh != 0;
+    float s = amax / 127.0f;
+    if (panel_bad || !(s > 0.0f) || !(s < 3.0e38f)) s = 1.0f;
+    const float inv_s = 1.0f / s;
+    float ss_e = 0.0f, ss_n = 0.0f;
+    int8_t* dst = q8 + grow * dpad8;
+    for (int g = part; g < ngroup8; g += 4) {
+        int lo = 0, hi = 0;
+        if (g < ngroup && !panel_bad) {
+            const float4 a = src[2 * g], b = src[2 * g + 1];  // a = k0 k2 k4 k6, b = k1 k3 k5 k7
+            const float x[8] = {a.x, b.x, a.y, b.y, a.z, b.z, a.w, b.w};
+            int q[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                ss_n = __fmaf_rn(x[e], x[e], ss_n);
+                q[e] = quant1(x[e], inv_s, s, ss_e);
+            }
+            lo = (q[0] & 255) | ((q[1] & 255) << 8) | ((q[2] & 255) << 16) | ((q[3] & 255) << 24);
+            hi = (q[4] & 255) | ((q[5] & 255) << 8) | ((q[6] & 255) << 16) | ((q[7] & 255) << 24);
+        }
+        *reinterpret_cast<int2*>(dst + g * 8) = make_int2(lo, hi);
+    }
+    // the four threads of a row are neighbours in the wave
+    ss_e += __shfl_xor(ss_e, 1); ss_e += __shfl_xor(ss_e, 2);
+    ss_n += __shfl_xor(ss_n, 1); ss_n += __shfl_xor(ss_n, 2);
+    if (part == 0 && grow < nq) {  // rows past the batch do not count (they are never reported)
+        atomicMax(&emax_sh, __float_as_uint(norm_up(ss_e, dpad)));  // non-negative floats order like their bits
+        atomicMax(&nmax_sh, __float_as_uint(norm_up(ss_n, dpad)));
+    }
+    __syncthreads();
+    if (tid == 0) {
+        float4 m;
+        m.x = inv_s;
+        m.y = panel_bad ? INFINITY : __uint_as_float(emax_sh);
+        m.z = panel_bad ? INFINITY : __uint_as_float(nmax_sh);
+        m.w = s;
+        pstat[blockIdx.x] = m;
+    }
+}
+
+int launch_quant_query_panels(const float* qpacked, int dpad, int nq, int npanel, void* q8, int dpad8, float4* pstat,
+                              hipStream_t stream) {
+    if (npanel <= 0) return VSC_OK;
+    hipLaunchKernelGGL(quant_query_panels_kernel, dim3((unsigned)npanel), dim3(512), 0, stream, qpacked, dpad, nq,
+                       reinterpret_cast<int8_t*>(q8), dpad8, pstat);
+    VSC_HIP(hipGetLastError());
+    return VSC_OK;
+}
+
+}  // namespace vscmi

@@ -485,7 +485,11 @@ static int launch_nkc(const SimF16PArgs& a, int grid, hipStream_t stream) {
 }
 
 int launch_sim_f16p(const SimF16PArgs& a, int grid, hipStream_t stream) {
-    if (grid <= 0 || a.npanel <= 0 || a.nsteps <= 0) return VSC_OK;
+    if (grid <= 0 || a.npanel <= 0 || a.nsteps <= 0) {
+        // nothing to search: the caller's exact stage must see empty segments, not stale fill levels
+        if (grid > 0) VSC_HIP(hipMemsetAsync(a.seg_count, 0, (size_t)grid * 8 * sizeof(int), stream));
+        return VSC_OK;
+    }
     VSC_HIP(hipMemsetAsync(a.next_slice, 0, (size_t)a.npanel * sizeof(int), stream));
     switch (a.dpadh) {
         case 128: return launch_nkc<1>(a, grid, stream);

@@ -239,7 +239,8 @@ class FlatIndex:
                                                      ctypes.byref(fl), 1 if reset else 0))
         out = {"sim_ms": ms.value, "sim_launches": n.value, "sim_flops": fl.value}
         # per kernel class: fp16 pre-filter GEMM and exact re-scoring of its candidates
-        for cls, name in ((1, "f16"), (2, "rescore"), (3, "select"), (4, "sort")):
+        # (5: the int8 pre-filter of the sparse batches, csrc/sim_i8p.hip)
+        for cls, name in ((1, "f16"), (2, "rescore"), (3, "select"), (4, "sort"), (5, "i8")):
             _lib.check(_lib.lib().vsc_index_profile_read_class(self._h, cls, ctypes.byref(ms), ctypes.byref(n),
                                                                ctypes.byref(fl), 1 if reset else 0))
             out.update({f"{name}_ms": ms.value, f"{name}_launches": n.value, f"{name}_flops": fl.value})
