@@ -8,20 +8,28 @@ workload : BASELINE.json configs[1] shape -- per GPU 200k query frames (8000 vid
            (K = 1200/video) -> (query, ref) max aggregation -> top 25/video candidates ->
            Temporal-Network localisation of the top 5/video pairs.
            All inputs are resident in HBM before the timed region (synthetic, generated on device).
-multi-GPU: one process per GPU (torchrun), queries sharded (weak scaling: every rank brings its own
-           8000 query videos), references replicated, the two global cuts resolved over RCCL
-           (vsc2022_amd/dist.py).
+multi-GPU: one process per GPU, queries sharded, references replicated, the two global cuts resolved over RCCL
+           (vsc2022_amd/dist.py).  `--gpus N` without a launcher re-executes itself under
+           `python -m torch.distributed.run --nproc-per-node N` (127.0.0.1 rendezvous, free port); under
+           torchrun it reads RANK / LOCAL_RANK / WORLD_SIZE.  Two scalings:
+             --scaling weak   (default) every rank brings its own 8000 query videos (configs[1] shape per GPU);
+             --scaling strong BASELINE configs[3] as written: 40000 query videos (1M frames) split N ways,
+                              score normalisation against a 2M-row noise set INSIDE the timed step
+                              (vsc/baseline/sscd_baseline.py:193-204), 2M reference frames replicated.
 
 Prints ONE JSON line on rank 0 (see the driver contract in the task statement); adds
 "roofline" (the dominant kernel, measured live with HIP events on the engine's stream), "kernels"
 (every kernel class of a step: ms, achieved TFLOP/s or GB/s against its peak) and, at N=1,
 "extra" (untimed legs after the headline measurement: the 200k x 2M k-NN of configs[1] as written,
-query-set upload, score normalisation against 2M noise rows, one search on the all-fp32 route) and
+query-set upload, score normalisation against 2M noise rows, one search on the all-fp32 route, and
+BASELINE configs[3] -- the metric's own configuration -- on this one GPU) and
 "cpu_baseline" (the C oracle on the host cores, bounded sample).
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -32,6 +40,7 @@ sys.path.insert(0, ROOT)
 
 FP32_MFMA_PEAK_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md: dense fp32 matrix rate
 FP16_MFMA_PEAK_TFLOPS = 2500.0  # same guide: dense fp16/bf16 matrix rate (sparsity figures excluded)
+INT8_MFMA_PEAK_TOPS = 5000.0    # same guide: int8 runs at 2x the bf16 rate (= the dense FP8 figure, ~5 P op/s)
 
 
 def parse():
@@ -47,7 +56,45 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the untimed k-NN / score-norm / all-fp32 legs")
     ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
+                    help="weak: --query-videos per GPU (configs[1] shape); strong: --total-query-videos split over the "
+                         "GPUs with score normalisation in the timed step (configs[3])")
+    ap.add_argument("--total-query-videos", type=int, default=40000, help="--scaling strong: query videos of the whole job")
+    ap.add_argument("--noise-rows", type=int, default=0, help="score-normalisation noise rows (default: as many as references)")
+    ap.add_argument("--launch-check", action="store_true",
+                    help="only launch the ranks, form the process group (gloo, no GPU needed) and report it")
     return ap.parse_args()
+
+
+def self_launch(args):
+    """`bench.py --gpus N` started without a launcher: run N ranks of this script under torch.distributed.run on
+    this node (what the reference's inference CLI does with torch.multiprocessing, vsc/baseline/inference.py:107-131)."""
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL between processes needs it on this driver
+    env["VSC_BENCH_SELF_LAUNCHED"] = "1"
+    return subprocess.call(cmd, env=env)
+
+
+def process_group_check(torch, dist, world, rank, local_rank, dev, share_gpu):
+    """Every rank must see `world` ranks of the expected backend, one per device (a mis-launched job would otherwise
+    time collectives out minutes later).  Returns what rank 0 reports."""
+    assert dist.get_world_size() == world and dist.get_rank() == rank
+    on_cpu = share_gpu or dev is None
+    seen = torch.zeros(world, dtype=torch.int64, device="cpu" if on_cpu else dev)
+    seen[rank] = 1 + local_rank
+    dist.all_reduce(seen)
+    assert int((seen > 0).sum()) == world, f"rank {rank}: only {int((seen > 0).sum())} of {world} ranks answered"
+    if not on_cpu:
+        assert dist.get_backend() == "nccl" and len(set(seen.tolist())) == world, \
+            f"ranks do not sit on distinct devices of this node: {seen.tolist()}"
+    return {"backend": dist.get_backend(), "ranks_answered": int((seen > 0).sum()),
+            "devices": [int(v) - 1 for v in seen.tolist()],
+            "launcher": "bench.py self-launch" if os.environ.get("VSC_BENCH_SELF_LAUNCHED") == "1" else "external"}
 
 
 def synth_on_device(torch, dev, seed, n_vid, frames, dim, static_frac=0.01):
@@ -174,9 +221,10 @@ def extra_legs(args, torch, dev, matcher, queries, n_qv, qf, n_rv, rf, dim):
         p = idx.profile_read(reset=True)
         knn[f"k{k}"] = {
             "ms": 1e3 * dt, "query_rows_per_s": nq / dt, "algorithmic_tflops": 2.0 * nq * nr * dim / dt / 1e12,
-            "kernel_ms": {"exact_fp32_subset_pass": p["sim_ms"], "fp16_prefilter": p["f16_ms"],
+            "kernel_ms": {"exact_fp32_subset_pass": p["sim_ms"], "int8_prefilter": p["i8_ms"], "fp16_prefilter": p["f16_ms"],
                           "exact_rescore": p["rescore_ms"]},
-            "prefilter_tflops": _rate(p["f16_flops"], p["f16_ms"], 1e12), "candidates": p["candidates"],
+            "prefilter_tops": _rate(p["f16_flops"] + p["i8_flops"], p["f16_ms"] + p["i8_ms"], 1e12),
+            "candidates": p["candidates"],
         }
         del D, I
     out["knn_200k_x_2M"] = knn
@@ -271,14 +319,86 @@ def cpu_baseline_blas(args):
     }
 
 
+def config4_leg(args, torch, dev, dim):
+    """BASELINE configs[3] -- the configuration the metric is quoted on -- on this ONE GPU, untimed extra leg: 40000
+    query videos x 25 frames, 2M reference + 2M noise frames; per query set: score normalisation (row L2 + 1-NN vs
+    the noise set, beta 1.2) -> query upload -> search K = 48M -> 1M candidates -> 200k pairs localised with bias 0.5
+    (vsc/baseline/sscd_baseline.py:185-231).  One warm-up set, one measured set."""
+    import time as _t
+
+    from vsc2022_amd.engine import DeviceMatcher, DeviceScoreNormalizer
+
+    n_qv, qf, n_rv, rf = args.total_query_videos, args.query_frames, args.ref_videos, args.ref_frames
+    n_noise = args.noise_rows or n_rv * rf
+    refs = synth_on_device(torch, dev, args.seed + 300, n_rv, rf, dim)
+    queries = synth_on_device(torch, dev, args.seed + 301, n_qv, qf, dim)
+    plant_copies(torch, dev, args.seed + 302, queries, n_qv, qf, refs, n_rv, rf)
+    noise = synth_on_device(torch, dev, args.seed + 310, n_noise, 1, dim, static_frac=0.0)  # (plant_copies draws from seed + 303)
+    norm = DeviceScoreNormalizer(noise, beta=1.2)
+    del noise
+    m = DeviceMatcher(norm.refs(refs), np.arange(n_rv + 1, dtype=np.int64) * rf, dev.index)
+    del refs
+    q_off = np.arange(n_qv + 1, dtype=np.int64) * qf
+
+    def one_set():
+        torch.cuda.synchronize()
+        t0 = _t.perf_counter()
+        qn = norm.queries(queries)
+        torch.cuda.synchronize()
+        t1 = _t.perf_counter()
+        m.set_queries(qn, q_off)
+        torch.cuda.synchronize()
+        t2 = _t.perf_counter()
+        res = m.match(bias=0.5)
+        torch.cuda.synchronize()
+        t3 = _t.perf_counter()
+        return (t1 - t0, t2 - t1, t3 - t2), res
+
+    one_set()
+    m.index.profile(True)
+    m.index.profile_read(reset=True)
+    _aux(0), _aux(1)
+    (ts, tu, tm), res = one_set()
+    p = m.index.profile_read(reset=True)
+    tn_ms = _aux(1)[0]
+    total = ts + tu + tm
+    out = {
+        "workload": f"BASELINE configs[3] on one GPU: {n_qv} query videos ({n_qv * qf} frames) vs {n_rv * rf} reference + "
+                    f"{n_noise} noise frames, {dim}-d",
+        "ms_per_query_set": 1e3 * total, "score_norm_ms": 1e3 * ts, "query_upload_ms": 1e3 * tu, "search_ms": 1e3 * tm - tn_ms,
+        "tn_ms": tn_ms, "query_videos_per_s": n_qv / total, "hits": res.n_hits, "candidates": res.n_candidates,
+        "pairs_localized": res.n_localized, "matches": res.n_matches,
+        "search_kernel_ms": {"int8_prefilter": p["i8_ms"], "fp16_prefilter": p["f16_ms"], "exact_fp32": p["sim_ms"],
+                             "exact_rescore": p["rescore_ms"], "select": p["select_ms"], "final_sort": p["sort_ms"]},
+    }
+    del m, norm, queries
+    torch.cuda.empty_cache()
+    return out
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args))
     import torch
     import torch.distributed as dist
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.launch_check:
+        # the launch + rendezvous path alone (tests/test_dist_gloo.py runs it on CPU): no GPU is touched
+        pg = {"backend": None, "ranks_answered": 1, "devices": [0], "launcher": "none"}
+        if world > 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+            pg = process_group_check(torch, dist, world, rank, local_rank, None, True)
+            dist.barrier()
+            dist.destroy_process_group()
+        if rank == 0:
+            print(json.dumps({"launch_check": True, "n_gpus": world, "gpus_requested": args.gpus, "process_group": pg}),
+                  flush=True)
+        return
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (gfx950) GPU: the engine has no CPU fallback")
     # VSC_BENCH_SHARE_GPU=1: debugging aid for a 1-GPU box -- all ranks use cuda:0 and the collectives
@@ -288,38 +408,56 @@ def main():
         local_rank = 0
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
+    pg = {"backend": None, "ranks_answered": 1, "devices": [local_rank], "launcher": "none"}
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if share_gpu:
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-        # self-check of the process group before any work: every rank must see `world` ranks of the expected
-        # backend, one per device (a mis-launched job would otherwise time collectives out minutes later)
-        assert dist.get_world_size() == world and dist.get_rank() == rank
-        seen = torch.zeros(world, dtype=torch.int64, device="cpu" if share_gpu else dev)
-        seen[rank] = 1 + local_rank
-        dist.all_reduce(seen)
-        assert int((seen > 0).sum()) == world, f"rank {rank}: only {int((seen > 0).sum())} of {world} ranks answered"
-        if not share_gpu:
-            assert dist.get_backend() == "nccl" and len(set(seen.tolist())) == world, \
-                f"ranks do not sit on distinct devices of this node: {seen.tolist()}"
+        pg = process_group_check(torch, dist, world, rank, local_rank, dev, share_gpu)
 
     from vsc2022_amd import _lib
-    from vsc2022_amd.engine import DeviceMatcher
+    from vsc2022_amd import dist as vdist
+    from vsc2022_amd.engine import DeviceMatcher, DeviceScoreNormalizer
 
-    n_qv, qf, n_rv, rf, dim = args.query_videos, args.query_frames, args.ref_videos, args.ref_frames, args.dim
+    strong = args.scaling == "strong"
+    qf, n_rv, rf, dim = args.query_frames, args.ref_videos, args.ref_frames, args.dim
+    if strong:
+        n_qv_total = args.total_query_videos
+        lo, hi = vdist.shard_ranges(n_qv_total, world)[rank]
+        n_qv, qv_base = hi - lo, lo
+    else:
+        n_qv, qv_base = args.query_videos, rank * args.query_videos
+        n_qv_total = n_qv * world
     refs = synth_on_device(torch, dev, args.seed, n_rv, rf, dim)
     queries = synth_on_device(torch, dev, args.seed + 1000 + rank, n_qv, qf, dim)
     plant_copies(torch, dev, args.seed + 2000 + rank, queries, n_qv, qf, refs, n_rv, rf)
     r_off = np.arange(n_rv + 1, dtype=np.int64) * rf
     q_off = np.arange(n_qv + 1, dtype=np.int64) * qf
-    matcher = DeviceMatcher(refs, r_off, local_rank)
-    matcher.set_queries(queries, q_off)
+    norm = None
+    if strong:
+        # configs[3]: both sides score-normalised against the noise set (resident state, like the reference index);
+        # the QUERY side of it belongs to every query set and is timed
+        noise = synth_on_device(torch, dev, args.seed + 77, args.noise_rows or n_rv * rf, 1, dim, static_frac=0.0)
+        norm = DeviceScoreNormalizer(noise, beta=1.2)
+        del noise
+        matcher = DeviceMatcher(norm.refs(refs), r_off, local_rank)
+        matcher.set_queries(norm.queries(queries), q_off)
+    else:
+        matcher = DeviceMatcher(refs, r_off, local_rank)
+        matcher.set_queries(queries, q_off)
     del refs
     kw = {}
     if world > 1:
-        kw = dict(n_qvid_global=n_qv * world, qvid_base=rank * n_qv, row_base=rank * n_qv * qf)
+        kw = dict(n_qvid_global=n_qv_total, qvid_base=qv_base, row_base=qv_base * qf)
+    if strong:
+        kw["bias"] = 0.5
+
+    def step():
+        if strong:
+            matcher.set_queries(norm.queries(queries), q_off)
+        return matcher.match(**kw)
 
     def barrier():
         if world > 1:
@@ -327,18 +465,22 @@ def main():
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):
-        res = matcher.match(**kw)
+        res = step()
     matcher.index.profile(True)
     matcher.index.profile_read(reset=True)
+    if norm is not None:
+        norm.noise_index.profile(True)
+        norm.noise_index.profile_read(reset=True)
     _lib.check(_lib.lib().vsc_aux_profile(1))
     _aux(0), _aux(1)
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        res = matcher.match(**kw)
+        res = step()
     barrier()
     dt = time.perf_counter() - t0
     prof = matcher.index.profile_read(reset=True)
+    nprof = norm.noise_index.profile_read(reset=True) if norm is not None else None
     pm_ms, pm_calls, pm_bytes = _aux(0)
     tn_ms, tn_calls, tn_bytes = _aux(1)
     if world > 1:
@@ -357,32 +499,43 @@ def main():
             dist.all_gather(hs, h)
         assert all(torch.equal(x, hs[0]) for x in hs), "candidate tables differ between ranks"
     if rank == 0:
-        # HBM-side bytes per launch of the dominant kernel come from the committed PMC passes
-        # (FETCH_SIZE / WRITE_SIZE cannot be sampled from inside the process)
-        traffic, traffic_src = None, None
-        for name in ("r02_roofline.json", "r01_roofline.json"):
-            try:
-                with open(os.path.join(ROOT, "profiles", name)) as fh:
-                    traffic = float(json.load(fh)["hbm_bytes_per_launch"])
-                traffic_src = "profiles/" + name
-                break
-            except Exception:
-                continue
-        total_videos = n_qv * world * args.steps
-        # Dominant kernel: the fp16 pre-filter GEMM (csrc/sim_f16p.hip) when the engine uses it, else
-        # the exact fp32 similarity kernel.  achieved = algorithmic flops (2 * rows * refs * dim of the
-        # launches) / their HIP-event time on the engine's stream.
-        use_f16 = prof.get("f16_ms", 0.0) > prof["sim_ms"]
-        k_ms, k_flops, k_launches = ((prof["f16_ms"], prof["f16_flops"], prof["f16_launches"]) if use_f16
-                                     else (prof["sim_ms"], prof["sim_flops"], prof["sim_launches"]))
-        peak = FP16_MFMA_PEAK_TFLOPS if use_f16 else FP32_MFMA_PEAK_TFLOPS
-        achieved = (k_flops / 1e12) / (k_ms / 1e3) if k_ms > 0 else 0.0
         steps = args.steps
+        # Dominant kernel = the similarity kernel class with the most time on the engine's stream: the int8 panel
+        # pre-filter (csrc/sim_i8p.hip), the fp16 one (csrc/sim_f16p.hip) or the exact fp32 kernel.  achieved =
+        # algorithmic operations (2 * rows * refs * dim of its launches) / their HIP-event time.
+        classes = {
+            "i8": ("sim_i8p_kernel (panel-stationary int8 MFMA pre-filter of the sparse batches, incl. the quantisation "
+                   "of its query panels; exact fp32 re-scoring of its candidates follows)", INT8_MFMA_PEAK_TOPS, "TOP/s"),
+            "f16": ("sim_f16p_kernel (panel-stationary fp16 MFMA pre-filter; exact fp32 re-scoring of its candidates "
+                    "follows)", FP16_MFMA_PEAK_TFLOPS, "TFLOP/s"),
+            "sim": ("sim_thresh_kernel (fp32 MFMA similarity + fused threshold compaction)", FP32_MFMA_PEAK_TFLOPS, "TFLOP/s"),
+        }
+        dom = max(classes, key=lambda c: prof.get(f"{c}_ms", 0.0))
+        k_ms, k_flops, k_launches = prof[f"{dom}_ms"], prof[f"{dom}_flops"], prof[f"{dom}_launches"]
+        peak = classes[dom][1]
+        achieved = (k_flops / 1e12) / (k_ms / 1e3) if k_ms > 0 else 0.0
+        # HBM-side bytes per launch of the dominant kernel come from the committed PMC passes of the SAME kernel
+        # (FETCH_SIZE / WRITE_SIZE cannot be sampled from inside the process): profiles/r03_roofline.json names the
+        # kernel, the commit it was measured at and the rocprofv3 files
+        traffic, traffic_src = None, None
+        try:
+            with open(os.path.join(ROOT, "profiles", "r03_roofline.json")) as fh:
+                rj = json.load(fh)
+            if rj.get("kernel_class") == dom:
+                traffic = float(rj["hbm_bytes_per_launch"])
+                traffic_src = f"profiles/r03_roofline.json, measured at commit {rj.get('commit', '?')}"
+        except Exception:
+            pass
         dpad_bytes = 8 * ((dim + 63) // 64 * 64)  # two packed fp32 rows per re-scored candidate
         cand = prof.get("candidates", 0)
         kernels = {
+            "sim_i8p_kernel (int8 MFMA pre-filter, sparse batches)": {
+                "ms_per_step": prof.get("i8_ms", 0.0) / steps, "launches_per_step": prof.get("i8_launches", 0) / steps,
+                "achieved": _rate(prof.get("i8_flops", 0.0), prof.get("i8_ms", 0.0), 1e12),
+                "peak": INT8_MFMA_PEAK_TOPS, "unit": "TOP/s", "bound": "mfma"},
             "sim_f16p_kernel (fp16 MFMA pre-filter)": {
-                "ms_per_step": prof.get("f16_ms", 0.0) / steps, "achieved": _rate(prof.get("f16_flops", 0.0), prof.get("f16_ms", 0.0), 1e12),
+                "ms_per_step": prof.get("f16_ms", 0.0) / steps, "launches_per_step": prof.get("f16_launches", 0) / steps,
+                "achieved": _rate(prof.get("f16_flops", 0.0), prof.get("f16_ms", 0.0), 1e12),
                 "peak": FP16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "bound": "mfma"},
             "sim_thresh_kernel (exact fp32 MFMA, dense early batches)": {
                 "ms_per_step": prof["sim_ms"] / steps, "achieved": _rate(prof["sim_flops"], prof["sim_ms"], 1e12),
@@ -409,9 +562,22 @@ def main():
                 "unit": "GB/s", "bound": "hbm (latency-bound in practice)",
                 "note": "algorithmic bytes = 4 * dim * (Lq + Lr) per pair + boxes"},
         }
+        if nprof is not None:
+            kernels["score normalisation of the query set (1-NN vs the noise index: exact subset pass + pre-filter + re-scoring)"] = {
+                "ms_per_step": (nprof["sim_ms"] + nprof["f16_ms"] + nprof["i8_ms"] + nprof["rescore_ms"]) / steps,
+                "int8_prefilter_ms_per_step": nprof["i8_ms"] / steps, "fp16_prefilter_ms_per_step": nprof["f16_ms"] / steps,
+                "achieved": _rate(nprof["i8_flops"] + nprof["f16_flops"], nprof["i8_ms"] + nprof["f16_ms"], 1e12),
+                "unit": "T(FL)OP/s of the pre-filter passes"}
         for v in kernels.values():
             if "achieved" in v and v.get("peak"):
                 v["frac"] = v["achieved"] / v["peak"]
+        total_videos = n_qv_total * args.steps
+        if strong:
+            workload = (f"BASELINE configs[3]: full pipeline incl. score normalisation + TN localisation, {n_qv_total} query "
+                        f"videos split over {world} GPU(s), {n_rv * rf} reference + {args.noise_rows or n_rv * rf} noise frames")
+        else:
+            workload = ("BASELINE configs[1]: brute-force cosine search 200k query x 2M ref 512-d fp32 per GPU "
+                        "+ candidates + TN localization (full hot path)")
         out = {
             "metric": "query-videos localized/sec @ 512-d SSCD",
             "value": total_videos / dt,
@@ -421,46 +587,53 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": 1e3 * dt / args.steps,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": args.scaling,
             "vs_baseline": None,
-            "dtype": "fp32 results; fp16 MFMA pre-filter",
+            "dtype": "fp32 results; int8 / fp16 MFMA pre-filters",
             "dtype_note": "every reported score is the exact fp32 fma chain (bit-identical to the all-fp32 "
-                          "path); fp16 MFMA only pre-filters pairs, with a rigorous error bound",
+                          "path); int8 and fp16 MFMA only pre-filter pairs, each with a rigorous error bound",
             "data": "synthetic",
+            "process_group": pg,
             "config": {
-                "workload": "BASELINE configs[1]: brute-force cosine search 200k query x 2M ref 512-d fp32 per GPU "
-                            "+ candidates + TN localization (full hot path)",
+                "workload": workload,
                 "query_videos_per_gpu": n_qv, "query_frames_per_gpu": n_qv * qf, "ref_frames": n_rv * rf,
-                "dim": dim, "global_k": 1200 * n_qv * world, "candidates": res.n_candidates,
+                "dim": dim, "global_k": 1200 * n_qv_total, "candidates": res.n_candidates,
                 "pairs_localized": res.n_localized, "matches": res.n_matches, "hits": res.n_hits,
+                "score_normalisation_in_step": strong,
                 "parallelism": f"query-sharded x{world}" if world > 1 else "single GPU",
             },
             "roofline": {
-                "kernel": ("sim_f16p_kernel (panel-stationary fp16 MFMA pre-filter of the thresholded search; exact "
-                           "fp32 re-scoring of its candidates follows)") if use_f16 else
-                          "sim_thresh_kernel (fp32 MFMA similarity + fused threshold compaction)",
+                "kernel": classes[dom][0],
                 "bound": "mfma",
                 "achieved": achieved,
                 "peak": peak,
-                "unit": "TFLOP/s",
+                "unit": classes[dom][2],
                 "frac": achieved / peak,
                 "traffic": traffic,
-                "traffic_unit": f"bytes/launch (PMC FETCH_SIZE x2 + WRITE_SIZE, {traffic_src})",
+                "traffic_unit": f"bytes/launch (PMC FETCH_SIZE x2 + WRITE_SIZE; {traffic_src})" if traffic else None,
                 "launches": k_launches,
                 "kernel_ms_per_step": k_ms / args.steps,
                 "prefilter_candidates_last_search": cand,
             },
             "kernels": kernels,
         }
-        if world == 1:
+        if world == 1 and not strong:
             # the untimed legs must never cost the headline line: a failure in one of them is reported, not raised
             if not args.no_extra:
                 try:
                     out["extra"] = extra_legs(args, torch, dev, matcher, queries, n_qv, qf, n_rv, rf, dim)
                     ms_fresh = out["ms_per_step"] + out["extra"]["set_queries_ms"]
                     out["extra"]["value_with_fresh_query_set"] = n_qv / (ms_fresh / 1e3)
+                    # the same query set WITH its score normalisation (configs[3]'s extra stage at this shape)
+                    out["value_with_score_norm"] = n_qv / ((ms_fresh + out["extra"]["score_normalize_queries_ms"]) / 1e3)
                 except Exception as exc:  # noqa: BLE001
                     out["extra_error"] = f"{type(exc).__name__}: {exc}"
+                try:
+                    del matcher
+                    torch.cuda.empty_cache()
+                    out.setdefault("extra", {})["config4_single_gpu"] = config4_leg(args, torch, dev, dim)
+                except Exception as exc:  # noqa: BLE001
+                    out["config4_error"] = f"{type(exc).__name__}: {exc}"
             if not args.no_cpu_baseline:
                 try:
                     out["cpu_baseline"] = cpu_baseline(args)
@@ -470,6 +643,11 @@ def main():
                     out["cpu_baseline_blas_search_only"] = cpu_baseline_blas(args)
                 except Exception as exc:  # noqa: BLE001
                     out["cpu_baseline_blas_error"] = f"{type(exc).__name__}: {exc}"
+        elif world == 1 and not args.no_cpu_baseline:
+            try:
+                out["cpu_baseline"] = cpu_baseline(args)
+            except Exception as exc:  # noqa: BLE001
+                out["cpu_baseline_error"] = f"{type(exc).__name__}: {exc}"
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

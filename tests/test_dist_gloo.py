@@ -315,3 +315,23 @@ def test_ref_sharded_index_equals_single_index(tmp_path):
             i, j, s = orc.global_threshold_search(q, r, K)
             assert np.array_equal(got[f"i{K}"], i) and np.array_equal(got[f"j{K}"], j), (rank, K)
             assert np.array_equal(got[f"s{K}"].view(np.uint32), s.view(np.uint32))
+
+
+def test_bench_self_launches_n_ranks():
+    """`python bench.py --gpus N` with no launcher must start N ranks itself (the driver's multi-GPU command goes
+    through torchrun, a user's may not): the launch + rendezvous path alone, over gloo, no GPU touched."""
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "3", "--launch-check"], cwd=root,
+                         env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(line) == 1, out.stdout                       # rank 0 alone prints
+    rep = json.loads(line[0])
+    assert rep["n_gpus"] == 3 and rep["process_group"]["ranks_answered"] == 3
+    assert rep["process_group"]["backend"] == "gloo" and rep["process_group"]["launcher"] == "bench.py self-launch"
+    assert sorted(rep["process_group"]["devices"]) == [0, 1, 2]

@@ -124,3 +124,69 @@ def test_fullsize_knn_properties(fullsize, orc):
     # idempotence
     D20b, I20b = m.index.search(queries, 20)
     assert np.array_equal(D20b.view(np.uint32), D20.view(np.uint32)) and np.array_equal(I20b, I20)
+
+
+def test_fullsize_score_normalised_path(fullsize, orc):
+    """BASELINE configs[3]'s extra stage at configs[1]'s size: `score_normalize`
+    (vsc/baseline/score_normalization.py:31-105) of 200 k query rows against a 2 M-row noise set on the device
+    (`DeviceScoreNormalizer`), then the search / candidates / localisation on the 511+1-d descriptors.
+    Sampled rows against the ORACLE: the prepared rows, the 1-NN value behind the bias column (orc.knn over all
+    2 M noise rows), hit scores of the normalised search bit for bit, order, completeness, planted copies."""
+    import torch
+    from bench import synth_on_device
+    from vsc2022_amd.engine import DeviceMatcher, DeviceScoreNormalizer
+
+    m, queries, refs, gt, (n_qv, qf, n_rv, rf, dim) = fullsize
+    dev = queries.device
+    nq, nr = n_qv * qf, n_rv * rf
+    noise = synth_on_device(torch, dev, 77, n_rv, rf, dim, static_frac=0.0)
+    beta = 1.2
+    norm = DeviceScoreNormalizer(noise, beta=beta)
+    qn = norm.queries(queries)
+    assert qn.shape == (nq, dim) and qn.is_cuda
+    # ---- the 1-NN behind the bias column, on sampled rows against all 2 M noise rows
+    rng = np.random.default_rng(5)
+    rows = np.sort(rng.choice(nq, 12, replace=False))
+    keep = norm.sel.cpu().numpy()
+    assert len(keep) == dim - 1
+    noise_prep = norm._prepare(noise)                       # what the noise index holds (column dropped, row-L2)
+    q_rows = queries[torch.from_numpy(rows).to(dev)].cpu().numpy()[:, keep]
+    q_prep = orc.row_normalize(q_rows)
+    got = qn[torch.from_numpy(rows).to(dev)].cpu().numpy()
+    assert np.array_equal(got[:, : dim - 1].view(np.uint32), q_prep.view(np.uint32))
+    best, best_id = orc.knn(q_prep, noise_prep.cpu().numpy(), 1)
+    assert np.array_equal(got[:, dim - 1].view(np.uint32), (best[:, 0] * np.float32(-beta)).view(np.uint32))
+    del noise_prep, noise
+    # ---- the search on the normalised descriptors
+    rn = norm.refs(refs)
+    assert torch.equal(rn[:, dim - 1], torch.ones(nr, device=dev))
+    m2 = DeviceMatcher(rn, np.arange(n_rv + 1, dtype=np.int64) * rf, 0)
+    m2.set_queries(qn, np.arange(n_qv + 1, dtype=np.int64) * qf)
+    K = 1200 * n_qv
+    hi, hj, hs, radius = m2.search(K)
+    assert hs.numel() == K
+    s, i, j = hs.cpu().numpy(), hi.cpu().numpy(), hj.cpu().numpy()
+    assert np.all(s[:-1] >= s[1:]) and np.all(s > np.float32(radius))
+    same = s[:-1] == s[1:]
+    key = i.astype(np.int64) * nr + j
+    assert np.all(key[:-1][same] < key[1:][same]) and len(np.unique(key)) == K
+    pick = rng.choice(K, 1000, replace=False)
+    a = qn[torch.from_numpy(i[pick]).long().to(dev)].cpu().numpy()
+    b = rn[torch.from_numpy(j[pick]).long().to(dev)].cpu().numpy()
+    exact = np.array([orc.scores(a[k:k + 1], b[k:k + 1])[0, 0] for k in range(len(pick))], dtype=np.float32)
+    assert np.array_equal(exact.view(np.uint32), s[pick].view(np.uint32))
+    sub = orc.scores(got, rn[:200000].cpu().numpy())
+    hits_set = set(zip(i.tolist(), j.tolist()))
+    rr, cc = np.nonzero(sub > s[-1])
+    for x, y in zip(rr, cc):
+        assert (int(rows[x]), int(y)) in hits_set
+    # ---- candidates + localisation as the reference runs them on normalised descriptors (bias 0.5, MaxSim)
+    res = m2.match(bias=0.5)
+    assert res.n_hits == K and res.n_candidates == 25 * n_qv and res.n_localized == 5 * n_qv
+    planted = set(gt)
+    cand = set(zip(res.cand_q.cpu().tolist(), res.cand_r.cpu().tolist()))
+    assert len(planted & cand) >= 0.99 * len(planted)
+    nbox = res.nbox.cpu().numpy()
+    loc = set(zip(res.cand_q[: res.n_localized].cpu().numpy()[nbox > 0].tolist(),
+                  res.cand_r[: res.n_localized].cpu().numpy()[nbox > 0].tolist()))
+    assert len(planted & loc) >= 0.95 * len(planted)

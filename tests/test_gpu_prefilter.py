@@ -199,6 +199,50 @@ def test_parity_suites_with_forced_prefilter():
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
 
 
+def test_parity_suites_with_the_lds_ring_kernel():
+    """`sim_f16_kernel` (csrc/sim_f16.hip: the 256x256 LDS-ring pre-filter, the route of dims > 512) forced onto
+    every batch of every dimension (VSC_F16_KERNEL=ring VSC_PREFILTER=2, int8 off): same suites, same oracle."""
+    env = dict(os.environ, VSC_PREFILTER="2", VSC_F16_KERNEL="ring", VSC_I8="0")
+    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", "tests/test_gpu_search.py",
+                        "tests/test_gpu_edge_cases.py", "tests/test_gpu_golden.py"],
+                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=1200)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+
+
+@pytest.mark.parametrize("d,nq,nr,K,k", [(768, 520, 3000, 1500, 5), (600, 300, 2100, 700, 20), (1000, 260, 1300, 900, 1)])
+def test_dims_above_512_through_the_ring_kernel_match_oracle(gpu, orc, d, nq, nr, K, k):
+    """DINO descriptors are 768-d (docs/baseline_dino.md): dims > 512 take sim_f16_kernel; deterministic cases against
+    the oracle, thresholded search and k-NN, ties included (int8 off so that the fp16 ring kernel is what runs)."""
+    from vsc2022_amd.vsc.index import FlatIndex
+
+    rng = np.random.default_rng(d)
+    q, r = unit(rng, nq, d), unit(rng, nr, d)
+    r[40:90] = r[40]
+    q[17] = r[40]
+    old = os.environ.get("VSC_I8")
+    os.environ["VSC_I8"] = "0"
+    try:
+        with prefilter_mode("2"):
+            idx = FlatIndex(d)
+    finally:
+        if old is None:
+            os.environ.pop("VSC_I8", None)
+        else:
+            os.environ["VSC_I8"] = old
+    idx.profile(True)
+    idx.add(r[:1000])
+    idx.add(r[1000:])
+    got = idx.global_topk(q, K)
+    oi, oj, os_, info = orc.global_threshold_search(q, r, K, 0, return_info=True)
+    assert_same(got, (oi, oj, os_))
+    assert np.float32(got[3]) == np.float32(info["radius"])
+    D, I = idx.search(q, k)
+    Do, Io = orc.knn(q, r, k)
+    assert np.array_equal(I, Io) and np.array_equal(bits(D), bits(Do))
+    p = idx.profile_read()
+    assert p["f16_launches"] > 0 and p["i8_launches"] == 0
+
+
 @pytest.mark.parametrize("case", ["refs_subnormal", "both_subnormal", "mixed_elements", "mixed_rows"])
 def test_fp16_subnormal_rows_next_to_the_radius(gpu, orc, case):
     """The error bound of the pre-filter (api.hip: c2 = 2^-25 sqrt(D) per unit of norm) assumes GRADUAL underflow

@@ -1,7 +1,16 @@
-"""GPU: the reference-sharded index (vsc2022_amd/refshard.py, BASELINE configs[4]) equals a single index bit
-for bit.  The ranks share the one GPU of the test box, so the collectives run over gloo (staged through the
-host); on a multi-GPU node the same code runs over RCCL.  Every shard runs the HIP kernels (shard-local
-FlatIndex: vsc_index_knn / vsc_index_global_topk) on its own rows with its own row offset."""
+"""GPU: the reference-sharded index (vsc2022_amd/refshard.py, BASELINE configs[4]) against the CPU ORACLE.
+
+What the reference gets from FAISS when an index is spread over devices (vsc/index.py:153,171,
+vsc/baseline/score_normalization.py:88-89): the results of one index over the concatenated rows.  Every rank's
+`search` / `global_topk` is therefore compared with `orc.knn` / `orc.global_threshold_search` over ALL rows (bit for
+bit: ids, order, fp32 score patterns), including shards that hold fewer than k rows and a reference set smaller than
+k (the -FLT_MAX / -1 sentinel of a single index).  The ranks share the one GPU of the test box, so the collectives
+run over gloo (staged through the host); on a multi-GPU node the same code runs over RCCL.  Every shard runs the
+HIP kernels (shard-local FlatIndex: vsc_index_knn / vsc_index_global_topk) on its own rows with its own row offset.
+
+`test_fullsize_ref_sharded_properties`: BASELINE configs[4]'s 16 M x 512-d reference set as 4 shards x 4 M rows
+time-sharing the GPU (generated on the device from the seed), size-independent properties + oracle spot checks.
+"""
 import os
 import sys
 
@@ -17,10 +26,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def _data(seed):
     rng = np.random.default_rng(seed)
-    nq, nr, d = {1: (300, 5000, 64), 2: (150, 70000, 128), 3: (64, 900, 32)}[seed]
+    nq, nr, d = {1: (300, 5000, 64), 2: (150, 70000, 128), 3: (64, 900, 32), 4: (40, 50, 16), 5: (30, 12, 16)}[seed]
     q = rng.standard_normal((nq, d)).astype(np.float32)
     r = rng.standard_normal((nr, d)).astype(np.float32)
-    r[nr // 2 : nr // 2 + 40] = r[7:47]   # duplicate rows in different shards: exact ties across ranks
+    if nr >= 900:
+        r[nr // 2 : nr // 2 + 40] = r[7:47]   # duplicate rows in different shards: exact ties across ranks
     q[3] = q[4]
     q /= np.linalg.norm(q, axis=1, keepdims=True)
     r /= np.linalg.norm(r, axis=1, keepdims=True)
@@ -45,18 +55,12 @@ def _worker(rank, world, port, out_dir, seed, k, K):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("seed,world,k,K", [(1, 2, 5, 20000), (2, 3, 20, 60000), (3, 3, 1, 400)])
-def test_ref_sharded_index_equals_single_index(gpu, tmp_path, seed, world, k, K):
-    from vsc2022_amd import _lib
-    from vsc2022_amd.vsc.index import FlatIndex
-
+@pytest.mark.parametrize("seed,world,k,K", [(1, 2, 5, 20000), (2, 3, 20, 60000), (3, 3, 1, 400), (4, 3, 20, 300),
+                                            (5, 2, 20, 100)])
+def test_ref_sharded_index_equals_the_oracle(gpu, orc, tmp_path, seed, world, k, K):
     q, r = _data(seed)
-    single = FlatIndex(r.shape[1], _lib.METRIC_INNER_PRODUCT, 0)
-    single.add(r)
-    D, I = single.search(q, k)
-    i, j, s, _ = single.global_topk(q, K)
-    del single
-    torch.cuda.empty_cache()
+    D, I = orc.knn(q, r, k)                       # incl. -FLT_MAX / -1 where the whole set holds fewer than k rows
+    i, j, s = orc.global_threshold_search(q, r, K)
     mp.spawn(_worker, args=(world, 29750 + os.getpid() % 200, str(tmp_path), seed, k, K), nprocs=world, join=True)
     rows = 0
     for rank in range(world):
@@ -64,7 +68,106 @@ def test_ref_sharded_index_equals_single_index(gpu, tmp_path, seed, world, k, K)
         assert int(got["row0"]) == rows
         rows += int(got["nloc"])
         assert np.array_equal(got["I"], I), rank
-        assert np.array_equal(got["D"].view(np.uint32), D.view(np.uint32))
+        assert np.array_equal(got["D"].view(np.uint32), D.view(np.uint32)), rank
         assert np.array_equal(got["i"], i) and np.array_equal(got["j"], j.astype(np.int64)), rank
-        assert np.array_equal(got["s"].view(np.uint32), s.view(np.uint32))
+        assert np.array_equal(got["s"].view(np.uint32), s.view(np.uint32)), rank
     assert rows == len(r)
+
+
+# ---------------------------------------------------------------- BASELINE configs[4] at full size
+FULL = dict(world=4, refs_per_rank=4_000_000, dim=512, nq=4096, k=20, K=200_000)
+
+
+def _unit(n, dim, seed, dev):
+    g = torch.Generator(device=dev)
+    g.manual_seed(seed)
+    x = torch.randn((n, dim), generator=g, device=dev)
+    return x / x.norm(dim=1, keepdim=True)
+
+
+def _full_worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), LOCAL_RANK="0")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        sys.path.insert(0, ROOT)
+        from vsc2022_amd import _lib
+        from vsc2022_amd.refshard import RefShardedIndex
+        from vsc2022_amd.vsc.index import FlatIndex
+
+        dev = torch.device("cuda", 0)
+        n, d = FULL["refs_per_rank"], FULL["dim"]
+        shard = _unit(n, d, 100 + rank, dev)
+        q = _unit(FULL["nq"], d, 7, dev)
+        # planted: query row t copies global reference row 1000 t + 17 (spread over all shards)
+        tgt = torch.arange(64, device=dev) * (world * n // 64) + 17
+        mine = (tgt >= rank * n) & (tgt < (rank + 1) * n)
+        # every rank needs the planted rows: gather them from their owners through the host
+        rows = torch.zeros((64, d), dtype=torch.float32)
+        rows[mine.cpu()] = shard[(tgt[mine] - rank * n)].cpu()
+        dist.all_reduce(rows)
+        q[:64] = rows.to(dev)
+        local = FlatIndex(d, _lib.METRIC_INNER_PRODUCT, 0)
+        local.add(shard)
+        idx = RefShardedIndex(local, rank * n, world * n, None, dev)
+        D, I = idx.search(q, FULL["k"])
+        D2, I2 = idx.search(q, FULL["k"])           # idempotence
+        i, j, s, tau = idx.global_topk(q, FULL["K"])
+        # sample for the oracle: the shard rows that the merged results of 24 query rows point into, + 3000 more
+        sample_q = np.r_[np.arange(8), np.arange(64, 64 + 16)]
+        want = np.unique(I[sample_q].ravel())
+        loc = want[(want >= rank * n) & (want < (rank + 1) * n)] - rank * n
+        extra = np.arange(0, n, n // 3000)[:3000]
+        take = np.unique(np.r_[loc, extra])
+        np.savez(os.path.join(out_dir, f"full{rank}.npz"), D=D, I=I, same=np.array_equal(D, D2) and np.array_equal(I, I2),
+                 i=i.cpu().numpy(), j=j.cpu().numpy(), s=s.cpu().numpy(), tau=tau, q=q[sample_q].cpu().numpy(),
+                 sample_q=sample_q, ref_ids=take + rank * n, ref_rows=shard[torch.from_numpy(take).to(dev)].cpu().numpy(),
+                 tgt=tgt.cpu().numpy())
+    finally:
+        dist.destroy_process_group()
+
+
+def test_fullsize_ref_sharded_properties(gpu, orc, tmp_path):
+    world, k, K = FULL["world"], FULL["k"], FULL["K"]
+    mp.spawn(_full_worker, args=(world, 29350 + os.getpid() % 200, str(tmp_path)), nprocs=world, join=True)
+    got = [np.load(tmp_path / f"full{r}.npz") for r in range(world)]
+    g0 = got[0]
+    D, I = g0["D"], g0["I"]
+    nq = D.shape[0]
+    for g in got:  # every rank holds the same merged result, twice
+        assert bool(g["same"])
+        assert np.array_equal(g["I"], I) and np.array_equal(g["D"].view(np.uint32), D.view(np.uint32))
+        assert np.array_equal(g["i"], g0["i"]) and np.array_equal(g["j"], g0["j"])
+        assert np.array_equal(g["s"].view(np.uint32), g0["s"].view(np.uint32))
+    # k-NN: per-row order (score desc, id asc), no duplicates, ids inside the 16 M rows, planted rows found first
+    assert (np.diff(D, axis=1) <= 0).all()
+    tie = np.diff(D, axis=1) == 0
+    assert (np.diff(I, axis=1)[tie] > 0).all()
+    assert all(len(set(row)) == k for row in I[:: nq // 256])
+    assert I.min() >= 0 and I.max() < world * FULL["refs_per_rank"]
+    assert np.array_equal(I[:64, 0], g0["tgt"]) and (D[:64, 0] > 0.9999).all()
+    # oracle: every listed score of the sampled rows recomputed bit for bit, and completeness against the sampled
+    # reference rows of all shards (no sampled row may beat a row's k-th listed score without being listed)
+    ref_ids = np.concatenate([g["ref_ids"] for g in got])
+    ref_rows = np.concatenate([g["ref_rows"] for g in got])
+    sq, q = g0["sample_q"], g0["q"]
+    pos = {int(v): n for n, v in enumerate(ref_ids)}
+    exact = orc.scores(q, ref_rows)
+    for n, row in enumerate(sq):
+        cols = [pos[int(v)] for v in I[row]]
+        assert np.array_equal(exact[n, cols].view(np.uint32), D[row].view(np.uint32))
+        listed = set(int(v) for v in I[row])
+        better = [int(ref_ids[c]) for c in np.flatnonzero(exact[n] > D[row, -1])]
+        assert set(better) <= listed
+    # global top-K: exactly K hits, total order (score desc, row asc, ref asc), distinct, all above tau; the planted
+    # pairs lead the list; sampled hits recomputed by the oracle
+    i, j, s = g0["i"], g0["j"], g0["s"]
+    assert len(s) == K and (s >= np.float32(g0["tau"])).all()   # tau = the K-th best score (the distributed cut)
+    key = np.stack([-s.astype(np.float64), i.astype(np.float64), j.astype(np.float64)], 1)
+    assert (np.lexsort((key[:, 2], key[:, 1], key[:, 0])) == np.arange(K)).all()
+    assert len(set(zip(i.tolist(), j.tolist()))) == K
+    assert set(zip(i[:64].tolist(), j[:64].tolist())) == set(zip(range(64), g0["tgt"].tolist()))
+    hit_rows = np.flatnonzero(np.isin(i, sq) & np.isin(j, ref_ids))
+    assert len(hit_rows) >= 8
+    qmap = {int(v): n for n, v in enumerate(sq)}
+    for h in hit_rows[:500]:
+        assert exact[qmap[int(i[h])], pos[int(j[h])]].view(np.uint32) == s[h].view(np.uint32)

@@ -221,3 +221,64 @@ def test_batchnorm_folding_keeps_the_function():
     with torch.no_grad():
         a, b = model(x), fused(x)
     assert torch.allclose(a, b, rtol=1e-3, atol=1e-4), (a - b).abs().max()
+
+
+@pytest.mark.gpu
+def test_fast_inference_configuration_against_fp32_eager(gpu):
+    """Accuracy gate of the configuration that profiles/r0*_config3_inference.md TIMES -- bf16 autocast, frames of
+    consecutive videos packed into batches of 256, channels-last, BatchNorms folded into the convolutions -- against
+    what the reference runs (vsc/baseline/inference_impl.py:210-239: fp32, eager, one video per batch), on 256
+    synthetic videos x 25 frames of structured content (low-frequency patterns: iid noise frames would all map to
+    one descriptor).  Stated tolerance: cosine >= 0.999 for every frame, and every frame's nearest neighbour among
+    the fp32 descriptors of ALL frames is the frame itself (identical top-1 retrieval), searched on the engine."""
+    from dataclasses import dataclass
+
+    from vsc2022_amd.vsc.baseline.inference import SyntheticVideos, build_sscd_model, fold_batchnorm, run_inference, \
+        run_inference_packed, to_flat
+    from vsc2022_amd.vsc.index import FlatIndex
+
+    @dataclass
+    class PatternVideos(SyntheticVideos):
+        def video(self, idx, n_frames, device):
+            g = torch.Generator(device=device)
+            g.manual_seed(self.seed * 1000003 + idx)
+            base = torch.rand((1, 3, 6, 6), generator=g, device=device)           # the video's scene
+            frames = base + 0.35 * torch.rand((n_frames, 3, 6, 6), generator=g, device=device)
+            frames = torch.nn.functional.interpolate(frames, size=(self.size, self.size), mode="bilinear")
+            frames = frames + 0.03 * torch.rand(frames.shape, generator=g, device=device)
+            return (frames / frames.amax(dim=(1, 2, 3), keepdim=True) * 255.0).to(torch.uint8)
+
+    dev = torch.device("cuda", 0)
+    src = PatternVideos(n_videos=256, frames=(25, 25), size=320, seed=11)
+    model = build_sscd_model(device=dev)
+    # A random-init ReLU trunk with identity BatchNorms collapses every input onto one direction (different frames
+    # came out 0.9997 alike).  Give the BatchNorms the statistics of the data, as training would have: one
+    # cumulative-average pass over 8 videos in train mode, then back to eval.
+    from vsc2022_amd.vsc.baseline.inference import preprocess
+
+    for mod in model.modules():
+        if isinstance(mod, torch.nn.BatchNorm2d):
+            mod.reset_running_stats()
+            mod.momentum = None
+    model.train()
+    with torch.no_grad():
+        for v in range(8):
+            model(preprocess(src.video(1000 + v, 25, dev)))
+    model.eval()
+    slow, off, ids = to_flat(run_inference(model, src, dev, batch_size=32, autocast_dtype=None))
+    fast, off2, ids2 = to_flat(run_inference_packed(fold_batchnorm(model), src, dev, batch_size=256,
+                                                    autocast_dtype=torch.bfloat16))
+    assert ids == ids2 and np.array_equal(off, off2) and slow.shape == fast.shape == (256 * 25, 512)
+    assert torch.isfinite(slow).all() and torch.isfinite(fast).all()
+    cos = torch.nn.functional.cosine_similarity(slow, fast, dim=1)
+    # descriptors of different frames must be distinguishable for the gate to mean anything
+    sn = slow / slow.norm(dim=1, keepdim=True)
+    spread = (sn[:2000] @ sn[2000:4000].T).max().item()
+    print(f"spread {spread:.5f}  min cosine {cos.min().item():.6f}  mean cosine {cos.mean().item():.6f}")
+    assert spread < 0.99, f"degenerate descriptors: different frames are {spread:.5f} alike"
+    assert cos.min().item() >= 0.999, f"min cosine {cos.min().item():.5f} (mean {cos.mean().item():.5f})"
+    index = FlatIndex(512)
+    index.add(sn)
+    fn = fast / fast.norm(dim=1, keepdim=True)
+    _, top1 = index.search(fn, 1)
+    assert np.array_equal(top1[:, 0], np.arange(len(fn))), f"{int((top1[:, 0] != np.arange(len(fn))).sum())} frames retrieve another frame"

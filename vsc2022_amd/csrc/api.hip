@@ -66,10 +66,12 @@ struct Workspace {
     DevBuf rowthr;          // per-row thresholds of the pre-filtered k-NN
     DevBuf slices;          // per-panel slice counters of the panel-stationary pre-filter
     DevBuf q8, pstat;       // int8 image + per-panel {1/s, E, N, s} of ONE launch's query rows (sim_i8p.hip)
+    DevBuf tailfill;        // fill levels of the chunks of the candidate list's shared tail (cand_list.h)
+    DevBuf rt8;             // ... and its row thresholds in position order (rows sorted by threshold inside a launch)
     void release() {
         stage.release(); qbuf.release();
         qh.release(); qn.release(); ci.release(); cj.release(); segcnt.release(); rowthr.release(); slices.release();
-        q8.release(); pstat.release();
+        q8.release(); pstat.release(); rt8.release(); tailfill.release();
         for (auto& b : hA) b.release();
         for (auto& b : hB) b.release();
         ctl.release(); w0.release(); w1.release(); w2.release(); w3.release(); tmp.release(); cnt.release();
@@ -142,6 +144,11 @@ struct vsc_index {
     DevBuf ref8, ref8m;
     int dpad8 = 0, i8_mode = 0;
     double i8_density = 2e-4;
+    // sum / count of E_r / N_r over the reference rows: sqrt(dim) x their mean is the references' share of eps / sigma
+    // (0.17 for unit-norm Gaussian-like rows); above i8_max_rel the 8-bit bound passes too much and the batches stay
+    // on the fp16 kernel (e.g. score-normalised descriptors: one coordinate of every row is 1, the scale follows it)
+    double i8_loose_sum = 0.0, i8_loose_cnt = 0.0, i8_max_rel = 0.35;
+    unsigned long long stat_i8_fallbacks = 0;
     bool prefilter = false, prefilter_force = false;
     double prefilter_density = 0.02;  // expected hit density below which a batch goes through the pre-filter
     unsigned long long stat_candidates = 0, stat_hits = 0;  // last search (vsc_index_profile_read)
@@ -299,6 +306,8 @@ int vsc_index_create(int dim, int metric, int device, vsc_index_t** out) {
         if (idx->i8_mode && i8 && i8[0] == '2') idx->i8_mode = 2;
         const char* dd = getenv("VSC_I8_DENSITY");
         if (dd && atof(dd) > 0.0) idx->i8_density = atof(dd);
+        const char* mr = getenv("VSC_I8_MAX_REL");
+        if (mr && atof(mr) > 0.0) idx->i8_max_rel = atof(mr);
     }
     idx->device = device;
     hipError_t e = hipStreamCreateWithFlags(&idx->stream, hipStreamNonBlocking);
@@ -429,9 +438,27 @@ int vsc_index_add(vsc_index_t* idx, const float* x, int64_t n, int x_mem) {
         }
     }
     VSC_TRY(pack_into(x, n, idx->dim, x_mem, dst, need_rows - idx->ntotal, idx->dpad, idx->ws, idx->stream, h));
+    if (idx->i8_mode) {
+        // looseness of the 8-bit image of the new rows (two doubles through the sort scratch)
+        VSC_TRY(idx->ws.cnt.reserve(2 * sizeof(double)));
+        VSC_TRY(launch_meta_looseness(idx->ref8m.as<float4>() + idx->ntotal, n, idx->ws.cnt.as<double>(), idx->stream));
+        double h2[2] = {0.0, 0.0};
+        VSC_HIP(hipMemcpyAsync(h2, idx->ws.cnt.p, sizeof(h2), hipMemcpyDeviceToHost, idx->stream));
+        VSC_HIP(hipStreamSynchronize(idx->stream));
+        idx->i8_loose_sum += h2[0];
+        idx->i8_loose_cnt += h2[1];
+    }
     VSC_HIP(hipStreamSynchronize(idx->stream));
     idx->ntotal += n;
     return VSC_OK;
+}
+
+// May this search use the int8 kernel at all?  (mode 2 = forced by the tests)
+static bool i8_usable(const vsc_index* idx) {
+    if (idx->i8_mode == 2) return true;
+    if (idx->i8_mode != 1) return false;
+    if (idx->i8_loose_cnt <= 0.0) return true;
+    return std::sqrt((double)idx->dim) * (idx->i8_loose_sum / idx->i8_loose_cnt) <= idx->i8_max_rel;
 }
 
 // Pack the query rows: returns device pointer; buffer holds round_up(nq,128)+128 zero-padded rows.
@@ -496,7 +523,7 @@ static int enqueue_f16(vsc_index* idx, const float* qpacked, int64_t i0, int64_t
         const float c3 = (float)(D * ldexp(1.0, -50));
         int32_t* const cand_i = idx->ws.ci.as<int32_t>();
         int32_t* const cand_j = idx->ws.cj.as<int32_t>();
-        int grid = 0, seg_cap = 0;
+        int grid = 0, seg_cap = 0, tail_shift = 6;
         int64_t tail_base = 0;
         long long tail_cap = 0;
         hipEvent_t stop;
@@ -509,8 +536,18 @@ static int enqueue_f16(vsc_index* idx, const float* qpacked, int64_t i0, int64_t
             VSC_TRY(idx->ws.q8.reserve((size_t)f.npanel * F16P_PANEL_ROWS * idx->dpad8));
             VSC_TRY(idx->ws.pstat.reserve((size_t)f.npanel * sizeof(float4)));
             VSC_TRY(prof_begin(idx, &stop, 5));
+            const int32_t* perm = nullptr;
+            float* rt_pos = nullptr;
+            if (row_thr) {
+                // k-NN thresholds differ from row to row: the launch sees its rows sorted by threshold
+                VSC_TRY(idx->ws.rt8.reserve((size_t)f.npanel * F16P_PANEL_ROWS * sizeof(float)));
+                rt_pos = idx->ws.rt8.as<float>();
+                VSC_TRY(sort_rows_by_threshold(row_thr + i0, nqb, idx->ws.w0, idx->ws.w1, idx->ws.w2, idx->ws.w3,
+                                               idx->ws.tmp, &perm, idx->stream));
+            }
             VSC_TRY(launch_quant_query_panels(qpacked + i0 * idx->dpad, idx->dpad, nqb, f.npanel, idx->ws.q8.p, idx->dpad8,
-                                              idx->ws.pstat.as<float4>(), idx->stream));
+                                              idx->ws.pstat.as<float4>(), perm, row_thr ? row_thr + i0 : nullptr, rt_pos,
+                                              idx->stream));
             f.Q = idx->ws.q8.p;
             f.pstat = idx->ws.pstat.as<float4>();
             f.Rf = idx->ref8.p;
@@ -523,7 +560,8 @@ static int enqueue_f16(vsc_index* idx, const float* qpacked, int64_t i0, int64_t
             // the exact fp32 chain is within dpad 2^-24 |q||r| (1 + tiny) of the real inner product
             f.c_acc = (float)(((double)idx->dpad + 2.0) * ldexp(1.0, -23));
             f.radius = &ctl->radius;
-            f.row_thr = row_thr ? row_thr + i0 : nullptr;
+            f.row_thr = rt_pos;
+            f.perm = perm;
             f.out_i = cand_i;
             f.out_j = cand_j;
             seg_cap = (int)std::min<int64_t>(ccap / (grid * 8), 0x7fffffff);
@@ -533,6 +571,9 @@ static int enqueue_f16(vsc_index* idx, const float* qpacked, int64_t i0, int64_t
             f.seg_count = idx->ws.segcnt.as<int>();
             f.tail_base = tail_base;
             f.tail_cap = tail_cap;
+            f.tail_shift = tail_shift = tail_chunk_shift_for(tail_cap, grid * 8);
+            VSC_TRY(idx->ws.tailfill.reserve((size_t)((tail_cap >> tail_shift) + 2) * sizeof(int)));
+            f.tail_fill = idx->ws.tailfill.as<int>();
             f.tail_count = &ctl->n_tail;
             f.overflow = &ctl->overflow;
             VSC_TRY(launch_sim_i8p(f, grid, idx->stream));
@@ -563,6 +604,9 @@ static int enqueue_f16(vsc_index* idx, const float* qpacked, int64_t i0, int64_t
             f.seg_count = idx->ws.segcnt.as<int>();
             f.tail_base = tail_base;
             f.tail_cap = tail_cap;
+            f.tail_shift = tail_shift = tail_chunk_shift_for(tail_cap, grid * 8);
+            VSC_TRY(idx->ws.tailfill.reserve((size_t)((tail_cap >> tail_shift) + 2) * sizeof(int)));
+            f.tail_fill = idx->ws.tailfill.as<int>();
             f.tail_count = &ctl->n_tail;
             f.overflow = &ctl->overflow;
             VSC_TRY(prof_begin(idx, &stop, 1));
@@ -593,6 +637,9 @@ static int enqueue_f16(vsc_index* idx, const float* qpacked, int64_t i0, int64_t
             f.seg_count = idx->ws.segcnt.as<int>();
             f.tail_base = tail_base;
             f.tail_cap = tail_cap;
+            f.tail_shift = tail_shift = tail_chunk_shift_for(tail_cap, grid * 8);
+            VSC_TRY(idx->ws.tailfill.reserve((size_t)((tail_cap >> tail_shift) + 2) * sizeof(int)));
+            f.tail_fill = idx->ws.tailfill.as<int>();
             f.tail_count = &ctl->n_tail;
             f.overflow = &ctl->overflow;
             VSC_TRY(prof_begin(idx, &stop, 1));
@@ -612,6 +659,8 @@ static int enqueue_f16(vsc_index* idx, const float* qpacked, int64_t i0, int64_t
         r.tail_base = tail_base;
         r.tail_cap = tail_cap;
         r.tail_count = &ctl->n_tail;
+        r.tail_shift = tail_shift;
+        r.tail_fill = idx->ws.tailfill.as<int>();
         r.n_cand_total = &ctl->n_cand_total;
         r.radius = &ctl->radius;
         r.out_i = idx->ws.hA[0].as<int32_t>();
@@ -703,7 +752,9 @@ int vsc_index_global_topk(vsc_index_t* idx, const float* q, int64_t nq, int q_me
     if (cap <= 0) cap = std::max<int64_t>(32 * idx->ntotal, 2 * K) + 2 * K + 1024;
     cap = std::min<int64_t>(cap, cap_max);
     SelectCtl h;
+    bool allow_i8 = i8_usable(idx);
     for (;;) {
+        bool used_i8 = false;
         VSC_TRY(ensure_hit_buffers(idx, cap));
         // initial radius -1e10 (IP) / +1e10 (L2) -> -1e10 in score space either way (vsc/index.py:146)
         VSC_TRY(init_ctl(idx, -1e10f));
@@ -720,8 +771,9 @@ int vsc_index_global_topk(vsc_index_t* idx, const float* q, int64_t nq, int q_me
                              (idx->prefilter && i0 > 0 && (double)K < idx->prefilter_density * (double)i0 * (double)idx->ntotal);
             // ... and once it is low enough that the int8 kernel's 4-5x candidates cost less than the fp16 kernel's
             // second half (the bound of 8-bit rows is ~16x looser), the batch runs on int8
-            const bool i8 = f16 && (idx->i8_mode == 2 ||
-                                    (idx->i8_mode == 1 && i0 > 0 && (double)K < idx->i8_density * (double)i0 * (double)idx->ntotal));
+            const bool i8 = f16 && allow_i8 &&
+                            (idx->i8_mode == 2 || (i0 > 0 && (double)K < idx->i8_density * (double)i0 * (double)idx->ntotal));
+            used_i8 |= i8;
             VSC_TRY(enqueue_batch(idx, qp, i0, i1, cap, f16, i8));
             hipEvent_t stop;
             VSC_TRY(prof_begin(idx, &stop, 3));
@@ -738,6 +790,13 @@ int vsc_index_global_topk(vsc_index_t* idx, const float* q, int64_t nq, int q_me
         VSC_TRY(prof_collect(idx));
         idx->stat_candidates = h.n_cand_total;
         if (!h.overflow) break;
+        if (used_i8 && idx->i8_mode != 2) {
+            // the candidate list overflowed with int8 batches in the schedule: their bound may simply be too loose for
+            // these rows -- same buffers, fp16 pre-filter throughout
+            allow_i8 = false;
+            idx->stat_i8_fallbacks += 1;
+            continue;
+        }
         // A batch emitted more hits than the buffer holds (heavy score ties keep the radius low).
         // The schedule is deterministic, so simply rerun it with a larger buffer.
         if (idx->hit_cap_user > 0 || cap >= cap_max) {
@@ -978,7 +1037,7 @@ static int knn_prefiltered(vsc_index* idx, const float* qp, int64_t nq, int k, f
     const int64_t nr = idx->ntotal;
     // the thresholded passes run on the int8 kernel when the index keeps an int8 image (VSC_I8_KNN=0: fp16)
     static const bool knn_i8_env = !(getenv("VSC_I8_KNN") && getenv("VSC_I8_KNN")[0] == '0');
-    const bool knn_i8 = idx->i8_mode == 2 || (idx->i8_mode == 1 && knn_i8_env);
+    bool knn_i8 = idx->i8_mode == 2 || (i8_usable(idx) && knn_i8_env);
     static const double subset_factor = getenv("VSC_KNN_SUBSET") ? atof(getenv("VSC_KNN_SUBSET")) : 300.0;
     static const bool two_level = !(getenv("VSC_KNN_LEVELS") && getenv("VSC_KNN_LEVELS")[0] == '1');
     // one level: S0 = sqrt(300 k nr) balances the exact pass (~2 dim S0 / 1e14 s per row) against the per-hit cost of
@@ -1002,6 +1061,12 @@ static int knn_prefiltered(vsc_index* idx, const float* qp, int64_t nq, int k, f
         const int64_t S1 = std::min<int64_t>(nr, round_up64((idx->prefilter_force ? 3 : 16) * S0, F16P_COL_STEP));
         // expected hits per row: k * S1 / S0 (plus the filter's inflation); generous factor
         int rc = knn_threshold_pass(idx, qp, nq, S1, k, (double)k * ((double)S1 / (double)S0) * 4.0, ds, dj, knn_i8);
+        if (rc == VSC_ERR_OVERFLOW && knn_i8 && idx->i8_mode != 2) {
+            // (ds / dj still hold the first level's lists: the overflow is detected before they are rewritten)
+            knn_i8 = false;
+            idx->stat_i8_fallbacks += 1;
+            rc = knn_threshold_pass(idx, qp, nq, S1, k, (double)k * ((double)S1 / (double)S0) * 4.0, ds, dj, false);
+        }
         if (rc == VSC_OK) {
             VSC_TRY(launch_knn_row_thr(ds, nq, k, idx->ws.rowthr.as<float>(), rows_h, idx->stream));
             S_last = S1;
@@ -1013,7 +1078,12 @@ static int knn_prefiltered(vsc_index* idx, const float* qp, int64_t nq, int k, f
             VSC_TRY(launch_knn_row_thr(ds, nq, k, idx->ws.rowthr.as<float>(), rows_h, idx->stream));
         }
     }
-    return knn_threshold_pass(idx, qp, nq, nr, k, (double)k * ((double)nr / (double)S_last) * 4.0, ds, dj, knn_i8);
+    int rc = knn_threshold_pass(idx, qp, nq, nr, k, (double)k * ((double)nr / (double)S_last) * 4.0, ds, dj, knn_i8);
+    if (rc == VSC_ERR_OVERFLOW && knn_i8 && idx->i8_mode != 2) {
+        idx->stat_i8_fallbacks += 1;
+        rc = knn_threshold_pass(idx, qp, nq, nr, k, (double)k * ((double)nr / (double)S_last) * 4.0, ds, dj, false);
+    }
+    return rc;
 }
 
 int vsc_index_knn(vsc_index_t* idx, const float* q, int64_t nq, int q_mem, int k, float* out_s,
@@ -1391,15 +1461,30 @@ int vsc_tn_set_queries(vsc_tn_ctx_t* c, const float* qfeat, const int64_t* q_off
         return VSC_ERR_INVALID;
     }
     VSC_HIP(hipSetDevice(c->device));
-    c->n_qvid = n_qvid;
-    c->q_off.assign(q_off, q_off + n_qvid + 1);
-    const int64_t nq = c->q_off.back();
+    // everything that can fail (allocation, packing, upload) runs on local state first: the context keeps its old,
+    // consistent query side if any of it does, and takes the new offsets only once the device holds the new rows
+    std::vector<int64_t> off(q_off, q_off + n_qvid + 1);
+    const int64_t nq = off.back();
     const int64_t q_rows = round_up64(nq + 32, ROW_PAD);  // (+32: see vsc_tn_create)
-    VSC_TRY(c->qfeat.reserve((size_t)q_rows * c->dpad * 4));
-    VSC_TRY(pack_into(qfeat, nq, c->dim, feat_mem, c->qfeat.as<float>(), q_rows, c->dpad, c->ws, c->stream));
-    VSC_TRY(c->d_qoff.reserve((size_t)(n_qvid + 1) * 8));
-    VSC_HIP(hipMemcpyAsync(c->d_qoff.p, c->q_off.data(), (size_t)(n_qvid + 1) * 8, hipMemcpyHostToDevice, c->stream));
-    VSC_HIP(hipStreamSynchronize(c->stream));
+    int rc = c->qfeat.reserve((size_t)q_rows * c->dpad * 4);
+    if (rc == VSC_OK) rc = pack_into(qfeat, nq, c->dim, feat_mem, c->qfeat.as<float>(), q_rows, c->dpad, c->ws, c->stream);
+    if (rc == VSC_OK) rc = c->d_qoff.reserve((size_t)(n_qvid + 1) * 8);
+    if (rc == VSC_OK) {
+        hipError_t e = hipMemcpyAsync(c->d_qoff.p, off.data(), (size_t)(n_qvid + 1) * 8, hipMemcpyHostToDevice, c->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        if (e != hipSuccess) {
+            set_error("vsc_tn_set_queries: upload of the query offsets failed: %s", hipGetErrorString(e));
+            rc = VSC_ERR_HIP;
+        }
+    }
+    if (rc != VSC_OK) {
+        // the packed rows may be half written: an empty query side is the only state that cannot index past them
+        c->n_qvid = 0;
+        c->q_off.assign(1, 0);
+        return rc;
+    }
+    c->n_qvid = n_qvid;
+    c->q_off.swap(off);
     return VSC_OK;
 }
 

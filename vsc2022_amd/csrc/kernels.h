@@ -2,6 +2,7 @@
 // the C-ABI layer in api.hip).
 #pragma once
 #include "vscmi_common.h"
+#include "cand_list.h"
 
 namespace vscmi {
 
@@ -23,7 +24,7 @@ struct SimF16Args {
     const float* row_thr;
     // candidate list = one private segment of seg_cap entries per wave of the launch (8 per workgroup)
     // + a shared tail (atomic counter) for waves whose segment is full
-    int seg_cap; int* seg_count; int64_t tail_base; long long tail_cap; unsigned long long* tail_count;
+    int seg_cap; int* seg_count; int64_t tail_base; long long tail_cap; int tail_shift; int* tail_fill; unsigned long long* tail_count;
     int* overflow;
 };
 // panel-stationary fp16 pre-filter (sim_f16p.hip; dpadh <= 512): the query side is the natural fp16 image, the
@@ -40,7 +41,7 @@ struct SimF16PArgs {
     float c1, c2, c3;
     const float* radius; const float* row_thr;  // as in SimF16Args
     int32_t* out_i; int32_t* out_j;
-    int seg_cap; int* seg_count; int64_t tail_base; long long tail_cap; unsigned long long* tail_count;
+    int seg_cap; int* seg_count; int64_t tail_base; long long tail_cap; int tail_shift; int* tail_fill; unsigned long long* tail_count;
     int* overflow;
 };
 // panel-stationary INT8 pre-filter (sim_i8p.hip; dims <= 1024): the query side is the launch's own int8 image with one
@@ -54,15 +55,17 @@ struct SimI8PArgs {
     int npanel; int nsteps; int slice;     // work split (sim_f16p_plan)
     int* next_slice;
     float c_acc;                           // rounding of the exact fp32 chain per |q||r|
-    const float* radius; const float* row_thr;  // as in SimF16Args (row_thr indexed from the launch's first row)
+    const float* radius; const float* row_thr;  // as in SimF16Args (row_thr indexed by POSITION inside the launch)
+    const int32_t* perm;                   // position inside the launch -> row of the launch (nullptr: identity)
     int32_t* out_i; int32_t* out_j;
-    int seg_cap; int* seg_count; int64_t tail_base; long long tail_cap; unsigned long long* tail_count;
+    int seg_cap; int* seg_count; int64_t tail_base; long long tail_cap; int tail_shift; int* tail_fill; unsigned long long* tail_count;
     int* overflow;
 };
 struct RescoreArgs {
     const float* Q; const float* R; int dpad;  // packed fp32 images (exact arithmetic contract)
     const int32_t* cand_i; const int32_t* cand_j; int n_seg; int seg_cap; const int* seg_count;
     int64_t tail_base; long long tail_cap; unsigned long long* tail_count;  // reset to 0 after the pass
+    int tail_shift; const int* tail_fill;  // the tail is handed out in chunks of 1 << tail_shift entries, each with a fill level
     unsigned long long* n_cand_total;      // statistics
     const float* radius; int32_t* out_i; int32_t* out_j; float* out_s;
     unsigned long long* counter; long long cap; int* overflow;
@@ -108,7 +111,10 @@ void sim_f16p_plan(int64_t nq, int64_t nr, int* npanel, int* nsteps, int* slice,
 int launch_sim_f16p(const SimF16PArgs&, int grid, hipStream_t);
 int launch_sim_i8p(const SimI8PArgs&, int grid, hipStream_t);
 int launch_quant_ref_frag(const float*, int64_t, int, void*, float4*, int64_t, int64_t, int, hipStream_t);
-int launch_quant_query_panels(const float*, int, int, int, void*, int, float4*, hipStream_t);
+int launch_meta_looseness(const float4*, int64_t, double*, hipStream_t);
+int launch_quant_query_panels(const float*, int, int, int, void*, int, float4*, const int32_t*, const float*, float*,
+                              hipStream_t);
+int sort_rows_by_threshold(const float*, int64_t, DevBuf&, DevBuf&, DevBuf&, DevBuf&, DevBuf&, const int32_t**, hipStream_t);
 int launch_pack_half_frag(const float*, int64_t, int, _Float16*, float*, int64_t, int64_t, int, hipStream_t);
 int launch_pack_half(const float*, int64_t, int, _Float16*, float*, int64_t, int, hipStream_t);
 int launch_sim_knn(const SimKnnArgs&, hipStream_t);

@@ -14,6 +14,8 @@
 //   quant_query_panels  query rows of ONE launch: one scale per 128-row PANEL (the kernel's epilogue compares the
 //                     integer accumulators of a whole panel against one threshold per reference column), natural
 //                     image [panel rows][dpad8], pstat[panel] = {1 / s, max E, max N, s}
+#include <algorithm>
+
 #include "kernels.h"
 
 namespace vscmi {
@@ -98,20 +100,50 @@ int launch_quant_ref_frag(const float* src, int64_t n, int dim, void* image, flo
     return VSC_OK;
 }
 
+// sum over rows of E / N (rows with a finite, non-zero N) and their count: how loose the 8-bit bound is relative to
+// the rows it describes.  For two sets of rows with isotropic directions eps / sigma(score) ~ sqrt(dim) (E_q / N_q +
+// E_r / N_r): api.hip keeps the int8 kernel off when the references alone already spend the budget.
+__global__ __launch_bounds__(256) void meta_looseness_kernel(const float4* __restrict__ meta, int64_t n, double* __restrict__ out) {
+    double s = 0.0, c = 0.0;
+    for (int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x; r < n; r += (int64_t)gridDim.x * 256) {
+        const float4 m = meta[r];
+        if (m.z > 0.0f && m.z < INFINITY && m.y < INFINITY) { s += (double)m.y / (double)m.z; c += 1.0; }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { s += __shfl_xor(s, off); c += __shfl_xor(c, off); }
+    if ((threadIdx.x & 63) == 0) { atomicAdd(&out[0], s); atomicAdd(&out[1], c); }
+}
+
+int launch_meta_looseness(const float4* meta, int64_t n, double* out2, hipStream_t stream) {
+    VSC_HIP(hipMemsetAsync(out2, 0, 2 * sizeof(double), stream));
+    if (n <= 0) return VSC_OK;
+    const unsigned grid = (unsigned)std::min<int64_t>(1024, (n + 255) / 256);
+    hipLaunchKernelGGL(meta_looseness_kernel, dim3(grid), dim3(256), 0, stream, meta, n, out2);
+    VSC_HIP(hipGetLastError());
+    return VSC_OK;
+}
+
 // One workgroup per 128-row panel of the launch's query rows; source = the PACKED fp32 image (vscmi_common.h:
 // dpad floats per row, inside every group of 8 the order [k0 k2 k4 k6 | k1 k3 k5 k7], zero padded rows and columns).
 // Thread t: row t >> 2, groups (t & 3), (t & 3) + 4, ...  Two passes over the panel (256 KiB at 512-d: L2-resident).
+// `perm` (optional): position p of the launch holds row perm[p] (rows sorted by threshold, sortpairs.hip); positions
+// past the batch are zero rows.  thr_src / thr_out (optional): the row thresholds, gathered into position order.
 __global__ __launch_bounds__(512) void quant_query_panels_kernel(const float* __restrict__ qpacked, int dpad, int nq,
                                                                  int8_t* __restrict__ q8, int dpad8,
-                                                                 float4* __restrict__ pstat) {
+                                                                 float4* __restrict__ pstat,
+                                                                 const int32_t* __restrict__ perm,
+                                                                 const float* __restrict__ thr_src,
+                                                                 float* __restrict__ thr_out) {
     __shared__ float red[8];
     __shared__ unsigned int emax_sh, nmax_sh;
     __shared__ int bad_sh;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int row = tid >> 2, part = tid & 3;
-    const int64_t grow = (int64_t)blockIdx.x * 128 + row;
-    const float4* src = reinterpret_cast<const float4*>(qpacked + grow * dpad);
-    const int ngroup = dpad / 8, ngroup8 = dpad8 / 8;
+    const int64_t grow = (int64_t)blockIdx.x * 128 + row;  // position inside the launch
+    const int64_t srow = perm ? (grow < nq ? (int64_t)perm[grow] : -1) : grow;
+    const float4* src = reinterpret_cast<const float4*>(qpacked + (srow < 0 ? 0 : srow) * dpad);
+    const int ngroup = srow < 0 ? 0 : dpad / 8, ngroup8 = dpad8 / 8;
+    if (thr_out && part == 0) thr_out[grow] = grow < nq ? thr_src[srow] : INFINITY;
     if (tid == 0) { emax_sh = 0u; nmax_sh = 0u; bad_sh = 0; }
     float amax = 0.0f;
     bool bad = false;
@@ -171,10 +203,10 @@ __global__ __launch_bounds__(512) void quant_query_panels_kernel(const float* __
 }
 
 int launch_quant_query_panels(const float* qpacked, int dpad, int nq, int npanel, void* q8, int dpad8, float4* pstat,
-                              hipStream_t stream) {
+                              const int32_t* perm, const float* thr_src, float* thr_out, hipStream_t stream) {
     if (npanel <= 0) return VSC_OK;
     hipLaunchKernelGGL(quant_query_panels_kernel, dim3((unsigned)npanel), dim3(512), 0, stream, qpacked, dpad, nq,
-                       reinterpret_cast<int8_t*>(q8), dpad8, pstat);
+                       reinterpret_cast<int8_t*>(q8), dpad8, pstat, perm, thr_src, thr_out);
     VSC_HIP(hipGetLastError());
     return VSC_OK;
 }

@@ -191,6 +191,10 @@ template <class K, class V>
 int radix_sort_pairs(K* keys_a, K* keys_b, V* vals_a, V* vals_b, int64_t n, int begin_bit, int end_bit, bool desc,
                      void* tmp, hipStream_t stream) {
     if (n <= 0) return 0;
+    if (n > 0xffffffffLL) {  // histograms, totals and scatter offsets are 32-bit
+        set_error("radix_sort_pairs: %lld entries exceed the 2^32 limit of the sort", (long long)n);
+        return -1;
+    }
     const int ntiles = (int)((n + RADIX_TILE - 1) / RADIX_TILE);
     unsigned* hist = reinterpret_cast<unsigned*>(tmp);
     unsigned* totals = hist + (size_t)256 * ntiles;

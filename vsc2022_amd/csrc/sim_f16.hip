@@ -301,7 +301,7 @@ template <bool ROWTHR>
 __device__ __forceinline__ void emit_candidates(const SimF16Args& a, bool all, float thr, const float (&thrb)[4],
                                                 const float* rt, float eps, int row0, int row0_tile, int64_t col0,
                                                 const f32x16 (&acc)[4][2], const float (&bm)[4][2], int lane,
-                                                int64_t seg_base, int seg_cap, int& count) {
+                                                int64_t seg_base, int seg_cap, int& count, TailExt* ext) {
     // C layout of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
     const int row_base = row0 + 4 * (lane >> 5);
     const int col_base = (int)col0 + (lane & 31);
@@ -332,15 +332,9 @@ __device__ __forceinline__ void emit_candidates(const SimF16Args& a, bool all, f
                     pos = seg_base + count;
                     count += total;
                 } else {
-                    // segment full (candidates are not spread evenly): shared tail behind the segments
-                    unsigned long long base = 0;
-                    if (lane == 0) base = atomicAdd(a.tail_count, (unsigned long long)total);
-                    base = __shfl(base, 0);
-                    if ((long long)(base + total) > a.tail_cap) {
-                        if (lane == 0) atomicOr(a.overflow, 1);
+                    // segment full (candidates are not spread evenly): the wave's chunk of the shared tail
+                    if (!tail_take(a.tail_count, a.tail_cap, a.tail_base, a.tail_shift, a.tail_fill, a.overflow, total, lane, ext, pos))
                         continue;
-                    }
-                    pos = a.tail_base + (int64_t)base;
                 }
                 if ((ok >> lane) & 1ull) {
                     pos += __popcll(ok & ((1ull << lane) - 1));
@@ -359,6 +353,7 @@ __global__ __launch_bounds__(512, 1) void sim_f16_kernel(SimF16Args a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     __shared__ float norm_max_buf[2][8];  // double-buffered by tile parity (no barrier between tiles)
     __shared__ float row_thr_buf[2][ROWTHR ? 256 : 1];
+    __shared__ TailExt tail_sh[8];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave >> 2, wc = wave & 3;
     TileThread t;
@@ -370,6 +365,7 @@ __global__ __launch_bounds__(512, 1) void sim_f16_kernel(SimF16Args a) {
     const int seg = blockIdx.x * 8 + __builtin_amdgcn_readfirstlane(wave);
     const int64_t seg_base = (int64_t)seg * a.seg_cap;
     int count = 0;
+    tail_init(&tail_sh[wave], lane);
     int64_t local = blockIdx.x >> 3;
     int tqi;
     int64_t tri;
@@ -433,7 +429,7 @@ __global__ __launch_bounds__(512, 1) void sim_f16_kernel(SimF16Args a) {
             count += mx == 12345.678f;  // keeps the accumulators alive; garbage results are not emitted
         } else if (all || __any(ROWTHR ? any_blk : mx > thr))
             emit_candidates<ROWTHR>(a, all, thr, thrb, rt, eps, tqi * BM + wr * 128, wr * 128,
-                                    tri * BN + wc * 64, acc, bm, lane, seg_base, a.seg_cap, count);
+                                    tri * BN + wc * 64, acc, bm, lane, seg_base, a.seg_cap, count, &tail_sh[wave]);
         if (!has_next) break;
         local += lstride;
         tqi = ntq;
@@ -441,6 +437,7 @@ __global__ __launch_bounds__(512, 1) void sim_f16_kernel(SimF16Args a) {
     }
     // the stream fetched two K-tiles past its end: let them land before the LDS is handed back
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    tail_close(a.tail_base, a.tail_shift, a.tail_fill, lane, &tail_sh[wave]);
     if (lane == 0) a.seg_count[seg] = count;
 }
 
@@ -459,6 +456,7 @@ int launch_sim_f16(const SimF16Args& a, hipStream_t stream) {
                                     f16::LDS_BYTES));
         VSC_HIP(hipFuncSetAttribute((const void*)sim_f16_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                     f16::LDS_BYTES));
+        once.commit();
     }
     if ((int64_t)a.tq * a.tr >= 0x7fffffffLL) {
         set_error("sim_f16: more than 2^31 output tiles in one launch");
@@ -517,13 +515,14 @@ __device__ __forceinline__ void flush_hits(const RescoreArgs& a, WaveHits& buf, 
 // candidates of one list; thread x serves candidate x >> 2 (x0 = first thread index, `step` threads apart)
 __device__ __forceinline__ void rescore_list(const RescoreArgs& a, float radius, const int32_t* ci,
                                              const int32_t* cj, long long n, long long x0, long long step,
-                                             WaveHits& buf, int& pend) {
+                                             WaveHits& buf, int& pend, const int* fill = nullptr, int shift = 0) {
     const int lane = threadIdx.x & 63, g = lane & 3;
     const long long n_thr = (4 * n + 63) & ~63ll;  // whole waves stay together (DPP, ballot)
     const int rounds = a.dpad / 32;
     for (long long x = x0; x < n_thr; x += step) {
         const long long c = x >> 2;
-        const bool valid = c < n;
+        // (the tail is a sequence of chunks, each filled up to its own level: cand_list.h)
+        const bool valid = c < n && (fill == nullptr || (int)(c & ((1ll << shift) - 1)) < fill[c >> shift]);
         const int i = valid ? ci[c] : 0, j = valid ? cj[c] : 0;
         const f32x4* q = reinterpret_cast<const f32x4*>(a.Q + (int64_t)i * a.dpad) + 2 * g;
         const f32x4* r = reinterpret_cast<const f32x4*>(a.R + (int64_t)j * a.dpad) + 2 * g;
@@ -590,7 +589,8 @@ __global__ __launch_bounds__(256) void rescore_kernel(RescoreArgs a) {
     const long long nt = nt_all < (unsigned long long)a.tail_cap ? (long long)nt_all : a.tail_cap;
     if (nt > 0) {
         rescore_list(a, radius, a.cand_i + a.tail_base, a.cand_j + a.tail_base, nt,
-                     (long long)blockIdx.x * 256 + threadIdx.x, (long long)gridDim.x * 256, buf, pend);
+                     (long long)blockIdx.x * 256 + threadIdx.x, (long long)gridDim.x * 256, buf, pend, a.tail_fill,
+                     a.tail_shift);
         if (blockIdx.x == 0) seen += (unsigned long long)nt;
     }
     flush_hits(a, buf, pend);

@@ -112,7 +112,7 @@ template <bool ROWTHR>
 __device__ __forceinline__ void emit_candidates(const SimF16PArgs& a, const bool (&all)[2], const float (&thr)[2],
                                                 const float (&eps)[2], const float* rt, const float (&rtmin)[4],
                                                 int row0, int col0, bool interior, const f32x16 (&acc)[4][2],
-                                                const float (&bm)[4][2], int64_t seg_base, int& count) {
+                                                const float (&bm)[4][2], int64_t seg_base, int& count, TailExt* ext) {
     // C layout of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
 #pragma unroll
     for (int m = 0; m < 4; ++m)
@@ -147,15 +147,9 @@ __device__ __forceinline__ void emit_candidates(const SimF16PArgs& a, const bool
                     pos = seg_base + count;
                     count += total;
                 } else {
-                    // segment full (candidates are not spread evenly): shared tail behind the segments
-                    unsigned long long base = 0;
-                    if (ln == 0) base = atomicAdd(a.tail_count, (unsigned long long)total);
-                    base = __shfl(base, 0);
-                    if ((long long)(base + total) > a.tail_cap) {
-                        if (ln == 0) atomicOr(a.overflow, 1);
+                    // segment full (candidates are not spread evenly): the wave's chunk of the shared tail
+                    if (!tail_take(a.tail_count, a.tail_cap, a.tail_base, a.tail_shift, a.tail_fill, a.overflow, total, ln, ext, pos))
                         continue;
-                    }
-                    pos = a.tail_base + (int64_t)base;
                 }
                 if (mine) {
                     pos += __builtin_amdgcn_mbcnt_hi((unsigned)(ok >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)ok, 0u));
@@ -175,7 +169,7 @@ template <bool ROWTHR>
 __device__ __forceinline__ void emit_candidates_blk(const SimF16PArgs& a, const bool (&all)[2], const float (&thr)[2],
                                                     const float (&eps)[2], const float* rt, const float (&rtmin)[4],
                                                     int row0, int col0, bool interior, const f32x16 (&acc)[4][2],
-                                                    const float (&bm)[4][2], int64_t seg_base, int& count) {
+                                                    const float (&bm)[4][2], int64_t seg_base, int& count, TailExt* ext) {
 #pragma unroll
     for (int m = 0; m < 4; ++m)
 #pragma unroll
@@ -218,15 +212,9 @@ __device__ __forceinline__ void emit_candidates_blk(const SimF16PArgs& a, const 
                 pos = seg_base + count;
                 count += total;
             } else {
-                // segment full (candidates are not spread evenly): shared tail behind the segments
-                unsigned long long base = 0;
-                if (ln == 0) base = atomicAdd(a.tail_count, (unsigned long long)total);
-                base = __shfl(base, 0);
-                if ((long long)(base + total) > a.tail_cap) {
-                    if (ln == 0) atomicOr(a.overflow, 1);
+                // segment full (candidates are not spread evenly): the wave's chunk of the shared tail
+                if (!tail_take(a.tail_count, a.tail_cap, a.tail_base, a.tail_shift, a.tail_fill, a.overflow, total, ln, ext, pos))
                     continue;
-                }
-                pos = a.tail_base + (int64_t)base;
             }
             pos += before;
             const int ibase = a.i0 + row0 + m * 32 + hi4;
@@ -291,6 +279,7 @@ __global__ __launch_bounds__(512) void sim_f16p_kernel(SimF16PArgs a) {
     __shared__ float qn_max_w[8];
     __shared__ float rt_sh[ROWTHR ? PR : 1];
     __shared__ int item_sh[2];
+    __shared__ TailExt tail_sh[8];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     constexpr int NKS = NKC * 8;
@@ -308,6 +297,7 @@ __global__ __launch_bounds__(512) void sim_f16p_kernel(SimF16PArgs a) {
     const int seg = blockIdx.x * 8 + wave;  // this wave's private segment of the candidate list
     const int64_t seg_base = (int64_t)seg * a.seg_cap;
     int count = 0;
+    tail_init(&tail_sh[wave], lane);  // the wave's chunk of the shared tail once its segment is full (cand_list.h)
     // the wave's segment of the two candidate arrays as buffer resources (emit_candidates_seg)
     const __amdgpu_buffer_rsrc_t rs_ci = __builtin_amdgcn_make_buffer_rsrc(
         (void*)uniform_ptr(reinterpret_cast<const char*>(a.out_i + seg_base)), 0, a.seg_cap * 4, 0x00020000);
@@ -323,7 +313,15 @@ __global__ __launch_bounds__(512) void sim_f16p_kernel(SimF16PArgs a) {
         __syncthreads();
         if (wave == 0) {
             int p = panel, s = 0;
+            // a launch whose candidate list has overflowed is lost (the host reruns it with larger buffers): stop
+            // taking work
+#ifndef VSC_NO_LOST_CHECK
+            const bool lost = __hip_atomic_load(a.overflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
+#else
+            const bool lost = false;
+#endif
             for (;;) {
+                if (lost) { p = -1; break; }
                 if (lane == 0) s = atomicAdd(&a.next_slice[p], 1);
                 s = __shfl(s, 0);
                 if (s < nslice) break;
@@ -443,13 +441,14 @@ __global__ __launch_bounds__(512) void sim_f16p_kernel(SimF16PArgs a) {
                     emit_candidates_seg(a, thr, panel * PR, col0, acc, bm, rs_ci, rs_cj, count);
                 else if (VSC_F16P_EMIT == 2 || (VSC_F16P_EMIT == 0 && !ROWTHR))
                     emit_candidates_blk<ROWTHR>(a, all, thr, eps, rt_sh, rtmin, panel * PR, col0, interior, acc, bm,
-                                                seg_base, count);
+                                                seg_base, count, &tail_sh[wave]);
                 else
                     emit_candidates<ROWTHR>(a, all, thr, eps, rt_sh, rtmin, panel * PR, col0, interior, acc, bm,
-                                            seg_base, count);
+                                            seg_base, count, &tail_sh[wave]);
             }
         }
     }
+    tail_close(a.tail_base, a.tail_shift, a.tail_fill, lane, &tail_sh[wave]);
     if (lane == 0) a.seg_count[seg] = count;
 }
 
@@ -475,6 +474,7 @@ static int launch_nkc(const SimF16PArgs& a, int grid, hipStream_t stream) {
     if (once.first()) {
         VSC_HIP(hipFuncSetAttribute((const void*)sim_f16p_kernel<NKC, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         VSC_HIP(hipFuncSetAttribute((const void*)sim_f16p_kernel<NKC, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        once.commit();
     }
     if (a.row_thr)
         hipLaunchKernelGGL((sim_f16p_kernel<NKC, true>), dim3((unsigned)grid), dim3(512), lds, stream, a);

@@ -106,7 +106,7 @@ __device__ __forceinline__ void emit_candidates(const SimI8PArgs& a, const bool 
                                                 const float (&eps)[2], const float (&inv)[2], const float* rt,
                                                 const float (&rtmin)[4], int row0, int col0, bool interior,
                                                 const i32x16 (&acc)[4][2], const int (&bm)[4][2], int64_t seg_base,
-                                                int& count) {
+                                                int& count, TailExt* ext) {
     // C layout of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
 #pragma unroll
     for (int m = 0; m < 4; ++m)
@@ -139,18 +139,13 @@ __device__ __forceinline__ void emit_candidates(const SimI8PArgs& a, const bool 
                     pos = seg_base + count;
                     count += total;
                 } else {
-                    unsigned long long base = 0;
-                    if (ln == 0) base = atomicAdd(a.tail_count, (unsigned long long)total);
-                    base = __shfl(base, 0);
-                    if ((long long)(base + total) > a.tail_cap) {
-                        if (ln == 0) atomicOr(a.overflow, 1);
+                    // segment full (candidates are not spread evenly): the wave's chunk of the shared tail
+                    if (!tail_take(a.tail_count, a.tail_cap, a.tail_base, a.tail_shift, a.tail_fill, a.overflow, total, ln, ext, pos))
                         continue;
-                    }
-                    pos = a.tail_base + (int64_t)base;
                 }
                 if (mine) {
                     pos += __builtin_amdgcn_mbcnt_hi((unsigned)(ok >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)ok, 0u));
-                    a.out_i[pos] = a.i0 + i;
+                    a.out_i[pos] = a.i0 + (a.perm ? a.perm[i] : i);
                     a.out_j[pos] = j;
                 }
             }
@@ -195,6 +190,7 @@ __global__ __launch_bounds__(512) void sim_i8p_kernel(SimI8PArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];  // the panel: NKC x 32 KiB
     __shared__ float rt_sh[ROWTHR ? PR : 1];
     __shared__ int item_sh[2];
+    __shared__ TailExt tail_sh[8];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     constexpr int NKS = NKC * 8;
@@ -211,6 +207,7 @@ __global__ __launch_bounds__(512) void sim_i8p_kernel(SimI8PArgs a) {
     const int seg = blockIdx.x * 8 + wave;  // this wave's private segment of the candidate list
     const int64_t seg_base = (int64_t)seg * a.seg_cap;
     int count = 0;
+    tail_init(&tail_sh[wave], lane);  // the wave's chunk of the shared tail once its segment is full (cand_list.h)
     const __amdgpu_buffer_rsrc_t rs_ci = __builtin_amdgcn_make_buffer_rsrc(
         (void*)uniform_ptr(reinterpret_cast<const char*>(a.out_i + seg_base)), 0, a.seg_cap * 4, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_cj = __builtin_amdgcn_make_buffer_rsrc(
@@ -226,7 +223,16 @@ __global__ __launch_bounds__(512) void sim_i8p_kernel(SimI8PArgs a) {
         __syncthreads();
         if (wave == 0) {
             int p = panel, s = 0;
+            // a launch whose candidate list has overflowed is lost (the host reruns the batch on the fp16 kernel or
+            // with larger buffers): stop taking work instead of pushing billions of candidates through the tail's
+            // one atomic counter (an 8-bit bound that is too loose for the data can pass most of the matrix)
+#ifndef VSC_NO_LOST_CHECK
+            const bool lost = __hip_atomic_load(a.overflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
+#else
+            const bool lost = false;
+#endif
             for (;;) {
+                if (lost) { p = -1; break; }
                 if (lane == 0) s = atomicAdd(&a.next_slice[p], 1);
                 s = __shfl(s, 0);
                 if (s < nslice) break;
@@ -346,10 +352,11 @@ __global__ __launch_bounds__(512) void sim_i8p_kernel(SimI8PArgs a) {
                     emit_candidates_seg(a, ti, panel * PR, col0, acc, bm, rs_ci, rs_cj, count);
                 else
                     emit_candidates<ROWTHR>(a, all, ti, eps, inv, rt_sh, rtmin, panel * PR, col0, interior, acc, bm,
-                                            seg_base, count);
+                                            seg_base, count, &tail_sh[wave]);
             }
         }
     }
+    tail_close(a.tail_base, a.tail_shift, a.tail_fill, lane, &tail_sh[wave]);
     if (lane == 0) a.seg_count[seg] = count;
 }
 
@@ -360,6 +367,7 @@ static int launch_nkc(const SimI8PArgs& a, int grid, hipStream_t stream) {
     if (once.first()) {
         VSC_HIP(hipFuncSetAttribute((const void*)sim_i8p_kernel<NKC, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         VSC_HIP(hipFuncSetAttribute((const void*)sim_i8p_kernel<NKC, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        once.commit();
     }
     if (a.row_thr)
         hipLaunchKernelGGL((sim_i8p_kernel<NKC, true>), dim3((unsigned)grid), dim3(512), lds, stream, a);

@@ -568,6 +568,7 @@ int launch_sim_knn(const SimKnnArgs& a, hipStream_t stream) {
         // the kernel also owns a few hundred bytes of static LDS (__syncthreads_or)
         VSC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(sim_knn_kernel),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024));
+        once.commit();
     }
     hipLaunchKernelGGL(sim_knn_kernel, dim3((unsigned)grid), dim3(256), lds, stream, a);
     VSC_HIP(hipGetLastError());
@@ -586,6 +587,7 @@ int set_thresh_kernel_attrs() {
     if (once.first()) {
         VSC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(sim_thresh_kernel),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS));
+        once.commit();
     }
     return VSC_OK;
 }

@@ -79,6 +79,39 @@ int sort_hits_topk(const int32_t* hi, const int32_t* hj, const float* hs, int64_
     return VSC_OK;
 }
 
+// ----------------------------------------------------------------------------- rows of a launch by threshold
+//
+// The int8 pre-filter tests a 32-row block against the SMALLEST of its row thresholds before it looks at single
+// accumulators; with an 8-bit error bound that gate only filters when the rows of a block have similar thresholds.
+// Inside one launch the row order is free (candidates carry their row index), so the rows are handed to the kernel
+// sorted by threshold: perm[position] = row.  16 key bits (2 radix passes) are plenty for "similar".
+__global__ __launch_bounds__(256) void thr_keys_kernel(const float* __restrict__ thr, int n, uint32_t* __restrict__ keys,
+                                                       int32_t* __restrict__ vals) {
+    const int x = blockIdx.x * 256 + threadIdx.x;
+    if (x >= n) return;
+    keys[x] = f2key(thr[x]);
+    vals[x] = x;
+}
+
+int sort_rows_by_threshold(const float* thr, int64_t n, DevBuf& w0, DevBuf& w1, DevBuf& w2, DevBuf& w3, DevBuf& tmp,
+                           const int32_t** perm, hipStream_t stream) {
+    *perm = nullptr;
+    if (n <= 0) return VSC_OK;
+    VSC_TRY(w0.reserve(sizeof(uint32_t) * n));
+    VSC_TRY(w1.reserve(sizeof(uint32_t) * n));
+    VSC_TRY(w2.reserve(sizeof(int32_t) * n));
+    VSC_TRY(w3.reserve(sizeof(int32_t) * n));
+    VSC_TRY(tmp.reserve(radix_tmp_bytes(n)));
+    uint32_t *ka = w0.as<uint32_t>(), *kb = w1.as<uint32_t>();
+    int32_t *va = w2.as<int32_t>(), *vb = w3.as<int32_t>();
+    hipLaunchKernelGGL(thr_keys_kernel, dim3(grid_for(n)), dim3(256), 0, stream, thr, (int)n, ka, va);
+    VSC_HIP(hipGetLastError());
+    const int w = radix_sort_pairs<uint32_t, int32_t>(ka, kb, va, vb, n, 16, 32, false, tmp.p, stream);
+    if (w < 0) { set_error("radix sort launch failed"); return VSC_ERR_HIP; }
+    *perm = w ? vb : va;
+    return VSC_OK;
+}
+
 // ----------------------------------------------------------------------------- pair max
 
 __global__ __launch_bounds__(256) void pair_key_kernel(const int32_t* hi, const int32_t* hj, int64_t n,

@@ -655,6 +655,7 @@ int launch_tn_pairs(const TnPairArgs& a, size_t lds_bytes, hipStream_t stream) {
     if (once.first()) {
         VSC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&tn_pair_kernel<short, false>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024));
+        once.commit();
     }
     hipLaunchKernelGGL((tn_pair_kernel<short, false>), dim3((unsigned)a.n_work), dim3(64), lds_bytes, stream, a);
     VSC_HIP(hipGetLastError());

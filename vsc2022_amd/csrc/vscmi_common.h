@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
@@ -76,13 +77,20 @@ bool poison_mode();
 // Kernel attributes (the > 64 KiB dynamic-LDS opt-in) are per DEVICE, not per process: a process that creates
 // handles on a second device must set them there too.  true exactly once per (call site, current device).
 struct PerDeviceOnce {
-    bool done[64] = {};
+    std::atomic<bool> done[64] = {};
+    int dev_seen = -1;
+    // true while the attributes of the current device are not known to be set: the caller sets them and then calls
+    // commit() -- a failed hipFuncSetAttribute returns early (VSC_HIP) and is retried by the next launch.  Two threads
+    // racing on a fresh device both set the (idempotent) attributes.
     bool first() {
         int dev = 0;
-        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return true;  // unknown device: always set
-        if (done[dev]) return false;
-        done[dev] = true;
-        return true;
+        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) { dev_seen = -1; return true; }  // unknown: always set
+        dev_seen = dev;
+        return !done[dev].load(std::memory_order_acquire);
+    }
+    void commit() {
+        int dev = 0;
+        if (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64) done[dev].store(true, std::memory_order_release);
     }
 };
 

@@ -91,9 +91,8 @@ class DeviceScoreNormalizer:
 
     def queries(self, q: torch.Tensor) -> torch.Tensor:
         q = self._prepare(q)
-        best, _ = self.noise_index.search(q, 1)
-        penalty = torch.from_numpy(best[:, :1]).to(q.device) * (-self.beta)
-        return torch.cat([q, penalty], dim=1).contiguous()
+        best, _ = self.noise_index.search(q, 1, device_out=True)  # [n, 1] in HBM: no host round trip
+        return torch.cat([q, best * (-self.beta)], dim=1).contiguous()
 
     def refs(self, r: torch.Tensor) -> torch.Tensor:
         r = self._prepare(r)

@@ -63,15 +63,21 @@ class RefShardedIndex:
         """(D float32 [n, k], I int64 [n, k]) with GLOBAL reference ids; identical on every rank."""
         n = int(x.shape[0])
         n_loc = int(self.local.ntotal)
-        D = np.full((n, k), -np.inf, dtype=np.float32)
-        I = np.full((n, k), -1, dtype=np.int64)
+        on_gpu = self.device.type == "cuda"
+        if getattr(self.local, "metric_type", 0) == 1:
+            raise NotImplementedError("the reference-sharded merge orders by larger-is-better scores (inner product)")
+        # missing slots carry the single index's sentinel (-FLT_MAX and id -1, include/vscmi.h), not -inf
+        D = torch.full((n, k), -float(np.finfo(np.float32).max), dtype=torch.float32, device=self.device)
+        I = torch.full((n, k), -1, dtype=torch.int64, device=self.device)
         kk = min(k, n_loc)
         if kk > 0 and n > 0:
-            d, i = self.local.search(x, kk)
+            if on_gpu:
+                d, i = self.local.search(x, kk, device_out=True)  # stays in HBM until the all-gather
+            else:
+                d, i = (torch.from_numpy(np.ascontiguousarray(a)) for a in self.local.search(x, kk))
             D[:, :kk] = d
-            I[:, :kk] = np.where(i >= 0, i + self.row0, -1)
-        gD, gI = vdist.ref_sharded_knn(torch.from_numpy(D).to(self.device), torch.from_numpy(I).to(self.device), k,
-                                       self.group)
+            I[:, :kk] = torch.where(i >= 0, i + self.row0, torch.full_like(i, -1))
+        gD, gI = vdist.ref_sharded_knn(D, I, k, self.group)
         return gD.cpu().numpy(), gI.cpu().numpy()
 
     # ---- global top-K of the whole score matrix

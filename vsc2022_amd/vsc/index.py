@@ -169,9 +169,20 @@ class FlatIndex:
         p, mem, n, keep = self._rows(x)
         _lib.check(_lib.lib().vsc_index_add(self._h, p, n, mem))
 
-    def search(self, x, k: int):
-        """faiss index.search: (D float32 [n, k], I int64 [n, k])."""
+    def search(self, x, k: int, device_out: bool = False):
+        """faiss index.search: (D float32 [n, k], I int64 [n, k]); with device_out torch tensors that never leave
+        the HBM (score normalisation and the reference-sharded merge consume them there)."""
         p, mem, n, keep = self._rows(x)
+        if device_out:
+            import torch
+
+            dev = torch.device("cuda", self.device)
+            D = torch.empty((n, k), dtype=torch.float32, device=dev)
+            I = torch.empty((n, k), dtype=torch.int64, device=dev)
+            torch.cuda.synchronize(dev)
+            _lib.check(_lib.lib().vsc_index_knn(self._h, p, n, mem, int(k), D.data_ptr(), I.data_ptr(),
+                                                _lib.MEM_DEVICE))
+            return D, I
         D = np.empty((n, k), dtype=np.float32)
         I = np.empty((n, k), dtype=np.int64)
         _lib.check(_lib.lib().vsc_index_knn(self._h, p, n, mem, int(k), D.ctypes.data, I.ctypes.data,
