@@ -38,5 +38,5 @@ for k in args.k:
     eff = 2.0 * args.nq * args.nr * args.dim / dt / 1e12
     print(f"k={k} nq={args.nq} nr={args.nr} wall={dt*1e3:.1f} ms (= {eff:.0f} effective TFLOP/s) | exact fp32 kernel "
           f"{p['sim_ms']:.1f} ms {p['sim_flops']/1e12/max(p['sim_ms'],1e-9)*1e3:.1f} TFLOP/s | f16 {p['f16_ms']:.1f} ms "
-          f"{p['f16_flops']/1e12/max(p['f16_ms'],1e-9)*1e3:.1f} TFLOP/s | rescore {p['rescore_ms']:.1f} ms "
+          f"{p['f16_flops']/1e12/max(p['f16_ms'],1e-9)*1e3:.1f} TFLOP/s | i8 {p['i8_ms']:.1f} ms | rescore {p['rescore_ms']:.1f} ms "
           f"candidates={p['candidates']}")

@@ -212,6 +212,93 @@ def test_int8_chosen_by_density_equals_fp16_and_fp32_routes(gpu):
         assert outs[0][0][3] == other[0][3]
 
 
+def score_normalised_like(rng, nq, nr, d):
+    """Descriptors shaped like the output of score_normalize (vsc/baseline/score_normalization.py:99-104): unit rows
+    in d - 1 coordinates, the last coordinate = 1 for every reference and a per-row penalty for the queries."""
+    q = np.concatenate([unit(rng, nq, d - 1), -rng.uniform(0.15, 0.45, (nq, 1)).astype(np.float32)], axis=1)
+    r = np.concatenate([unit(rng, nr, d - 1), np.ones((nr, 1), np.float32)], axis=1)
+    return np.ascontiguousarray(q), np.ascontiguousarray(r)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("nq,nr,d,K,k", [(700, 3000, 129, 900, 5), (300, 1500, 512, 400, 1), (1100, 5000, 65, 3000, 20)])
+def test_constant_reference_coordinate_is_kept_out_of_the_int8_image(gpu, orc, nq, nr, d, K, k):
+    """All references agree on the last coordinate (score-normalised descriptors): it is excluded from the 8-bit
+    images and enters through per-row thresholds (rows of a launch sorted by threshold).  Forced int8, thresholded
+    search and k-NN against the oracle."""
+    rng = np.random.default_rng(nq + d)
+    q, r = score_normalised_like(rng, nq, nr, d)
+    q[7] = q[8]
+    r[30:50] = r[30]
+    idx = forced_index(d)
+    idx.profile(True)
+    idx.add(r[: nr // 2 + 3])
+    idx.add(r[nr // 2 + 3:])
+    i, j, s, radius = idx.global_topk(q, K)
+    oi, oj, os_, info = orc.global_threshold_search(q, r, K, 0, return_info=True)
+    assert_same((i, j, s), (oi, oj, os_))
+    assert np.float32(radius) == np.float32(info["radius"])
+    D, I = idx.search(q, k)
+    oD, oI = orc.knn(q, r, k)
+    assert np.array_equal(I, oI) and np.array_equal(bits(D), bits(oD))
+    assert i8_launches(idx) > 0
+
+
+@pytest.mark.gpu
+def test_excluded_coordinates_follow_the_rows_that_are_added(gpu, orc):
+    """The set of coordinates on which ALL references agree can only shrink as rows arrive: the image is rewritten
+    before the next search when it does.  More agreeing coordinates than the 8 the kernels handle; a huge one; a NaN
+    in a query's excluded coordinate."""
+    rng = np.random.default_rng(77)
+    d = 96
+    q, r = unit(rng, 500, d), unit(rng, 2600, d)
+    const = {3: 0.7, 10: -1.5, 11: 2.0, 20: 0.25, 21: 0.25, 22: 0.25, 23: 0.25, 24: 0.25, 25: 0.25, 26: 0.25, 40: 30.0}
+    for c, v in const.items():
+        r[:, c] = v
+    r[1800:, 10] = 0.3          # the third add breaks the agreement on coordinate 10 ...
+    r[1800:, 40] = -2.0         # ... and on the largest one
+    q[:, 40] *= 0.05
+    idx = forced_index(d)
+    idx.profile(True)
+    for lo, hi, K in ((0, 900, 700), (900, 1800, 1500), (1800, 2600, 2500)):
+        idx.add(r[lo:hi])
+        got = idx.global_topk(q, K)
+        assert_same(got[:3], orc.global_threshold_search(q, r[:hi], K))
+        D, I = idx.search(q, 3)
+        oD, oI = orc.knn(q, r[:hi], 3)
+        assert np.array_equal(I, oI) and np.array_equal(bits(D), bits(oD))
+    assert i8_launches(idx) > 0
+    q2 = q.copy()
+    q2[5, 3] = np.nan           # excluded coordinate of a query row: its threshold is NaN, every pair must pass
+    q2[6, 11] = np.inf
+    assert_same(idx.global_topk(q2, 1200)[:3], orc.global_threshold_search(q2, r, 1200))
+
+
+@pytest.mark.gpu
+def test_int8_is_chosen_for_score_normalised_descriptors(gpu):
+    """Without the exclusion the looseness gate keeps score-normalised references off the int8 kernel (one
+    coordinate sets the scale of the row); with it the density rule picks int8 for the late batches, and the three
+    device routes agree bit for bit."""
+    from vsc2022_amd.vsc.index import FlatIndex
+
+    rng = np.random.default_rng(36)
+    q, r = score_normalised_like(rng, 70000, 120000, 128)
+    K = 300000
+    outs = []
+    for kv in (dict(VSC_I8=None, VSC_PREFILTER=None, VSC_I8_EXCLUDE=None), dict(VSC_I8="0", VSC_PREFILTER=None, VSC_I8_EXCLUDE=None),
+               dict(VSC_I8="0", VSC_PREFILTER="0", VSC_I8_EXCLUDE=None)):
+        with env(**kv):
+            idx = FlatIndex(128)
+        idx.profile(True)
+        idx.add(r)
+        out = idx.global_topk(q, K)
+        outs.append((out, idx.profile_read(reset=True)))
+    assert outs[0][1]["i8_launches"] > 0 and outs[1][1]["i8_launches"] == 0 and outs[1][1]["f16_launches"] > 0
+    for other in outs[1:]:
+        assert_same(outs[0][0][:3], other[0][:3])
+        assert outs[0][0][3] == other[0][3]
+
+
 @pytest.mark.gpu
 def test_parity_suites_with_forced_int8():
     """The search / candidate / golden / sharded / pre-filter parity suites again with the int8 kernel on every

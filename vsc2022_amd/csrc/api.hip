@@ -67,11 +67,12 @@ struct Workspace {
     DevBuf slices;          // per-panel slice counters of the panel-stationary pre-filter
     DevBuf q8, pstat;       // int8 image + per-panel {1/s, E, N, s} of ONE launch's query rows (sim_i8p.hip)
     DevBuf tailfill;        // fill levels of the chunks of the candidate list's shared tail (cand_list.h)
-    DevBuf rt8;             // ... and its row thresholds in position order (rows sorted by threshold inside a launch)
+    DevBuf rt8, rt8b;       // ... and its row thresholds in position order (rows sorted by threshold inside a launch);
+                            // rt8b: thresholds lowered by the excluded coordinates' contribution, in row order
     void release() {
         stage.release(); qbuf.release();
         qh.release(); qn.release(); ci.release(); cj.release(); segcnt.release(); rowthr.release(); slices.release();
-        q8.release(); pstat.release(); rt8.release(); tailfill.release();
+        q8.release(); pstat.release(); rt8.release(); rt8b.release(); tailfill.release();
         for (auto& b : hA) b.release();
         for (auto& b : hB) b.release();
         ctl.release(); w0.release(); w1.release(); w2.release(); w3.release(); tmp.release(); cnt.release();
@@ -90,15 +91,10 @@ struct HalfImage {
     int dpadh = 0;
     bool frag = false;         // fragment-major reference image of the panel-stationary pre-filter (sim_f16p.hip)
     int64_t row0 = 0;          // fragment-major: absolute index of the first row written
-    // optional int8 image of the same rows (quant_i8.hip; fragment-major, same row0 / rows_out)
-    void* i8 = nullptr;        // base of the WHOLE int8 image
-    float4* i8meta = nullptr;  // first meta entry to write
-    int dpad8 = 0;
 };
 
 static int pack_half_any(const float* x, int64_t n, int dim, const HalfImage& h, int64_t r0, int64_t rows_out,
                          hipStream_t stream) {
-    if (h.i8) VSC_TRY(launch_quant_ref_frag(x, n, dim, h.i8, h.i8meta + r0, h.row0 + r0, rows_out, h.dpad8, stream));
     if (h.frag)
         return launch_pack_half_frag(x, n, dim, h.rows, h.norms + r0, h.row0 + r0, rows_out, h.dpadh, stream);
     return launch_pack_half(x, n, dim, h.rows + r0 * h.dpadh, h.norms + r0, rows_out, h.dpadh, stream);
@@ -148,6 +144,14 @@ struct vsc_index {
     // (0.17 for unit-norm Gaussian-like rows); above i8_max_rel the 8-bit bound passes too much and the batches stay
     // on the fp16 kernel (e.g. score-normalised descriptors: one coordinate of every row is 1, the scale follows it)
     double i8_loose_sum = 0.0, i8_loose_cnt = 0.0, i8_max_rel = 0.35;
+    // coordinates on which all reference rows agree (order-preserving keys of the per-coordinate min / max over every
+    // row added so far), the ones the int8 image currently leaves out, and whether the image lags behind the rows
+    // (it is (re)written from the packed fp32 rows: for the new rows at `add` while the excluded set stays the same,
+    // for all rows before the next search when it changed)
+    std::vector<unsigned> cmin_key, cmax_key;
+    ExcludedDims i8_ex;
+    bool i8_dirty = false;
+    int64_t i8_rows = 0;  // rows [0, i8_rows) of the image are current
     unsigned long long stat_i8_fallbacks = 0;
     bool prefilter = false, prefilter_force = false;
     double prefilter_density = 0.02;  // expected hit density below which a batch goes through the pre-filter
@@ -366,6 +370,77 @@ int vsc_index_sync(vsc_index_t* idx) {
     return VSC_OK;
 }
 
+}  // extern "C"
+
+// (Re)write rows [row0, row0 + rows) of the int8 image and their meta from the packed fp32 rows, with the index's
+// current set of excluded coordinates; the first `count_rows - row0` of them enter the looseness statistic.
+static int i8_quantise(vsc_index* idx, int64_t row0, int64_t rows, int64_t count_rows) {
+    if (rows <= 0) return VSC_OK;
+    VSC_TRY(launch_quant_ref_frag(idx->ref.as<float>(), idx->dpad, idx->ref8.p, idx->ref8m.as<float4>(), row0, rows,
+                                  idx->dpad8, idx->i8_ex, idx->stream));
+    const int64_t real = std::max<int64_t>(0, std::min(row0 + rows, count_rows) - row0);
+    VSC_TRY(idx->ws.cnt.reserve(2 * sizeof(double)));
+    VSC_TRY(launch_meta_looseness(idx->ref8m.as<float4>() + row0, real, idx->ws.cnt.as<double>(), idx->stream));
+    double h2[2] = {0.0, 0.0};
+    VSC_HIP(hipMemcpyAsync(h2, idx->ws.cnt.p, sizeof(h2), hipMemcpyDeviceToHost, idx->stream));
+    VSC_HIP(hipStreamSynchronize(idx->stream));
+    idx->i8_loose_sum += h2[0];
+    idx->i8_loose_cnt += h2[1];
+    idx->i8_rows = std::max(idx->i8_rows, row0 + rows);
+    return VSC_OK;
+}
+
+// After `n` rows were appended at `first_new` (already packed): fold their per-coordinate min / max into the index's,
+// re-derive the set of coordinates on which ALL rows agree (up to 8, largest magnitude first, zero values are
+// pointless) and either quantise just the new rows (set unchanged) or mark the whole image stale.
+static int i8_after_add(vsc_index* idx, int64_t first_new, int64_t n, int64_t need_rows) {
+    const int dpad = idx->dpad;
+    VSC_TRY(idx->ws.tmp.reserve((size_t)2 * dpad * sizeof(unsigned)));
+    unsigned* d_mn = idx->ws.tmp.as<unsigned>();
+    unsigned* d_mx = d_mn + dpad;
+    VSC_TRY(launch_dim_minmax(idx->ref.as<float>() + first_new * dpad, n, dpad, d_mn, d_mx, idx->stream));
+    std::vector<unsigned> mn((size_t)dpad), mx((size_t)dpad);
+    VSC_HIP(hipMemcpyAsync(mn.data(), d_mn, (size_t)dpad * sizeof(unsigned), hipMemcpyDeviceToHost, idx->stream));
+    VSC_HIP(hipMemcpyAsync(mx.data(), d_mx, (size_t)dpad * sizeof(unsigned), hipMemcpyDeviceToHost, idx->stream));
+    VSC_HIP(hipStreamSynchronize(idx->stream));
+    if (idx->cmin_key.empty()) {
+        idx->cmin_key.assign((size_t)idx->dim, 0xffffffffu);
+        idx->cmax_key.assign((size_t)idx->dim, 0u);
+    }
+    for (int k = 0; k < idx->dim; ++k) {
+        const int p = k_slot(k);
+        idx->cmin_key[(size_t)k] = std::min(idx->cmin_key[(size_t)k], mn[(size_t)p]);
+        idx->cmax_key[(size_t)k] = std::max(idx->cmax_key[(size_t)k], mx[(size_t)p]);
+    }
+    // constant coordinates, largest magnitude first
+    std::vector<std::pair<float, int>> cst;
+    for (int k = 0; k < idx->dim; ++k)
+        if (idx->cmin_key[(size_t)k] == idx->cmax_key[(size_t)k]) {
+            const float v = key2f(idx->cmin_key[(size_t)k]);
+            if (std::isfinite(v) && v != 0.0f) cst.emplace_back(-std::fabs(v), k);
+        }
+    std::sort(cst.begin(), cst.end());
+    ExcludedDims ex;
+    static const bool no_ex = getenv("VSC_I8_EXCLUDE") && getenv("VSC_I8_EXCLUDE")[0] == '0';
+    for (size_t c = 0; c < cst.size() && ex.n < I8_MAX_EXCLUDED && !no_ex; ++c) {
+        ex.idx[ex.n] = cst[c].second;
+        ex.val[ex.n] = key2f(idx->cmin_key[(size_t)cst[c].second]);
+        ++ex.n;
+    }
+    bool same = ex.n == idx->i8_ex.n;
+    for (int c = 0; same && c < ex.n; ++c) same = ex.idx[c] == idx->i8_ex.idx[c] && ex.val[c] == idx->i8_ex.val[c];
+    if (!same && first_new > 0) {
+        idx->i8_ex = ex;
+        idx->i8_dirty = true;  // the rows quantised so far left other coordinates out
+        return VSC_OK;
+    }
+    idx->i8_ex = ex;
+    if (idx->i8_dirty) return VSC_OK;  // everything is rewritten before the next search anyway
+    return i8_quantise(idx, first_new, need_rows - first_new, first_new + n);
+}
+
+extern "C" {
+
 int vsc_index_add(vsc_index_t* idx, const float* x, int64_t n, int x_mem) {
     if (!idx || n < 0 || (n > 0 && !x)) {
         set_error("vsc_index_add: invalid argument");
@@ -431,25 +506,22 @@ int vsc_index_add(vsc_index_t* idx, const float* x, int64_t n, int x_mem) {
         h.norms = idx->refn.as<float>() + idx->ntotal;
         h.rows_out = need_rows - idx->ntotal;
         h.dpadh = idx->dpadh;
-        if (idx->i8_mode) {
-            h.i8 = idx->ref8.p;
-            h.i8meta = idx->ref8m.as<float4>() + idx->ntotal;
-            h.dpad8 = idx->dpad8;
-        }
     }
     VSC_TRY(pack_into(x, n, idx->dim, x_mem, dst, need_rows - idx->ntotal, idx->dpad, idx->ws, idx->stream, h));
-    if (idx->i8_mode) {
-        // looseness of the 8-bit image of the new rows (two doubles through the sort scratch)
-        VSC_TRY(idx->ws.cnt.reserve(2 * sizeof(double)));
-        VSC_TRY(launch_meta_looseness(idx->ref8m.as<float4>() + idx->ntotal, n, idx->ws.cnt.as<double>(), idx->stream));
-        double h2[2] = {0.0, 0.0};
-        VSC_HIP(hipMemcpyAsync(h2, idx->ws.cnt.p, sizeof(h2), hipMemcpyDeviceToHost, idx->stream));
-        VSC_HIP(hipStreamSynchronize(idx->stream));
-        idx->i8_loose_sum += h2[0];
-        idx->i8_loose_cnt += h2[1];
-    }
     VSC_HIP(hipStreamSynchronize(idx->stream));
+    const int64_t first_new = idx->ntotal;
     idx->ntotal += n;
+    if (idx->i8_mode) VSC_TRY(i8_after_add(idx, first_new, n, need_rows));
+    return VSC_OK;
+}
+
+// Call before a search that may use the int8 kernel: brings the image up to date when the set of excluded
+// coordinates changed since it was written.
+static int i8_prepare(vsc_index* idx) {
+    if (!idx->i8_mode || !idx->i8_dirty) return VSC_OK;
+    idx->i8_loose_sum = idx->i8_loose_cnt = 0.0;
+    VSC_TRY(i8_quantise(idx, 0, round_up64(idx->ntotal, ROW_PAD_REF), idx->ntotal));
+    idx->i8_dirty = false;
     return VSC_OK;
 }
 
@@ -538,16 +610,30 @@ static int enqueue_f16(vsc_index* idx, const float* qpacked, int64_t i0, int64_t
             VSC_TRY(prof_begin(idx, &stop, 5));
             const int32_t* perm = nullptr;
             float* rt_pos = nullptr;
-            if (row_thr) {
-                // k-NN thresholds differ from row to row: the launch sees its rows sorted by threshold
+            const float* thr_src = row_thr ? row_thr + i0 : nullptr;
+            if (idx->i8_ex.n > 0) {
+                // coordinates the images leave out (all references agree on them) act through the rows' thresholds:
+                // t_row - sum_c q_c v_c, with t_row the row's k-NN threshold or the search radius
+                VSC_TRY(idx->ws.rt8b.reserve((size_t)nqb * sizeof(float)));
+                VSC_TRY(launch_row_bias_thresholds(qpacked + i0 * idx->dpad, idx->dpad, nqb, thr_src, &ctl->radius,
+                                                   idx->i8_ex, idx->ws.rt8b.as<float>(), idx->stream));
+                thr_src = idx->ws.rt8b.as<float>();
+            }
+            // VSC_I8_SORT=0: rows in their own order (A/B; the kernel then gates blocks of unrelated thresholds)
+            static const bool sort_rows = !(getenv("VSC_I8_SORT") && getenv("VSC_I8_SORT")[0] == '0');
+            if (thr_src && !sort_rows) {
                 VSC_TRY(idx->ws.rt8.reserve((size_t)f.npanel * F16P_PANEL_ROWS * sizeof(float)));
                 rt_pos = idx->ws.rt8.as<float>();
-                VSC_TRY(sort_rows_by_threshold(row_thr + i0, nqb, idx->ws.w0, idx->ws.w1, idx->ws.w2, idx->ws.w3,
-                                               idx->ws.tmp, &perm, idx->stream));
+            } else if (thr_src) {
+                // thresholds that differ from row to row: the launch sees its rows sorted by threshold (the kernel
+                // gates 32-row blocks by their smallest threshold)
+                VSC_TRY(idx->ws.rt8.reserve((size_t)f.npanel * F16P_PANEL_ROWS * sizeof(float)));
+                rt_pos = idx->ws.rt8.as<float>();
+                VSC_TRY(sort_rows_by_threshold(thr_src, nqb, idx->ws.w0, idx->ws.w1, idx->ws.w2, idx->ws.w3, idx->ws.tmp,
+                                               &perm, idx->stream));
             }
             VSC_TRY(launch_quant_query_panels(qpacked + i0 * idx->dpad, idx->dpad, nqb, f.npanel, idx->ws.q8.p, idx->dpad8,
-                                              idx->ws.pstat.as<float4>(), perm, row_thr ? row_thr + i0 : nullptr, rt_pos,
-                                              idx->stream));
+                                              idx->ws.pstat.as<float4>(), perm, thr_src, rt_pos, idx->i8_ex, idx->stream));
             f.Q = idx->ws.q8.p;
             f.pstat = idx->ws.pstat.as<float4>();
             f.Rf = idx->ref8.p;
@@ -747,6 +833,7 @@ int vsc_index_global_topk(vsc_index_t* idx, const float* q, int64_t nq, int q_me
     VSC_HIP(hipSetDevice(idx->device));
     float* qp = nullptr;
     VSC_TRY(pack_queries(idx, q, nq, q_mem, &qp, idx->prefilter));
+    VSC_TRY(i8_prepare(idx));
     const int64_t cap_max = nq * idx->ntotal + 1024;  // the whole score matrix always fits
     int64_t cap = idx->hit_cap_user;
     if (cap <= 0) cap = std::max<int64_t>(32 * idx->ntotal, 2 * K) + 2 * K + 1024;
@@ -795,6 +882,9 @@ int vsc_index_global_topk(vsc_index_t* idx, const float* q, int64_t nq, int q_me
             // these rows -- same buffers, fp16 pre-filter throughout
             allow_i8 = false;
             idx->stat_i8_fallbacks += 1;
+            if (getenv("VSC_DEBUG_I8"))
+                fprintf(stderr, "[vscmi] int8 batches overflowed the candidate list (cap %lld, candidates so far %llu, tail %llu, "
+                        "kept %llu): fp16 pre-filter for this search\n", (long long)cap, h.n_cand_total, h.n_tail, h.n);
             continue;
         }
         // A batch emitted more hits than the buffer holds (heavy score ties keep the radius low).
@@ -906,6 +996,7 @@ int vsc_index_range_search(vsc_index_t* idx, const float* q, int64_t nq, int q_m
     VSC_HIP(hipSetDevice(idx->device));
     float* qp = nullptr;
     VSC_TRY(pack_queries(idx, q, nq, q_mem, &qp, idx->prefilter));
+    VSC_TRY(i8_prepare(idx));
     int64_t cap = idx->hit_cap_user > 0 ? idx->hit_cap_user : std::min<int64_t>(nq * idx->ntotal, (int64_t)1 << 28);
     cap = std::max<int64_t>(cap, 1024);
     VSC_TRY(ensure_hit_buffers(idx, cap));
@@ -1004,7 +1095,7 @@ static int knn_threshold_pass(vsc_index* idx, const float* qp, int64_t nq, int64
     // the candidate list is consumed slab by slab, only the hits accumulate over the whole query set
     const int64_t slab_rows = std::min(nq, step);
     // (the int8 bound is looser: ~4-5x the candidates per hit)
-    int64_t ccap = std::min<int64_t>((int64_t)((double)slab_rows * per_row * (use_i8 ? 4.0 : 1.0)) + (1 << 20),
+    int64_t ccap = std::min<int64_t>((int64_t)((double)slab_rows * per_row * (use_i8 ? 6.0 : 1.0)) + (1 << 20),
                                      slab_rows * nrefs + 1024);
     if (!use_i8) ccap = std::min(ccap, std::max<int64_t>(cap, 1024));
     VSC_TRY(ensure_hit_buffers(idx, cap, ccap, false));
@@ -1109,6 +1200,7 @@ int vsc_index_knn(vsc_index_t* idx, const float* q, int64_t nq, int q_mem, int k
                      (idx->prefilter_force || ((double)nq * (double)nr >= 4e9 && nr >= 65536));
     float* qp = nullptr;
     VSC_TRY(pack_queries(idx, q, nq, q_mem, &qp, pre));
+    if (pre) VSC_TRY(i8_prepare(idx));
     float* ds = out_s;
     int64_t* dj = out_j;
     if (out_mem == VSC_MEM_HOST) {

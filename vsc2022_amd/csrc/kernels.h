@@ -48,9 +48,22 @@ struct SimF16PArgs {
 // scale per 128-row panel (quant_query_panels), the reference side the fragment-major int8 image + per-row meta of
 // launch_quant_ref_frag (quant_i8.hip)
 constexpr int I8P_MAX_DPAD8 = 1024;    // the panel must fit the LDS: 128 rows x dpad8 B <= 128 KiB
+// coordinates left out of the int8 images because every reference row holds the same value there (quant_i8.hip)
+constexpr int I8_MAX_EXCLUDED = 8;
+struct ExcludedDims {
+    int n = 0;
+    int idx[I8_MAX_EXCLUDED] = {};     // logical coordinate
+    float val[I8_MAX_EXCLUDED] = {};   // the references' common value
+    __host__ __device__ bool holds(int k) const {
+        bool h = false;
+#pragma unroll
+        for (int c = 0; c < I8_MAX_EXCLUDED; ++c) h |= c < n && idx[c] == k;
+        return h;
+    }
+};
 struct SimI8PArgs {
-    const void* Q; const float4* pstat;   // [npanel * 128][dpad8] int8; per panel {1 / s, max E, max N, s}
-    const void* Rf; const float4* rmeta;  // fragment-major int8 image; per reference row {1 / s, E, N, s}
+    const void* Q; const float4* pstat;   // [npanel * 128][dpad8] int8; per panel {1 / s, max E, max N, max N'}
+    const void* Rf; const float4* rmeta;  // fragment-major int8 image; per reference row {1 / s, E, N, N'}
     int dpad8; int nq; int i0; int nr;
     int npanel; int nsteps; int slice;     // work split (sim_f16p_plan)
     int* next_slice;
@@ -110,10 +123,12 @@ int launch_rescore(const RescoreArgs&, hipStream_t);
 void sim_f16p_plan(int64_t nq, int64_t nr, int* npanel, int* nsteps, int* slice, int* grid);
 int launch_sim_f16p(const SimF16PArgs&, int grid, hipStream_t);
 int launch_sim_i8p(const SimI8PArgs&, int grid, hipStream_t);
-int launch_quant_ref_frag(const float*, int64_t, int, void*, float4*, int64_t, int64_t, int, hipStream_t);
+int launch_quant_ref_frag(const float*, int, void*, float4*, int64_t, int64_t, int, const ExcludedDims&, hipStream_t);
+int launch_dim_minmax(const float*, int64_t, int, unsigned*, unsigned*, hipStream_t);
 int launch_meta_looseness(const float4*, int64_t, double*, hipStream_t);
 int launch_quant_query_panels(const float*, int, int, int, void*, int, float4*, const int32_t*, const float*, float*,
-                              hipStream_t);
+                              const ExcludedDims&, hipStream_t);
+int launch_row_bias_thresholds(const float*, int, int, const float*, const float*, const ExcludedDims&, float*, hipStream_t);
 int sort_rows_by_threshold(const float*, int64_t, DevBuf&, DevBuf&, DevBuf&, DevBuf&, DevBuf&, const int32_t**, hipStream_t);
 int launch_pack_half_frag(const float*, int64_t, int, _Float16*, float*, int64_t, int64_t, int, hipStream_t);
 int launch_pack_half(const float*, int64_t, int, _Float16*, float*, int64_t, int, hipStream_t);

@@ -10,10 +10,20 @@
 //
 //   quant_ref_frag    reference rows: one scale per ROW (max |x| / 127), fragment-major image (the B operand of one
 //                     v_mfma_i32_32x32x32_i8 -- lane l: row l & 31, k bytes 16 (l >> 5) .. + 15 -- is 1 KiB of
-//                     consecutive memory), meta[row] = {1 / s, E, N, s}
+//                     consecutive memory), meta[row] = {1 / s, E, N, N'}
 //   quant_query_panels  query rows of ONE launch: one scale per 128-row PANEL (the kernel's epilogue compares the
 //                     integer accumulators of a whole panel against one threshold per reference column), natural
-//                     image [panel rows][dpad8], pstat[panel] = {1 / s, max E, max N, s}
+//                     image [panel rows][dpad8], pstat[panel] = {1 / s, max E, max N, max N'}
+//
+// EXCLUDED coordinates.  A coordinate that has the same value v_c in every reference row contributes q_c v_c to every
+// score of query row q: a per-row constant, not something 8 bits should be spent on -- and when it is large it
+// ruins the scale of the whole row (score-normalised descriptors, vsc/baseline/score_normalization.py:99-104: the
+// last coordinate of every reference is 1, the others ~0.04; one scale for both leaves +-5 levels for the
+// descriptor).  Up to 8 such coordinates are left out of both images (quantised as 0, not counted in E and N');
+// their contribution b_q = sum_c q_c v_c moves the row's threshold instead (row_bias_thresholds), which the kernel's
+// per-row-threshold variant applies.  N stays the norm of the WHOLE row (the rounding of the exact fp32 chain scales
+// with it), N' is the norm of what the image represents:
+//     | x . y - b - s_x s_y (q_x . q_y) | <= E_x N'_y + (N'_x + E_x) E_y       (x, y restricted to the kept coordinates)
 #include <algorithm>
 
 #include "kernels.h"
@@ -34,33 +44,44 @@ __device__ __forceinline__ int quant1(float x, float inv_s, float s, float& ss_e
     return (int)q;
 }
 
-// One wave per row, lane c holds k = 16 c .. 16 c + 15 (dims <= 1024).  `row0` = absolute index of the first row
-// written (incremental adds append to a partly filled 64-row tile); rows [row0 + n, row0 + rows_out) are zero rows.
-__global__ __launch_bounds__(256) void quant_ref_frag_kernel(const float* __restrict__ src, int64_t n, int dim,
+// One wave per row, lane c holds k = 16 c .. 16 c + 15 (dims <= 1024); source = the PACKED fp32 rows of the index
+// (vscmi_common.h: dpad floats per row, every group of 8 stored [k0 k2 k4 k6 | k1 k3 k5 k7]; rows past the last one
+// and coordinates past dim are zero).  Rows [row0, row0 + rows) of the index are (re)written.
+__global__ __launch_bounds__(256) void quant_ref_frag_kernel(const float* __restrict__ packed, int dpad,
                                                              i32x4* __restrict__ image, float4* __restrict__ meta,
-                                                             int64_t row0, int64_t rows_out, int dpad8) {
+                                                             int64_t row0, int64_t rows, int dpad8, ExcludedDims ex) {
     const int lane = threadIdx.x & 63;
     const int64_t rel = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (rel >= rows_out) return;
+    if (rel >= rows) return;
     const int64_t row = row0 + rel;
     const int npiece = dpad8 / 16, nks = dpad8 / 32;
-    const float* r = src + rel * dim;
     float v[16];
-    float amax = 0.0f, ss_n = 0.0f;
+    float amax = 0.0f, ss_n = 0.0f, ss_k = 0.0f;
     bool bad = false;
+    if (lane * 16 < dpad) {
+        const float4* src = reinterpret_cast<const float4*>(packed + row * dpad + lane * 16);
+        const float4 e0 = src[0], o0 = src[1], e1 = src[2], o1 = src[3];
+        const float t[16] = {e0.x, o0.x, e0.y, o0.y, e0.z, o0.z, e0.w, o0.w, e1.x, o1.x, e1.y, o1.y, e1.z, o1.z, e1.w, o1.w};
+#pragma unroll
+        for (int e = 0; e < 16; ++e) v[e] = t[e];
+    } else {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) v[e] = 0.0f;
+    }
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
-        const int k = lane * 16 + e;
-        const float x = (rel < n && k < dim) ? r[k] : 0.0f;
-        v[e] = x;
+        const float x = v[e];
         bad |= !(fabsf(x) <= 3.0e38f);
-        amax = fmaxf(amax, fabsf(x));
         ss_n = __fmaf_rn(x, x, ss_n);
+        if (ex.holds(lane * 16 + e)) v[e] = 0.0f;  // excluded coordinate: not in the image
+        amax = fmaxf(amax, fabsf(v[e]));
+        ss_k = __fmaf_rn(v[e], v[e], ss_k);
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
         amax = fmaxf(amax, __shfl_xor(amax, off));
         ss_n += __shfl_xor(ss_n, off);
+        ss_k += __shfl_xor(ss_k, off);
     }
     bad = __any(bad);
     float s = amax / 127.0f;
@@ -83,31 +104,60 @@ __global__ __launch_bounds__(256) void quant_ref_frag_kernel(const float* __rest
     if (lane == 0) {
         float4 m;
         m.x = inv_s;
-        m.y = bad ? INFINITY : norm_up(ss_e, dim);
-        m.z = bad ? INFINITY : norm_up(ss_n, dim);
-        m.w = s;
-        meta[rel] = m;
+        m.y = bad ? INFINITY : norm_up(ss_e, dpad);
+        m.z = bad ? INFINITY : norm_up(ss_n, dpad);
+        m.w = bad ? INFINITY : norm_up(ss_k, dpad);
+        meta[row] = m;
     }
 }
 
-// image: base of the whole fragment-major image; meta: first entry to write (row0's)
-int launch_quant_ref_frag(const float* src, int64_t n, int dim, void* image, float4* meta, int64_t row0,
-                          int64_t rows_out, int dpad8, hipStream_t stream) {
-    if (rows_out <= 0) return VSC_OK;
-    hipLaunchKernelGGL(quant_ref_frag_kernel, dim3((unsigned)((rows_out + 3) / 4)), dim3(256), 0, stream, src, n, dim,
-                       reinterpret_cast<i32x4*>(image), meta, row0, rows_out, dpad8);
+// image / meta: bases of the whole fragment-major image and of the whole meta table
+int launch_quant_ref_frag(const float* packed, int dpad, void* image, float4* meta, int64_t row0, int64_t rows, int dpad8,
+                          const ExcludedDims& ex, hipStream_t stream) {
+    if (rows <= 0) return VSC_OK;
+    hipLaunchKernelGGL(quant_ref_frag_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, stream, packed, dpad,
+                       reinterpret_cast<i32x4*>(image), meta, row0, rows, dpad8, ex);
     VSC_HIP(hipGetLastError());
     return VSC_OK;
 }
 
-// sum over rows of E / N (rows with a finite, non-zero N) and their count: how loose the 8-bit bound is relative to
+// Per-coordinate minimum and maximum over packed rows, as order-preserving keys (f2key) in packed-position order:
+// mn[p] / mx[p] must hold 0xffffffff / 0 on entry.  A coordinate is constant over the rows iff its two keys agree.
+__global__ __launch_bounds__(256) void dim_minmax_kernel(const float* __restrict__ packed, int64_t rows, int dpad,
+                                                         unsigned* __restrict__ mn, unsigned* __restrict__ mx) {
+    const int64_t per = (rows + gridDim.y - 1) / gridDim.y;
+    const int64_t r0 = (int64_t)blockIdx.y * per, r1 = min(rows, r0 + per);
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= dpad || r0 >= r1) return;
+    unsigned lo = 0xffffffffu, hi = 0u;
+    for (int64_t r = r0; r < r1; ++r) {
+        const unsigned k = f2key(packed[r * dpad + p]);
+        lo = min(lo, k);
+        hi = max(hi, k);
+    }
+    atomicMin(&mn[p], lo);
+    atomicMax(&mx[p], hi);
+}
+
+int launch_dim_minmax(const float* packed, int64_t rows, int dpad, unsigned* mn, unsigned* mx, hipStream_t stream) {
+    VSC_HIP(hipMemsetAsync(mn, 0xff, (size_t)dpad * sizeof(unsigned), stream));
+    VSC_HIP(hipMemsetAsync(mx, 0x00, (size_t)dpad * sizeof(unsigned), stream));
+    if (rows <= 0) return VSC_OK;
+    const unsigned chunks = (unsigned)std::max<int64_t>(1, std::min<int64_t>(1024, rows / 256));
+    hipLaunchKernelGGL(dim_minmax_kernel, dim3((unsigned)((dpad + 255) / 256), chunks), dim3(256), 0, stream, packed, rows,
+                       dpad, mn, mx);
+    VSC_HIP(hipGetLastError());
+    return VSC_OK;
+}
+
+// sum over rows of E / N' (rows with a finite, non-zero N') and their count: how loose the 8-bit bound is relative to
 // the rows it describes.  For two sets of rows with isotropic directions eps / sigma(score) ~ sqrt(dim) (E_q / N_q +
 // E_r / N_r): api.hip keeps the int8 kernel off when the references alone already spend the budget.
 __global__ __launch_bounds__(256) void meta_looseness_kernel(const float4* __restrict__ meta, int64_t n, double* __restrict__ out) {
     double s = 0.0, c = 0.0;
     for (int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x; r < n; r += (int64_t)gridDim.x * 256) {
         const float4 m = meta[r];
-        if (m.z > 0.0f && m.z < INFINITY && m.y < INFINITY) { s += (double)m.y / (double)m.z; c += 1.0; }
+        if (m.w > 0.0f && m.w < INFINITY && m.y < INFINITY) { s += (double)m.y / (double)m.w; c += 1.0; }
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) { s += __shfl_xor(s, off); c += __shfl_xor(c, off); }
@@ -133,9 +183,9 @@ __global__ __launch_bounds__(512) void quant_query_panels_kernel(const float* __
                                                                  float4* __restrict__ pstat,
                                                                  const int32_t* __restrict__ perm,
                                                                  const float* __restrict__ thr_src,
-                                                                 float* __restrict__ thr_out) {
+                                                                 float* __restrict__ thr_out, ExcludedDims ex) {
     __shared__ float red[8];
-    __shared__ unsigned int emax_sh, nmax_sh;
+    __shared__ unsigned int emax_sh, nmax_sh, kmax_sh;
     __shared__ int bad_sh;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int row = tid >> 2, part = tid & 3;
@@ -144,16 +194,17 @@ __global__ __launch_bounds__(512) void quant_query_panels_kernel(const float* __
     const float4* src = reinterpret_cast<const float4*>(qpacked + (srow < 0 ? 0 : srow) * dpad);
     const int ngroup = srow < 0 ? 0 : dpad / 8, ngroup8 = dpad8 / 8;
     if (thr_out && part == 0) thr_out[grow] = grow < nq ? thr_src[srow] : INFINITY;
-    if (tid == 0) { emax_sh = 0u; nmax_sh = 0u; bad_sh = 0; }
+    if (tid == 0) { emax_sh = 0u; nmax_sh = 0u; kmax_sh = 0u; bad_sh = 0; }
     float amax = 0.0f;
     bool bad = false;
     for (int g = part; g < ngroup; g += 4) {
-        const float4 a = src[2 * g], b = src[2 * g + 1];
-        const float m = fmaxf(fmaxf(fmaxf(fabsf(a.x), fabsf(a.y)), fmaxf(fabsf(a.z), fabsf(a.w))),
-                              fmaxf(fmaxf(fabsf(b.x), fabsf(b.y)), fmaxf(fabsf(b.z), fabsf(b.w))));
-        bad |= !(m <= 3.0e38f) || !(a.x == a.x) || !(a.y == a.y) || !(a.z == a.z) || !(a.w == a.w) || !(b.x == b.x) ||
-               !(b.y == b.y) || !(b.z == b.z) || !(b.w == b.w);
-        amax = fmaxf(amax, m);
+        const float4 a = src[2 * g], b = src[2 * g + 1];  // a = k0 k2 k4 k6, b = k1 k3 k5 k7
+        const float x[8] = {a.x, b.x, a.y, b.y, a.z, b.z, a.w, b.w};
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            bad |= !(fabsf(x[e]) <= 3.0e38f);
+            if (!ex.holds(g * 8 + e)) amax = fmaxf(amax, fabsf(x[e]));
+        }
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) amax = fmaxf(amax, __shfl_xor(amax, off));
@@ -166,17 +217,19 @@ __global__ __launch_bounds__(512) void quant_query_panels_kernel(const float* __
     float s = amax / 127.0f;
     if (panel_bad || !(s > 0.0f) || !(s < 3.0e38f)) s = 1.0f;
     const float inv_s = 1.0f / s;
-    float ss_e = 0.0f, ss_n = 0.0f;
+    float ss_e = 0.0f, ss_n = 0.0f, ss_k = 0.0f;
     int8_t* dst = q8 + grow * dpad8;
     for (int g = part; g < ngroup8; g += 4) {
         int lo = 0, hi = 0;
         if (g < ngroup && !panel_bad) {
-            const float4 a = src[2 * g], b = src[2 * g + 1];  // a = k0 k2 k4 k6, b = k1 k3 k5 k7
-            const float x[8] = {a.x, b.x, a.y, b.y, a.z, b.z, a.w, b.w};
+            const float4 a = src[2 * g], b = src[2 * g + 1];
+            float x[8] = {a.x, b.x, a.y, b.y, a.z, b.z, a.w, b.w};
             int q[8];
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 ss_n = __fmaf_rn(x[e], x[e], ss_n);
+                if (ex.holds(g * 8 + e)) x[e] = 0.0f;  // excluded coordinate: in the row's threshold, not in the image
+                ss_k = __fmaf_rn(x[e], x[e], ss_k);
                 q[e] = quant1(x[e], inv_s, s, ss_e);
             }
             lo = (q[0] & 255) | ((q[1] & 255) << 8) | ((q[2] & 255) << 16) | ((q[3] & 255) << 24);
@@ -187,9 +240,11 @@ __global__ __launch_bounds__(512) void quant_query_panels_kernel(const float* __
     // the four threads of a row are neighbours in the wave
     ss_e += __shfl_xor(ss_e, 1); ss_e += __shfl_xor(ss_e, 2);
     ss_n += __shfl_xor(ss_n, 1); ss_n += __shfl_xor(ss_n, 2);
+    ss_k += __shfl_xor(ss_k, 1); ss_k += __shfl_xor(ss_k, 2);
     if (part == 0 && grow < nq) {  // rows past the batch do not count (they are never reported)
         atomicMax(&emax_sh, __float_as_uint(norm_up(ss_e, dpad)));  // non-negative floats order like their bits
         atomicMax(&nmax_sh, __float_as_uint(norm_up(ss_n, dpad)));
+        atomicMax(&kmax_sh, __float_as_uint(norm_up(ss_k, dpad)));
     }
     __syncthreads();
     if (tid == 0) {
@@ -197,16 +252,52 @@ __global__ __launch_bounds__(512) void quant_query_panels_kernel(const float* __
         m.x = inv_s;
         m.y = panel_bad ? INFINITY : __uint_as_float(emax_sh);
         m.z = panel_bad ? INFINITY : __uint_as_float(nmax_sh);
-        m.w = s;
+        m.w = panel_bad ? INFINITY : __uint_as_float(kmax_sh);
         pstat[blockIdx.x] = m;
     }
 }
 
 int launch_quant_query_panels(const float* qpacked, int dpad, int nq, int npanel, void* q8, int dpad8, float4* pstat,
-                              const int32_t* perm, const float* thr_src, float* thr_out, hipStream_t stream) {
+                              const int32_t* perm, const float* thr_src, float* thr_out, const ExcludedDims& ex,
+                              hipStream_t stream) {
     if (npanel <= 0) return VSC_OK;
     hipLaunchKernelGGL(quant_query_panels_kernel, dim3((unsigned)npanel), dim3(512), 0, stream, qpacked, dpad, nq,
-                       reinterpret_cast<int8_t*>(q8), dpad8, pstat, perm, thr_src, thr_out);
+                       reinterpret_cast<int8_t*>(q8), dpad8, pstat, perm, thr_src, thr_out, ex);
+    VSC_HIP(hipGetLastError());
+    return VSC_OK;
+}
+
+// Row thresholds of one launch when coordinates are excluded: a pair (q, r) with exact score > t (t = the row's own
+// threshold `base_thr[row]`, or the search radius *radius) has
+//     (score restricted to the kept coordinates)  >  t - b_q,      b_q = sum_c q_c v_c.
+// b is evaluated in fp32 (an fma chain over <= 8 terms): its own rounding, <= n 2^-23 sum |q_c v_c|, is subtracted too.
+__global__ __launch_bounds__(256) void row_bias_thresholds_kernel(const float* __restrict__ qpacked, int dpad, int nq,
+                                                                  const float* __restrict__ base_thr,
+                                                                  const float* __restrict__ radius, ExcludedDims ex,
+                                                                  float* __restrict__ thr) {
+    const int r = blockIdx.x * 256 + threadIdx.x;
+    if (r >= nq) return;
+    const float* q = qpacked + (int64_t)r * dpad;
+    float b = 0.0f, mag = 0.0f;
+#pragma unroll
+    for (int c = 0; c < I8_MAX_EXCLUDED; ++c)
+        if (c < ex.n) {
+            const float x = q[k_slot(ex.idx[c])];
+            b = __fmaf_rn(x, ex.val[c], b);
+            mag = __fmaf_rn(fabsf(x), fabsf(ex.val[c]), mag);
+        }
+    const float t = base_thr ? base_thr[r] : *radius;
+    const float lowered = t - b;
+    // (the subtraction's own rounding: 2^-24 relative to the larger operand; a NaN / inf bias leaves a NaN / -inf
+    // threshold, and the kernel passes every pair of such a row)
+    thr[r] = lowered - 1.2e-7f * ((float)ex.n * mag + fabsf(t) + fabsf(b));
+}
+
+int launch_row_bias_thresholds(const float* qpacked, int dpad, int nq, const float* base_thr, const float* radius,
+                               const ExcludedDims& ex, float* thr, hipStream_t stream) {
+    if (nq <= 0) return VSC_OK;
+    hipLaunchKernelGGL(row_bias_thresholds_kernel, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, stream, qpacked, dpad,
+                       nq, base_thr, radius, ex, thr);
     VSC_HIP(hipGetLastError());
     return VSC_OK;
 }

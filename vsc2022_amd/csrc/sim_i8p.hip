@@ -11,7 +11,8 @@
 // Why this is still exact: the integer accumulators are EXACT dot products of the quantised rows, so the only
 // error is quantisation, and quant_i8.hip records per row what was actually lost:
 //     x = s (q + e),  E >= ||x - s q||,  N >= ||x||   =>   | x.y - s_x s_y (q_x . q_y) | <= E_x N_y + (N_x + E_x) E_y
-// plus c_acc N_x N_y for the rounding of the exact fp32 chain itself.  A pair whose exact score exceeds the radius
+// plus c_acc N_x N_y for the rounding of the exact fp32 chain itself.  (Coordinates on which all references agree are
+// kept out of the images and enter through per-row thresholds instead: quant_i8.hip, "EXCLUDED coordinates".)  A pair whose exact score exceeds the radius
 // therefore has   q_x . q_y  >  (radius - eps_xy) / (s_x s_y);   the kernel tests the integer accumulator against
 // the floor of a lower bound of that quotient, per reference column (one scale per reference ROW, one scale and the
 // largest E / N per query PANEL).  With 8 bits the bound is ~16x looser than the fp16 one (eps ~ 0.018 for unit
@@ -78,12 +79,16 @@ __device__ __forceinline__ void tile_mma(const char* smem, const int (&abase)[8]
     }
 }
 
-// lower edge of the candidate test for an exact threshold t (as in sim_f16p.hip)
-__device__ __forceinline__ float candidate_edge(float t, float eps) { return (t - eps) - 2.4e-7f * (fabsf(t) + eps); }
+// lower edge of the candidate test for an exact threshold t (as in sim_f16p.hip); t = +inf (the rows of a panel that
+// lie past the batch) stays +inf instead of turning into inf - inf
+__device__ __forceinline__ float candidate_edge(float t, float eps) {
+    return t == INFINITY ? t : (t - eps) - 2.4e-7f * (fabsf(t) + eps);
+}
 // A lower bound of edge / (s_q s_r) from inv = (1 / s_q) (1 / s_r): the few roundings of the quotient are covered by
 // 2e-6 relative; the absolute term keeps a quotient that underflowed to +-0 on the safe side of the integers.
 __device__ __forceinline__ float quotient_low(float edge, float inv) {
     const float t = edge * inv;
+    if (!(fabsf(t) < INFINITY)) return t;  // +-inf thresholds (rows past the batch: +inf) stay what they are; NaN too
     return t - fabsf(t) * 2e-6f - 1e-3f;
 }
 // integer accumulator > t  <=>  accumulator > floor(t); out-of-range thresholds saturate to never / always
@@ -95,39 +100,29 @@ __device__ __forceinline__ int lane_now() {
     return l;
 }
 
-// Candidates of one wave tile -> the wave's private segment (no atomics; a shared atomic tail only when the
-// segment is full).  General form: edge tiles, full segments, pass-everything columns, k-NN row thresholds.
-//   ROWTHR = false: ti[n] = integer threshold of the lane's column of block column n (strict test)
-//   ROWTHR = true : rt = the panel's 128 row thresholds, rtmin[m] = smallest of row block m, eps[n] / inv[n] the lane's
-//                   column bound and inverse scale product (non-strict test in the float domain: the accumulators
-//                   are < 2^24 in magnitude, their conversion is exact)
-template <bool ROWTHR>
-__device__ __forceinline__ void emit_candidates(const SimI8PArgs& a, const bool (&all)[2], const int (&ti)[2],
-                                                const float (&eps)[2], const float (&inv)[2], const float* rt,
-                                                const float (&rtmin)[4], int row0, int col0, bool interior,
-                                                const i32x16 (&acc)[4][2], const int (&bm)[4][2], int64_t seg_base,
-                                                int& count, TailExt* ext) {
+// Candidates of one wave tile -> the wave's private segment (no atomics; the wave's chunk of the shared tail when the
+// segment is full).  ti[m][n] = integer threshold of 32-row block m x the lane's column of block column n: an
+// accumulator above it is a candidate.  Radius search: the same threshold for all four row blocks.  Per-row
+// thresholds (k-NN, excluded coordinates): the threshold of the block's SMALLEST row threshold -- the rows of a
+// launch arrive sorted by threshold (sortpairs.hip), so a block's 32 thresholds are next to equal and testing all
+// of its rows against the smallest one passes a few candidates more instead of costing a float comparison per
+// accumulator.  General form: edge tiles, full segments, pass-everything columns.
+__device__ __forceinline__ void emit_candidates(const SimI8PArgs& a, const bool (&all)[2], const int (&ti)[4][2], int row0,
+                                                int col0, bool interior, const i32x16 (&acc)[4][2],
+                                                const int (&bm)[4][2], int64_t seg_base, int& count, TailExt* ext) {
     // C layout of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
 #pragma unroll
     for (int m = 0; m < 4; ++m)
 #pragma unroll
         for (int n = 0; n < 2; ++n) {
-            const bool blk = all[n] || (ROWTHR ? (float)bm[m][n] >= quotient_low(candidate_edge(rtmin[m], eps[n]), inv[n])
-                                               : bm[m][n] > ti[n]);
-            if (!__any(blk)) continue;
-            const int ln_blk = ROWTHR ? lane_now() : 0;
+            if (!__any(all[n] || bm[m][n] > ti[m][n])) continue;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int rb = m * 32 + (r & 3) + 8 * (r >> 2);  // + 4 * (lane >> 5) = row inside the panel
-                bool cand;
-                if (ROWTHR)
-                    cand = (float)acc[m][n][r] >= quotient_low(candidate_edge(rt[rb + 4 * (ln_blk >> 5)], eps[n]), inv[n]);
-                else
-                    cand = acc[m][n][r] > ti[n];
-                const bool hit = all[n] || cand;
+                const bool hit = all[n] || acc[m][n][r] > ti[m][n];
                 const unsigned long long hits = __ballot(hit);
                 if (hits == 0ull) continue;
-                const int ln = ROWTHR ? ln_blk : lane_now();
+                const int ln = lane_now();
                 const int i = row0 + rb + 4 * (ln >> 5);
                 const int j = col0 + n * 32 + (ln & 31);
                 const bool mine = hit && (interior || (i < a.nq && j < a.nr));
@@ -152,29 +147,32 @@ __device__ __forceinline__ void emit_candidates(const SimI8PArgs& a, const bool 
         }
 }
 
-// The radius search's fast path: interior tile, room for a whole tile (8192 entries) left in the wave's segment:
-// position = count + (lanes of this register's ballot below me), two buffer stores with a 32-bit offset.
-__device__ __forceinline__ void emit_candidates_seg(const SimI8PArgs& a, const int (&ti)[2], int row0, int col0,
+// The fast path: interior tile, room for a whole tile (8192 entries) left in the wave's segment: position = count +
+// (lanes of this register's ballot below me), two buffer stores with a 32-bit offset.  PERM: the launch's rows are
+// permuted (a.perm: position -> row), one extra load per candidate.
+template <bool PERM>
+__device__ __forceinline__ void emit_candidates_seg(const SimI8PArgs& a, const int (&ti)[4][2], int row0, int col0,
                                                     const i32x16 (&acc)[4][2], const int (&bm)[4][2],
                                                     __amdgpu_buffer_rsrc_t rs_i, __amdgpu_buffer_rsrc_t rs_j, int& count) {
 #pragma unroll
     for (int m = 0; m < 4; ++m)
 #pragma unroll
         for (int n = 0; n < 2; ++n) {
-            if (!__any(bm[m][n] > ti[n])) continue;
+            if (!__any(bm[m][n] > ti[m][n])) continue;
             const int ln = lane_now();  // (live inside the block only: the register file is full)
-            const int ibase = a.i0 + row0 + m * 32 + 4 * (ln >> 5);
+            const int pbase = row0 + m * 32 + 4 * (ln >> 5);
             const int j = col0 + n * 32 + (ln & 31);
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const bool cand = acc[m][n][r] > ti[n];
+                const bool cand = acc[m][n][r] > ti[m][n];
                 const unsigned long long hits = __ballot(cand);
                 if (hits == 0ull) continue;
                 if (cand) {
                     const int off = (count + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(hits >> 32),
                                                                             __builtin_amdgcn_mbcnt_lo((unsigned)hits, 0u)))
                                     << 2;
-                    __builtin_amdgcn_raw_buffer_store_b32(ibase + (r & 3) + 8 * (r >> 2), rs_i, off, 0, 0);
+                    const int p = pbase + (r & 3) + 8 * (r >> 2);
+                    __builtin_amdgcn_raw_buffer_store_b32(a.i0 + (PERM ? a.perm[p] : p), rs_i, off, 0, 0);
                     __builtin_amdgcn_raw_buffer_store_b32(j, rs_j, off, 0, 0);
                 }
                 count += __popcll(hits);
@@ -214,8 +212,8 @@ __global__ __launch_bounds__(512) void sim_i8p_kernel(SimI8PArgs a) {
         (void*)uniform_ptr(reinterpret_cast<const char*>(a.out_j + seg_base)), 0, a.seg_cap * 4, 0x00020000);
     const int nslice = (a.nsteps + a.slice - 1) / a.slice;
     int cur_panel = -1;
-    // per panel (wave-uniform): 1 / s_q, the coefficient of N_r and the coefficient of E_r in eps
-    float inv_sq = 1.0f, coef_n = 0.0f, coef_e = 0.0f;
+    // per panel (wave-uniform): 1 / s_q and the coefficients of N'_r, E_r and N_r in eps
+    float inv_sq = 1.0f, coef_k = 0.0f, coef_e = 0.0f, coef_n = 0.0f;
     float rtmin[4] = {0.f, 0.f, 0.f, 0.f};
     int panel = blockIdx.x % a.npanel;
     for (;;) {
@@ -272,11 +270,12 @@ __global__ __launch_bounds__(512) void sim_i8p_kernel(SimI8PArgs a) {
                 const int c = kc * 16 + (slot ^ (row & 15));
                 dma16(qrs, row * ROWB + c * 16, smem + (n * 512 + wave * 64) * 16);
             }
-            const float4 ps = a.pstat[panel];  // {1 / s_q, max E_q, max N_q, s_q}
+            const float4 ps = a.pstat[panel];  // {1 / s_q, max E_q, max N_q, max N'_q}
             inv_sq = uniform_f(ps.x);
-            // eps_j = E_q N_r + (N_q + E_q) E_r + c_acc N_q N_r
-            coef_n = uniform_f(ps.y + a.c_acc * ps.z);
-            coef_e = uniform_f(ps.z + ps.y);
+            // eps_j = E_q N'_r + (N'_q + E_q) E_r + c_acc N_q N_r   (N' = norm over the coordinates the images hold)
+            coef_k = uniform_f(ps.y);
+            coef_e = uniform_f(ps.w + ps.y);
+            coef_n = uniform_f(a.c_acc * ps.z);
             if (ROWTHR && tid < PR) rt_sh[tid] = panel * PR + tid < a.nq ? a.row_thr[(int64_t)panel * PR + tid] : INFINITY;
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's DMA pieces have landed ...
             __syncthreads();                                  // ... and so have everybody else's
@@ -310,20 +309,36 @@ __global__ __launch_bounds__(512) void sim_i8p_kernel(SimI8PArgs a) {
         for (int m = 0; m < 4; ++m) afr[m] = *reinterpret_cast<const i32x4*>(smem + abase[0] + m * 8192);
         for (int cs = cs0; cs < cs1; ++cs) {
             const int col0 = cs * CSW + wave * 64;
-            // {1 / s_r, E_r, N_r, s_r} of the lane's two columns (the table is padded to whole col-steps)
+            // {1 / s_r, E_r, N_r, N'_r} of the lane's two columns (the table is padded to whole col-steps)
             const float4 m0 = a.rmeta[col0 + (lane & 31)], m1 = a.rmeta[col0 + 32 + (lane & 31)];
             i32x16 acc[4][2];
             tile_mma<NKC>(smem, abase, afr, ring, rs, so_tile, so_tile + 8 * TILEB, lane16, acc);
             so_tile += 8 * TILEB;
-            const float eps[2] = {(coef_n * m0.z + coef_e * m0.y) * 1.001f, (coef_n * m1.z + coef_e * m1.y) * 1.001f};
+            const float eps[2] = {(coef_k * m0.w + coef_e * m0.y + coef_n * m0.z) * 1.001f,
+                                  (coef_k * m1.w + coef_e * m1.y + coef_n * m1.z) * 1.001f};
             const float inv[2] = {inv_sq * m0.x, inv_sq * m1.x};
-            const float tl[2] = {quotient_low(candidate_edge(radius, eps[0]), inv[0]),
-                                 quotient_low(candidate_edge(radius, eps[1]), inv[1])};
+            // integer thresholds per (row block, column).  Radius search: strict, floor of a lower bound of the
+            // quotient.  Row thresholds: the block's smallest one, non-strict (accumulator >= T  <=  accumulator >
+            // floor(T) - 1), so that pairs tied with a row's threshold survive.
+            float tl[4][2];
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                const float t = ROWTHR ? rtmin[m] : radius;
+                tl[m][0] = (ROWTHR || m == 0) ? quotient_low(candidate_edge(t, eps[0]), inv[0]) : tl[0][0];
+                tl[m][1] = (ROWTHR || m == 0) ? quotient_low(candidate_edge(t, eps[1]), inv[1]) : tl[0][1];
+            }
             // pass everything where the arithmetic above says nothing: +inf / NaN bounds (unrepresentable rows), scale
-            // products outside the range where their inverse is a normal number, NaN quotients (0 x inf)
-            const bool all[2] = {!(eps[0] < INFINITY) || !(inv[0] >= 1e-30f && inv[0] < INFINITY) || !(tl[0] == tl[0]),
-                                 !(eps[1] < INFINITY) || !(inv[1] >= 1e-30f && inv[1] < INFINITY) || !(tl[1] == tl[1])};
-            const int ti[2] = {floor_sat(tl[0]), floor_sat(tl[1])};
+            // products outside the range where their inverse is a normal number, NaN quotients (0 x inf, NaN thresholds)
+            bool all[2] = {!(eps[0] < INFINITY) || !(inv[0] >= 1e-30f && inv[0] < INFINITY),
+                           !(eps[1] < INFINITY) || !(inv[1] >= 1e-30f && inv[1] < INFINITY)};
+            int ti[4][2];
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+#pragma unroll
+                for (int n = 0; n < 2; ++n) {
+                    all[n] |= !(tl[m][n] == tl[m][n]);
+                    ti[m][n] = floor_sat(tl[m][n]) - (ROWTHR ? 1 : 0);
+                }
             // candidates are rare: one max per 32x32 block first, one compare for the whole wave tile
             int bm[4][2];
 #pragma unroll
@@ -336,23 +351,18 @@ __global__ __launch_bounds__(512) void sim_i8p_kernel(SimI8PArgs a) {
                     bm[m][n] = max(x, acc[m][n][15]);
                 }
             bool any_blk = all[0] || all[1];
-            if (ROWTHR) {
 #pragma unroll
-                for (int m = 0; m < 4; ++m)
-                    any_blk |= (float)bm[m][0] >= quotient_low(candidate_edge(rtmin[m], eps[0]), inv[0]) ||
-                               (float)bm[m][1] >= quotient_low(candidate_edge(rtmin[m], eps[1]), inv[1]);
-            } else {
-                const int x0 = max(max(bm[0][0], bm[1][0]), max(bm[2][0], bm[3][0]));
-                const int x1 = max(max(bm[0][1], bm[1][1]), max(bm[2][1], bm[3][1]));
-                any_blk |= x0 > ti[0] || x1 > ti[1];
-            }
+            for (int m = 0; m < 4; ++m) any_blk |= bm[m][0] > ti[m][0] || bm[m][1] > ti[m][1];
             if (__any(any_blk)) {
                 const bool interior = panel * PR + PR <= a.nq && col0 + 64 <= a.nr;
-                if (!ROWTHR && interior && !all[0] && !all[1] && count + 8192 <= a.seg_cap)
-                    emit_candidates_seg(a, ti, panel * PR, col0, acc, bm, rs_ci, rs_cj, count);
-                else
-                    emit_candidates<ROWTHR>(a, all, ti, eps, inv, rt_sh, rtmin, panel * PR, col0, interior, acc, bm,
-                                            seg_base, count, &tail_sh[wave]);
+                if (interior && !all[0] && !all[1] && count + 8192 <= a.seg_cap) {
+                    if (ROWTHR && a.perm)
+                        emit_candidates_seg<true>(a, ti, panel * PR, col0, acc, bm, rs_ci, rs_cj, count);
+                    else
+                        emit_candidates_seg<false>(a, ti, panel * PR, col0, acc, bm, rs_ci, rs_cj, count);
+                } else {
+                    emit_candidates(a, all, ti, panel * PR, col0, interior, acc, bm, seg_base, count, &tail_sh[wave]);
+                }
             }
         }
     }

@@ -84,7 +84,9 @@ int sort_hits_topk(const int32_t* hi, const int32_t* hj, const float* hs, int64_
 // The int8 pre-filter tests a 32-row block against the SMALLEST of its row thresholds before it looks at single
 // accumulators; with an 8-bit error bound that gate only filters when the rows of a block have similar thresholds.
 // Inside one launch the row order is free (candidates carry their row index), so the rows are handed to the kernel
-// sorted by threshold: perm[position] = row.  16 key bits (2 radix passes) are plenty for "similar".
+// sorted by threshold: perm[position] = row.  All 32 key bits: the kernel tests a whole block against its smallest
+// threshold, and at 3.5 sigma a threshold that is 0.04 sigma too low (what 16 key bits leave inside a block) already
+// passes 15 % more candidates (measured: 1.02 -> 1.24 G candidates on the score-normalised config-4 search).
 __global__ __launch_bounds__(256) void thr_keys_kernel(const float* __restrict__ thr, int n, uint32_t* __restrict__ keys,
                                                        int32_t* __restrict__ vals) {
     const int x = blockIdx.x * 256 + threadIdx.x;
@@ -106,7 +108,7 @@ int sort_rows_by_threshold(const float* thr, int64_t n, DevBuf& w0, DevBuf& w1, 
     int32_t *va = w2.as<int32_t>(), *vb = w3.as<int32_t>();
     hipLaunchKernelGGL(thr_keys_kernel, dim3(grid_for(n)), dim3(256), 0, stream, thr, (int)n, ka, va);
     VSC_HIP(hipGetLastError());
-    const int w = radix_sort_pairs<uint32_t, int32_t>(ka, kb, va, vb, n, 16, 32, false, tmp.p, stream);
+    const int w = radix_sort_pairs<uint32_t, int32_t>(ka, kb, va, vb, n, 0, 32, false, tmp.p, stream);
     if (w < 0) { set_error("radix sort launch failed"); return VSC_ERR_HIP; }
     *perm = w ? vb : va;
     return VSC_OK;
