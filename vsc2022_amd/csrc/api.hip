@@ -160,6 +160,7 @@ struct vsc_index {
     hipStream_t stream = nullptr;
     Workspace ws;
     int64_t hit_cap_user = 0;
+    int64_t hit_cap_learned = 0;  // the capacity the last search ended with after overflow reruns (ties keep the radius low)
     // kernel-time accounting (HIP events on the handle's stream), per kernel class:
     // 0 = exact fp32 similarity kernels, 1 = fp16 pre-filter, 2 = exact re-scoring of candidates,
     // 3 = re-threshold (radix select + compaction) kernels, 4 = final ordering of the kept hits
@@ -836,7 +837,7 @@ int vsc_index_global_topk(vsc_index_t* idx, const float* q, int64_t nq, int q_me
     VSC_TRY(i8_prepare(idx));
     const int64_t cap_max = nq * idx->ntotal + 1024;  // the whole score matrix always fits
     int64_t cap = idx->hit_cap_user;
-    if (cap <= 0) cap = std::max<int64_t>(32 * idx->ntotal, 2 * K) + 2 * K + 1024;
+    if (cap <= 0) cap = std::max(std::max<int64_t>(32 * idx->ntotal, 2 * K) + 2 * K + 1024, idx->hit_cap_learned);
     cap = std::min<int64_t>(cap, cap_max);
     SelectCtl h;
     bool allow_i8 = i8_usable(idx);
@@ -877,7 +878,7 @@ int vsc_index_global_topk(vsc_index_t* idx, const float* q, int64_t nq, int q_me
         VSC_TRY(prof_collect(idx));
         idx->stat_candidates = h.n_cand_total;
         if (!h.overflow) break;
-        if (used_i8 && idx->i8_mode != 2) {
+        if (used_i8 && (h.overflow & 2) && idx->i8_mode != 2) {
             // the candidate list overflowed with int8 batches in the schedule: their bound may simply be too loose for
             // these rows -- same buffers, fp16 pre-filter throughout
             allow_i8 = false;
@@ -895,6 +896,7 @@ int vsc_index_global_topk(vsc_index_t* idx, const float* q, int64_t nq, int q_me
             return VSC_ERR_OVERFLOW;
         }
         cap = std::min<int64_t>(cap * 4, cap_max);
+        idx->hit_cap_learned = cap;  // the next search of this handle starts here instead of overflowing again
     }
     if (final_radius) *final_radius = ip ? h.radius : -h.radius;
     const int64_t n = (int64_t)h.n;

@@ -26,7 +26,8 @@ __device__ __forceinline__ void tail_init(TailExt* e, int ln) {
 }
 
 // Room for `total` (<= 64) more candidates of this wave behind its full segment: true and `pos` = first entry, or
-// false (tail exhausted: *overflow is set, the host reruns with larger buffers).  Wave-uniform arguments; ln = lane;
+// false (tail exhausted: bit 1 of *overflow is set -- bit 0 belongs to the kept-hit list -- and the host reruns the
+// search on the fp16 kernel or with larger buffers).  Wave-uniform arguments; ln = lane;
 // `e` = the wave's slot in LDS (one wave reads and writes it, in program order); chunk = 1 << chunk_shift.
 __device__ __forceinline__ bool tail_take(unsigned long long* tail_count, long long tail_cap, long long tail_base,
                                           int chunk_shift, int* tail_fill, int* overflow, int total, int ln, TailExt* e,
@@ -36,7 +37,7 @@ __device__ __forceinline__ bool tail_take(unsigned long long* tail_count, long l
     long long p = e->pos;
     if (left < 0) return false;
     if (total > chunk) {  // (only the block-at-a-time emitter asks for more than 64 at once: rerun with larger buffers)
-        if (ln == 0) { atomicOr(overflow, 1); e->left = -1; }
+        if (ln == 0) { atomicOr(overflow, 2); e->left = -1; }
         return false;
     }
     if (total > left) {
@@ -46,7 +47,7 @@ __device__ __forceinline__ bool tail_take(unsigned long long* tail_count, long l
         if (ln == 0) base = atomicAdd(tail_count, (unsigned long long)chunk);
         base = __shfl(base, 0);
         if ((long long)(base + chunk) > tail_cap) {
-            if (ln == 0) { atomicOr(overflow, 1); e->left = -1; e->have = 0; }
+            if (ln == 0) { atomicOr(overflow, 2); e->left = -1; e->have = 0; }
             return false;
         }
         p = tail_base + (long long)base;
