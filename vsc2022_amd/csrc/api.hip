@@ -1133,6 +1133,7 @@ static int knn_prefiltered(vsc_index* idx, const float* qp, int64_t nq, int k, f
     bool knn_i8 = idx->i8_mode == 2 || (i8_usable(idx) && knn_i8_env);
     static const double subset_factor = getenv("VSC_KNN_SUBSET") ? atof(getenv("VSC_KNN_SUBSET")) : 300.0;
     static const bool two_level = !(getenv("VSC_KNN_LEVELS") && getenv("VSC_KNN_LEVELS")[0] == '1');
+    static const int s0_div = getenv("VSC_KNN_S0DIV") && atoi(getenv("VSC_KNN_S0DIV")) > 0 ? atoi(getenv("VSC_KNN_S0DIV")) : 7;
     // one level: S0 = sqrt(300 k nr) balances the exact pass (~2 dim S0 / 1e14 s per row) against the per-hit cost of
     // the final pass (k nr / S0 hits per row, ~1 ns each).  Two levels: S0 = 16 k (k^2 nr^2 / 3e5)^(1/3) ... in
     // practice S0 ~ S_one / 7 and S1 = 16 S0 sit on a flat optimum (measured at 200 k x 2 M, k = 1 and 20)
@@ -1140,7 +1141,7 @@ static int knn_prefiltered(vsc_index* idx, const float* qp, int64_t nq, int k, f
         nr, round_up64(std::max<int64_t>((int64_t)std::sqrt(subset_factor * k * (double)nr), 4096), ROW_PAD));
     // (VSC_PREFILTER=2, the tests' switch, also forces the refinement on small problems)
     const int64_t S0_small = std::min<int64_t>(
-        nr, round_up64(std::max<int64_t>(S_one / 7, idx->prefilter_force ? (int64_t)k : 4096), ROW_PAD));
+        nr, round_up64(std::max<int64_t>(S_one / s0_div, idx->prefilter_force ? (int64_t)k : 4096), ROW_PAD));
     const bool refine = two_level && (idx->prefilter_force ? nr >= 2 * S0_small
                                                            : (nr >= 8 * S_one && (double)nq * (double)nr >= 4e10));
     const int64_t S0 = refine ? S0_small : S_one;
@@ -1151,24 +1152,31 @@ static int knn_prefiltered(vsc_index* idx, const float* qp, int64_t nq, int k, f
     VSC_TRY(launch_knn_row_thr(ds, nq, k, idx->ws.rowthr.as<float>(), rows_h, idx->stream));
     int64_t S_last = S0;
     if (refine) {
-        const int64_t S1 = std::min<int64_t>(nr, round_up64((idx->prefilter_force ? 3 : 16) * S0, F16P_COL_STEP));
-        // expected hits per row: k * S1 / S0 (plus the filter's inflation); generous factor
-        int rc = knn_threshold_pass(idx, qp, nq, S1, k, (double)k * ((double)S1 / (double)S0) * 4.0, ds, dj, knn_i8);
-        if (rc == VSC_ERR_OVERFLOW && knn_i8 && idx->i8_mode != 2) {
-            // (ds / dj still hold the first level's lists: the overflow is detected before they are rewritten)
-            knn_i8 = false;
-            idx->stat_i8_fallbacks += 1;
-            rc = knn_threshold_pass(idx, qp, nq, S1, k, (double)k * ((double)S1 / (double)S0) * 4.0, ds, dj, false);
-        }
-        if (rc == VSC_OK) {
+        // refinement levels: the prefix grows by `ratio` per level until less than a factor 2 is left for the final
+        // pass.  Every level costs one pre-filter pass over its prefix + k * ratio hits per row (x the filter's
+        // inflation in candidates); the int8 bound passes 4-5 candidates per hit, so its optimum is several levels
+        // of ratio ~5 where the fp16 filter (1.1 per hit) wanted one level of 16.
+        static const double ratio_env = getenv("VSC_KNN_RATIO") ? atof(getenv("VSC_KNN_RATIO")) : 0.0;
+        // measured at 200 k x 2 M (profiles/r03_knn_levels.md): k = 1: 244 / 249 / 271 ms at ratio 16 / 8 / 5;
+        // k = 20: 500 / 514 / 448 / 448 ms at 16 / 8 / 5 / 4
+        const double ratio = idx->prefilter_force ? 3.0
+                             : (ratio_env > 1.0 ? ratio_env : (knn_i8 ? std::min(16.0, std::max(4.0, 80.0 / (double)k)) : 16.0));
+        for (int level = 0; level < 8; ++level) {
+            const int64_t S1 = std::min<int64_t>(nr, round_up64((int64_t)(ratio * (double)S_last), F16P_COL_STEP));
+            if (S1 <= S_last || 2 * S1 > nr) break;
+            // expected hits per row: k * S1 / S_last (plus the filter's inflation); generous factor
+            const double per_row = (double)k * ((double)S1 / (double)S_last) * 4.0;
+            int rc = knn_threshold_pass(idx, qp, nq, S1, k, per_row, ds, dj, knn_i8);
+            if (rc == VSC_ERR_OVERFLOW && knn_i8 && idx->i8_mode != 2) {
+                // (ds / dj still hold the previous level's lists: the overflow is detected before they are rewritten)
+                knn_i8 = false;
+                idx->stat_i8_fallbacks += 1;
+                rc = knn_threshold_pass(idx, qp, nq, S1, k, per_row, ds, dj, false);
+            }
+            if (rc == VSC_ERR_OVERFLOW) break;  // keep the previous thresholds (ws.rowthr was not touched)
+            if (rc != VSC_OK) return rc;
             VSC_TRY(launch_knn_row_thr(ds, nq, k, idx->ws.rowthr.as<float>(), rows_h, idx->stream));
             S_last = S1;
-        } else if (rc != VSC_ERR_OVERFLOW) {
-            return rc;
-        } else {
-            // keep T_i(0): the thresholds in ws.rowthr are still the first level's (ds / dj were not touched
-            // before the overflow was detected)
-            VSC_TRY(launch_knn_row_thr(ds, nq, k, idx->ws.rowthr.as<float>(), rows_h, idx->stream));
         }
     }
     int rc = knn_threshold_pass(idx, qp, nq, nr, k, (double)k * ((double)nr / (double)S_last) * 4.0, ds, dj, knn_i8);

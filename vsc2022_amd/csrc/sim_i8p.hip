@@ -31,7 +31,9 @@ constexpr int CSW = F16P_COL_STEP;   // 512
 #ifndef VSC_I8P_PF
 #define VSC_I8P_PF 4
 #endif
-constexpr int PF = VSC_I8P_PF;       // register ring: k-steps (PF - 1 in flight, 2 KiB each per wave)
+constexpr int PF = VSC_I8P_PF;       // register ring: k-steps (PF - 1 in flight, 2 KiB each per wave).  Measured on the
+                                     // bench: 8 loses 3 % (2391 vs 2474 TOP/s); delaying the second wave of every
+                                     // SIMD by 1000-4000 cycles after an item's barrier changes nothing (2431-2435)
 
 __device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rsrc, int voff, char* lds) {
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)lds, 16, voff, 0, 0, 0);
