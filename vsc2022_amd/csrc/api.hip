@@ -597,6 +597,7 @@ static int enqueue_f16(vsc_index* idx, const float* qpacked, int64_t i0, int64_t
         int32_t* const cand_i = idx->ws.ci.as<int32_t>();
         int32_t* const cand_j = idx->ws.cj.as<int32_t>();
         int grid = 0, seg_cap = 0, tail_shift = 6;
+        const int32_t* cand_perm = nullptr;  // set when the candidate list holds positions of a permuted int8 launch
         int64_t tail_base = 0;
         long long tail_cap = 0;
         hipEvent_t stop;
@@ -633,6 +634,15 @@ static int enqueue_f16(vsc_index* idx, const float* qpacked, int64_t i0, int64_t
                 VSC_TRY(sort_rows_by_threshold(thr_src, nqb, idx->ws.w0, idx->ws.w1, idx->ws.w2, idx->ws.w3, idx->ws.tmp,
                                                &perm, idx->stream));
             }
+            else if (sort_rows && nqb >= 2 * F16P_PANEL_ROWS) {
+                // one threshold for all rows (the search radius): sort by the rows' largest element instead, so that
+                // a panel's shared scale is close to what each of its rows would have chosen (VSC_I8_SORT=0: off)
+                VSC_TRY(idx->ws.rt8b.reserve((size_t)nqb * sizeof(float)));
+                VSC_TRY(launch_row_absmax(qpacked + i0 * idx->dpad, idx->dpad, nqb, idx->i8_ex, idx->ws.rt8b.as<float>(),
+                                          idx->stream));
+                VSC_TRY(sort_rows_by_threshold(idx->ws.rt8b.as<float>(), nqb, idx->ws.w0, idx->ws.w1, idx->ws.w2, idx->ws.w3,
+                                               idx->ws.tmp, &perm, idx->stream));
+            }
             VSC_TRY(launch_quant_query_panels(qpacked + i0 * idx->dpad, idx->dpad, nqb, f.npanel, idx->ws.q8.p, idx->dpad8,
                                               idx->ws.pstat.as<float4>(), perm, thr_src, rt_pos, idx->i8_ex, idx->stream));
             f.Q = idx->ws.q8.p;
@@ -648,7 +658,7 @@ static int enqueue_f16(vsc_index* idx, const float* qpacked, int64_t i0, int64_t
             f.c_acc = (float)(((double)idx->dpad + 2.0) * ldexp(1.0, -23));
             f.radius = &ctl->radius;
             f.row_thr = rt_pos;
-            f.perm = perm;
+            cand_perm = perm;
             f.out_i = cand_i;
             f.out_j = cand_j;
             seg_cap = (int)std::min<int64_t>(ccap / (grid * 8), 0x7fffffff);
@@ -748,6 +758,8 @@ static int enqueue_f16(vsc_index* idx, const float* qpacked, int64_t i0, int64_t
         r.tail_count = &ctl->n_tail;
         r.tail_shift = tail_shift;
         r.tail_fill = idx->ws.tailfill.as<int>();
+        r.perm = cand_perm;
+        r.perm_i0 = (int)i0;
         r.n_cand_total = &ctl->n_cand_total;
         r.radius = &ctl->radius;
         r.out_i = idx->ws.hA[0].as<int32_t>();

@@ -69,7 +69,6 @@ struct SimI8PArgs {
     int* next_slice;
     float c_acc;                           // rounding of the exact fp32 chain per |q||r|
     const float* radius; const float* row_thr;  // as in SimF16Args (row_thr indexed by POSITION inside the launch)
-    const int32_t* perm;                   // position inside the launch -> row of the launch (nullptr: identity)
     int32_t* out_i; int32_t* out_j;
     int seg_cap; int* seg_count; int64_t tail_base; long long tail_cap; int tail_shift; int* tail_fill; unsigned long long* tail_count;
     int* overflow;
@@ -79,6 +78,9 @@ struct RescoreArgs {
     const int32_t* cand_i; const int32_t* cand_j; int n_seg; int seg_cap; const int* seg_count;
     int64_t tail_base; long long tail_cap; unsigned long long* tail_count;  // reset to 0 after the pass
     int tail_shift; const int* tail_fill;  // the tail is handed out in chunks of 1 << tail_shift entries, each with a fill level
+    // the int8 kernel hands over POSITIONS inside its launch when the launch's rows were permuted (sorted by threshold
+    // or by scale): row = perm_i0 + perm[position - perm_i0].  nullptr: the list holds rows
+    const int32_t* perm; int perm_i0;
     unsigned long long* n_cand_total;      // statistics
     const float* radius; int32_t* out_i; int32_t* out_j; float* out_s;
     unsigned long long* counter; long long cap; int* overflow;
@@ -128,6 +130,7 @@ int launch_dim_minmax(const float*, int64_t, int, unsigned*, unsigned*, hipStrea
 int launch_meta_looseness(const float4*, int64_t, double*, hipStream_t);
 int launch_quant_query_panels(const float*, int, int, int, void*, int, float4*, const int32_t*, const float*, float*,
                               const ExcludedDims&, hipStream_t);
+int launch_row_absmax(const float*, int, int, const ExcludedDims&, float*, hipStream_t);
 int launch_row_bias_thresholds(const float*, int, int, const float*, const float*, const ExcludedDims&, float*, hipStream_t);
 int sort_rows_by_threshold(const float*, int64_t, DevBuf&, DevBuf&, DevBuf&, DevBuf&, DevBuf&, const int32_t**, hipStream_t);
 int launch_pack_half_frag(const float*, int64_t, int, _Float16*, float*, int64_t, int64_t, int, hipStream_t);

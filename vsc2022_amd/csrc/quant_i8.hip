@@ -267,6 +267,35 @@ int launch_quant_query_panels(const float* qpacked, int dpad, int nq, int npanel
     return VSC_OK;
 }
 
+// Largest |x| of every row of a launch over the coordinates the image keeps (one wave per row): the radius search
+// sorts its rows by this value so that the rows of a 128-row panel -- which share one scale -- are rows that would
+// have picked nearly the same scale on their own (E_q of the panel ~ E of its rows: ~20 % fewer candidates).
+__global__ __launch_bounds__(256) void row_absmax_kernel(const float* __restrict__ qpacked, int dpad, int nq,
+                                                         ExcludedDims ex, float* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= nq) return;
+    const float* q = qpacked + (int64_t)r * dpad;
+    float m = 0.0f;
+    for (int g = lane; g < dpad / 8; g += 64) {
+        const float4 a = reinterpret_cast<const float4*>(q)[2 * g], b = reinterpret_cast<const float4*>(q)[2 * g + 1];
+        const float x[8] = {a.x, b.x, a.y, b.y, a.z, b.z, a.w, b.w};
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+            if (!ex.holds(g * 8 + e)) m = fmaxf(m, fabsf(x[e]));
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
+    if (lane == 0) out[r] = m;
+}
+
+int launch_row_absmax(const float* qpacked, int dpad, int nq, const ExcludedDims& ex, float* out, hipStream_t stream) {
+    if (nq <= 0) return VSC_OK;
+    hipLaunchKernelGGL(row_absmax_kernel, dim3((unsigned)((nq + 3) / 4)), dim3(256), 0, stream, qpacked, dpad, nq, ex, out);
+    VSC_HIP(hipGetLastError());
+    return VSC_OK;
+}
+
 // Row thresholds of one launch when coordinates are excluded: a pair (q, r) with exact score > t (t = the row's own
 // threshold `base_thr[row]`, or the search radius *radius) has
 //     (score restricted to the kept coordinates)  >  t - b_q,      b_q = sum_c q_c v_c.

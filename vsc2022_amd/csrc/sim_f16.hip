@@ -523,7 +523,9 @@ __device__ __forceinline__ void rescore_list(const RescoreArgs& a, float radius,
         const long long c = x >> 2;
         // (the tail is a sequence of chunks, each filled up to its own level: cand_list.h)
         const bool valid = c < n && (fill == nullptr || (int)(c & ((1ll << shift) - 1)) < fill[c >> shift]);
-        const int i = valid ? ci[c] : 0, j = valid ? cj[c] : 0;
+        int i = valid ? ci[c] : 0;
+        const int j = valid ? cj[c] : 0;
+        if (a.perm && valid) i = a.perm_i0 + a.perm[i - a.perm_i0];  // position inside a permuted int8 launch -> row
         const f32x4* q = reinterpret_cast<const f32x4*>(a.Q + (int64_t)i * a.dpad) + 2 * g;
         const f32x4* r = reinterpret_cast<const f32x4*>(a.R + (int64_t)j * a.dpad) + 2 * g;
         float acc = 0.0f;  // the live value sits in lane 0 of the quad at the top of every round

@@ -142,7 +142,7 @@ __device__ __forceinline__ void emit_candidates(const SimI8PArgs& a, const bool 
                 }
                 if (mine) {
                     pos += __builtin_amdgcn_mbcnt_hi((unsigned)(ok >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)ok, 0u));
-                    a.out_i[pos] = a.i0 + (a.perm ? a.perm[i] : i);
+                    a.out_i[pos] = a.i0 + i;  // (a position when the launch's rows are permuted: the exact stage maps it back)
                     a.out_j[pos] = j;
                 }
             }
@@ -150,9 +150,7 @@ __device__ __forceinline__ void emit_candidates(const SimI8PArgs& a, const bool 
 }
 
 // The fast path: interior tile, room for a whole tile (8192 entries) left in the wave's segment: position = count +
-// (lanes of this register's ballot below me), two buffer stores with a 32-bit offset.  PERM: the launch's rows are
-// permuted (a.perm: position -> row), one extra load per candidate.
-template <bool PERM>
+// (lanes of this register's ballot below me), two buffer stores with a 32-bit offset.
 __device__ __forceinline__ void emit_candidates_seg(const SimI8PArgs& a, const int (&ti)[4][2], int row0, int col0,
                                                     const i32x16 (&acc)[4][2], const int (&bm)[4][2],
                                                     __amdgpu_buffer_rsrc_t rs_i, __amdgpu_buffer_rsrc_t rs_j, int& count) {
@@ -174,7 +172,7 @@ __device__ __forceinline__ void emit_candidates_seg(const SimI8PArgs& a, const i
                                                                             __builtin_amdgcn_mbcnt_lo((unsigned)hits, 0u)))
                                     << 2;
                     const int p = pbase + (r & 3) + 8 * (r >> 2);
-                    __builtin_amdgcn_raw_buffer_store_b32(a.i0 + (PERM ? a.perm[p] : p), rs_i, off, 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b32(a.i0 + p, rs_i, off, 0, 0);
                     __builtin_amdgcn_raw_buffer_store_b32(j, rs_j, off, 0, 0);
                 }
                 count += __popcll(hits);
@@ -358,10 +356,7 @@ __global__ __launch_bounds__(512) void sim_i8p_kernel(SimI8PArgs a) {
             if (__any(any_blk)) {
                 const bool interior = panel * PR + PR <= a.nq && col0 + 64 <= a.nr;
                 if (interior && !all[0] && !all[1] && count + 8192 <= a.seg_cap) {
-                    if (ROWTHR && a.perm)
-                        emit_candidates_seg<true>(a, ti, panel * PR, col0, acc, bm, rs_ci, rs_cj, count);
-                    else
-                        emit_candidates_seg<false>(a, ti, panel * PR, col0, acc, bm, rs_ci, rs_cj, count);
+                    emit_candidates_seg(a, ti, panel * PR, col0, acc, bm, rs_ci, rs_cj, count);
                 } else {
                     emit_candidates(a, all, ti, panel * PR, col0, interior, acc, bm, seg_base, count, &tail_sh[wave]);
                 }
