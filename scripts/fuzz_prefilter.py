@@ -3,6 +3,7 @@
 all-fp32 route on the same GPU -- global top-K, k-NN and range search must agree bit for bit.
 
     python scripts/fuzz_prefilter.py --seconds 120 --seed 0
+    VSC_I8=2 python scripts/fuzz_prefilter.py --seconds 120        # ... with the int8 kernel on every pre-filtered batch
 """
 import argparse
 import os
@@ -42,14 +43,14 @@ def bits(x):
 t_end = time.time() + args.seconds
 n_cases = 0
 while time.time() < t_end:
-    d = int(rng.choice([3, 17, 40, 64, 100, 128, 200, 256, 384, 512, 600]))
+    d = int(rng.choice([3, 17, 40, 64, 100, 128, 200, 256, 384, 512, 600, 768, 1000]))
     nq = int(rng.integers(1, 4000))
     nr = int(rng.integers(1, 25000))
     if args.big:
         d = int(rng.choice([32, 64, 128, 256]))
         nq = int(rng.integers(2000, 70000))
         nr = int(rng.integers(20000, 150000))
-    style = int(rng.integers(0, 4))
+    style = int(rng.integers(0, 5))
     q = rng.standard_normal((nq, d)).astype(np.float32)
     r = rng.standard_normal((nr, d)).astype(np.float32)
     if style != 1:  # unit rows (descriptor-like); style 1 keeps raw gaussian rows (norm ~ sqrt(d))
@@ -61,6 +62,10 @@ while time.time() < t_end:
     if style == 3:  # widely different norms, log-uniform from 1e-5 (fp16-subnormal elements) to 20
         q *= np.exp(rng.uniform(np.log(1e-5), np.log(20.0), (nq, 1))).astype(np.float32)
         r *= np.exp(rng.uniform(np.log(1e-5), np.log(20.0), (nr, 1))).astype(np.float32)
+    if style == 4 and d > 4:  # coordinates on which all references agree (score-normalised descriptors have one)
+        for c in rng.choice(d, int(rng.integers(1, min(d - 1, 12))), replace=False):
+            r[:, c] = np.float32(rng.choice([1.0, -1.0, 0.3, 25.0, 1e-3]))
+            q[:, c] = rng.uniform(-0.5, 0.5, nq).astype(np.float32)
     if os.environ.get("FUZZ_VERBOSE"):
         print(f"case {n_cases}: d={d} nq={nq} nr={nr} style={style}", flush=True)
     cut = int(rng.integers(0, nr + 1))
