@@ -66,6 +66,7 @@ struct Workspace {
     DevBuf rowthr;          // per-row thresholds of the pre-filtered k-NN
     DevBuf slices;          // per-panel slice counters of the panel-stationary pre-filter
     DevBuf q8, pstat;       // int8 image + per-panel {1/s, E, N, s} of ONE launch's query rows (sim_i8p.hip)
+    DevBuf cs[4], cstmp, csn;  // candidates of a launch compacted + sorted by reference row (keys, values, ping-pong)
     DevBuf tailfill;        // fill levels of the chunks of the candidate list's shared tail (cand_list.h)
     DevBuf rt8, rt8b;       // ... and its row thresholds in position order (rows sorted by threshold inside a launch);
                             // rt8b: thresholds lowered by the excluded coordinates' contribution, in row order
@@ -73,6 +74,8 @@ struct Workspace {
         stage.release(); qbuf.release();
         qh.release(); qn.release(); ci.release(); cj.release(); segcnt.release(); rowthr.release(); slices.release();
         q8.release(); pstat.release(); rt8.release(); rt8b.release(); tailfill.release();
+        for (auto& b : cs) b.release();
+        cstmp.release(); csn.release();
         for (auto& b : hA) b.release();
         for (auto& b : hB) b.release();
         ctl.release(); w0.release(); w1.release(); w2.release(); w3.release(); tmp.release(); cnt.release();
@@ -770,7 +773,26 @@ static int enqueue_f16(vsc_index* idx, const float* qpacked, int64_t i0, int64_t
         r.overflow = &ctl->overflow;
         r.row_thr = row_thr;
         VSC_TRY(prof_begin(idx, &stop, 2));
-        VSC_TRY(launch_rescore(r, idx->stream));
+        // VSC_RESCORE_SORT=1: compact the candidates, sort them by reference row, re-score the dense list (needs the
+        // candidate count on the host: one stream sync per launch)
+        static const bool by_ref = getenv("VSC_RESCORE_SORT") && getenv("VSC_RESCORE_SORT")[0] == '1';
+        if (by_ref) {
+            const size_t cap_e = (size_t)2 * (size_t)ccap;
+            for (auto& b : idx->ws.cs) VSC_TRY(b.reserve(cap_e * sizeof(uint32_t)));
+            VSC_TRY(idx->ws.csn.reserve(sizeof(unsigned long long)));
+            const int n_chunks_max = (int)std::min<long long>((tail_cap >> tail_shift) + 1, 1 << 20);
+            VSC_TRY(launch_cand_compact(r, n_chunks_max, idx->ws.cs[0].as<uint32_t>(), idx->ws.cs[2].as<uint32_t>(),
+                                        idx->ws.csn.as<unsigned long long>(), idx->stream));
+            unsigned long long n_c = 0;
+            VSC_HIP(hipMemcpyAsync(&n_c, idx->ws.csn.p, sizeof(n_c), hipMemcpyDeviceToHost, idx->stream));
+            VSC_HIP(hipStreamSynchronize(idx->stream));
+            const uint32_t *sj = nullptr, *si = nullptr;
+            VSC_TRY(sort_candidates_by_ref(idx->ws.cs[0].as<uint32_t>(), idx->ws.cs[1].as<uint32_t>(), idx->ws.cs[2].as<uint32_t>(),
+                                           idx->ws.cs[3].as<uint32_t>(), (int64_t)n_c, nrefs, idx->ws.cstmp, &sj, &si, idx->stream));
+            VSC_TRY(launch_rescore_dense(r, sj, si, (long long)n_c, idx->stream));
+        } else {
+            VSC_TRY(launch_rescore(r, idx->stream));
+        }
         VSC_TRY(prof_end(idx, stop, 0.0, 2));
     }
     return VSC_OK;

@@ -122,6 +122,10 @@ int launch_sim_thresh(const SimThreshArgs&, hipStream_t);
 int launch_sim_f16(const SimF16Args&, hipStream_t);
 int sim_f16_grid(int tq, int tr);
 int launch_rescore(const RescoreArgs&, hipStream_t);
+int launch_cand_compact(const RescoreArgs&, int, uint32_t*, uint32_t*, unsigned long long*, hipStream_t);
+int launch_rescore_dense(const RescoreArgs&, const uint32_t*, const uint32_t*, long long, hipStream_t);
+int sort_candidates_by_ref(uint32_t*, uint32_t*, uint32_t*, uint32_t*, int64_t, int64_t, DevBuf&, const uint32_t**,
+                           const uint32_t**, hipStream_t);
 void sim_f16p_plan(int64_t nq, int64_t nr, int* npanel, int* nsteps, int* slice, int* grid);
 int launch_sim_f16p(const SimF16PArgs&, int grid, hipStream_t);
 int launch_sim_i8p(const SimI8PArgs&, int grid, hipStream_t);

@@ -17,6 +17,8 @@
 //   rescore_kernel   : four lanes per candidate run the exact ascending-k fp32 fma chain on the packed fp32
 //                      rows, the running sum hopping between them (one 128-byte line per row and load).
 //                      HBM/L2-bound: 8*dpad bytes per candidate.
+#include <algorithm>
+
 #include "kernels.h"
 
 namespace vscmi {
@@ -600,6 +602,75 @@ __global__ __launch_bounds__(256) void rescore_kernel(RescoreArgs a) {
 }
 
 __global__ void tail_reset_kernel(unsigned long long* tail_count) { *tail_count = 0; }
+
+// ---- candidates ordered by reference row
+// The candidates of a launch hit every reference row several times (int8 batches of the search: ~4 x, k-NN passes:
+// 10-80 x).  Compacted out of the waves' segments and sorted by reference row, the chains of one reference row sit in
+// neighbouring lanes: their loads of that row are one cache line request instead of several, and the row comes out of
+// HBM once.  cand_compact: one workgroup per segment / tail chunk, dense position by one atomic per workgroup (the
+// order inside the dense list does not matter: it is sorted next).
+__global__ __launch_bounds__(256) void cand_compact_kernel(RescoreArgs a, uint32_t* __restrict__ key_j,
+                                                           uint32_t* __restrict__ val_i, unsigned long long* n_out) {
+    __shared__ unsigned long long base_sh;
+    if (*a.overflow) return;
+    const int b = blockIdx.x;
+    const int32_t *ci, *cj;
+    int n;
+    if (b < a.n_seg) {
+        n = min(a.seg_count[b], a.seg_cap);
+        ci = a.cand_i + (int64_t)b * a.seg_cap;
+        cj = a.cand_j + (int64_t)b * a.seg_cap;
+    } else {
+        const long long chunk = b - a.n_seg;
+        const unsigned long long nt = *a.tail_count;
+        if ((unsigned long long)(chunk << a.tail_shift) >= nt || (long long)nt > a.tail_cap) return;
+        n = a.tail_fill[chunk];
+        ci = a.cand_i + a.tail_base + (chunk << a.tail_shift);
+        cj = a.cand_j + a.tail_base + (chunk << a.tail_shift);
+    }
+    if (n <= 0) return;
+    if (threadIdx.x == 0) base_sh = atomicAdd(n_out, (unsigned long long)n);
+    __syncthreads();
+    const unsigned long long base = base_sh;
+    for (int x = threadIdx.x; x < n; x += 256) {
+        int i = ci[x];
+        if (a.perm) i = a.perm_i0 + a.perm[i - a.perm_i0];  // position inside a permuted int8 launch -> row
+        key_j[base + x] = (uint32_t)cj[x];
+        val_i[base + x] = (uint32_t)i;
+    }
+}
+
+__global__ __launch_bounds__(256) void rescore_dense_kernel(RescoreArgs a, const uint32_t* __restrict__ sj,
+                                                            const uint32_t* __restrict__ si, long long n) {
+    if (*a.overflow) return;
+    __shared__ WaveHits wave_hits[4];
+    WaveHits& buf = wave_hits[threadIdx.x >> 6];
+    int pend = 0;
+    const float radius = a.row_thr ? 0.0f : *a.radius;
+    a.perm = nullptr;  // (rows already)
+    rescore_list(a, radius, reinterpret_cast<const int32_t*>(si), reinterpret_cast<const int32_t*>(sj), n,
+                 (long long)blockIdx.x * 256 + threadIdx.x, (long long)gridDim.x * 256, buf, pend);
+    flush_hits(a, buf, pend);
+    if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(a.n_cand_total, (unsigned long long)n);
+}
+
+int launch_cand_compact(const RescoreArgs& a, int n_chunks_max, uint32_t* key_j, uint32_t* val_i, unsigned long long* n_out,
+                        hipStream_t stream) {
+    VSC_HIP(hipMemsetAsync(n_out, 0, sizeof(unsigned long long), stream));
+    hipLaunchKernelGGL(cand_compact_kernel, dim3((unsigned)(a.n_seg + n_chunks_max)), dim3(256), 0, stream, a, key_j, val_i, n_out);
+    VSC_HIP(hipGetLastError());
+    return VSC_OK;
+}
+
+int launch_rescore_dense(const RescoreArgs& a, const uint32_t* sj, const uint32_t* si, long long n, hipStream_t stream) {
+    if (n > 0) {
+        const unsigned grid = (unsigned)std::min<long long>(16384, (n * 4 + 255) / 256);
+        hipLaunchKernelGGL(rescore_dense_kernel, dim3(grid), dim3(256), 0, stream, a, sj, si, n);
+    }
+    hipLaunchKernelGGL(tail_reset_kernel, dim3(1), dim3(1), 0, stream, a.tail_count);
+    VSC_HIP(hipGetLastError());
+    return VSC_OK;
+}
 
 int launch_rescore(const RescoreArgs& a, hipStream_t stream) {
     if (a.n_seg <= 0) return VSC_OK;

@@ -114,6 +114,21 @@ int sort_rows_by_threshold(const float* thr, int64_t n, DevBuf& w0, DevBuf& w1, 
     return VSC_OK;
 }
 
+// candidates (reference row, query row) of one launch ordered by reference row: keys need only the bits of nrefs
+int sort_candidates_by_ref(uint32_t* ka, uint32_t* kb, uint32_t* va, uint32_t* vb, int64_t n, int64_t nrefs, DevBuf& tmp,
+                           const uint32_t** sorted_j, const uint32_t** sorted_i, hipStream_t stream) {
+    *sorted_j = ka;
+    *sorted_i = va;
+    if (n <= 0) return VSC_OK;
+    VSC_TRY(tmp.reserve(radix_tmp_bytes(n)));
+    const int w = radix_sort_pairs<uint32_t, uint32_t>(ka, kb, va, vb, n, 0, bits_for((uint64_t)std::max<int64_t>(nrefs, 2) - 1),
+                                                       false, tmp.p, stream);
+    if (w < 0) { set_error("radix sort launch failed"); return VSC_ERR_HIP; }
+    *sorted_j = w ? kb : ka;
+    *sorted_i = w ? vb : va;
+    return VSC_OK;
+}
+
 // ----------------------------------------------------------------------------- pair max
 
 __global__ __launch_bounds__(256) void pair_key_kernel(const int32_t* hi, const int32_t* hj, int64_t n,
