@@ -66,7 +66,8 @@ struct SimI8PArgs {
     const void* Rf; const float4* rmeta;  // fragment-major int8 image; per reference row {1 / s, E, N, N'}
     int dpad8; int nq; int i0; int nr;
     int npanel; int nsteps; int slice;     // work split (sim_f16p_plan)
-    int* next_slice;
+    int* next_slice;                       // [npanel + 1]: per-panel slice counters + one global item counter
+    int order;                             // 0: panel-major with stealing; 1: slice-major (all panels of a slice first)
     float c_acc;                           // rounding of the exact fp32 chain per |q||r|
     const float* radius; const float* row_thr;  // as in SimF16Args (row_thr indexed by POSITION inside the launch)
     int32_t* out_i; int32_t* out_j;

@@ -229,6 +229,15 @@ __global__ __launch_bounds__(512) void sim_i8p_kernel(SimI8PArgs a) {
 #else
             const bool lost = false;
 #endif
+            if (a.order == 1 && !lost) {
+                // slice-major: items (slice, panel) in one global order -- every workgroup of the chip is inside
+                // the same few MB of the reference image, each XCD fetches a slice once; the price is a panel load
+                // (64 KiB at 512-d) per item
+                int t = 0;
+                if (lane == 0) t = atomicAdd(&a.next_slice[a.npanel], 1);
+                t = __shfl(t, 0);
+                if (t >= nslice * a.npanel) { p = -1; } else { s = t / a.npanel; p = t - s * a.npanel; }
+            } else
             for (;;) {
                 if (lost) { p = -1; break; }
                 if (lane == 0) s = atomicAdd(&a.next_slice[p], 1);
@@ -391,7 +400,7 @@ int launch_sim_i8p(const SimI8PArgs& a, int grid, hipStream_t stream) {
         if (grid > 0) VSC_HIP(hipMemsetAsync(a.seg_count, 0, (size_t)grid * 8 * sizeof(int), stream));
         return VSC_OK;
     }
-    VSC_HIP(hipMemsetAsync(a.next_slice, 0, (size_t)a.npanel * sizeof(int), stream));
+    VSC_HIP(hipMemsetAsync(a.next_slice, 0, ((size_t)a.npanel + 1) * sizeof(int), stream));
     switch (a.dpad8) {
         case 256: return launch_nkc<1>(a, grid, stream);
         case 512: return launch_nkc<2>(a, grid, stream);
