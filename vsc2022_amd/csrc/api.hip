@@ -157,7 +157,7 @@ struct vsc_index {
     int64_t i8_rows = 0;  // rows [0, i8_rows) of the image are current
     unsigned long long stat_i8_fallbacks = 0;
     bool prefilter = false, prefilter_force = false;
-    double prefilter_density = 0.02;  // expected hit density below which a batch goes through the pre-filter
+    double prefilter_density = 0.05;  // expected hit density below which a batch goes through the pre-filter (r03: 0.02 -> 0.05 with the cheaper exact stage: -0.8 %)
     unsigned long long stat_candidates = 0, stat_hits = 0;  // last search (vsc_index_profile_read)
     DevBuf cand[3];  // sorted hits of vsc_index_candidates
     hipStream_t stream = nullptr;
@@ -900,7 +900,7 @@ int vsc_index_global_topk(vsc_index_t* idx, const float* q, int64_t nq, int q_me
             // After i0 rows the radius sits near the K-th best of i0 * ntotal scores, so about
             // K / (i0 * ntotal) of this batch's pairs are hits.  While that density is high the
             // exact kernel is cheaper than pre-filtering and re-scoring nearly everything
-            // (exact: ~7.5 ps per pair; re-scoring: ~0.5 ns per candidate; measured optimum near 2 %).
+            // (exact: ~7.5 ps per pair; re-scoring: ~0.5 ns per candidate; measured optimum near 2 % with the segment-wise exact stage, 5 % with the sorted one).
             const bool f16 = idx->prefilter_force ||
                              (idx->prefilter && i0 > 0 && (double)K < idx->prefilter_density * (double)i0 * (double)idx->ntotal);
             // ... and once it is low enough that the int8 kernel's 4-5x candidates cost less than the fp16 kernel's
