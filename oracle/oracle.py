@@ -34,6 +34,28 @@ def build(force: bool = False) -> str:
     return _LIB_PATH
 
 
+def _usable_cpus() -> int:
+    """CPUs this process may really use: the affinity mask, cut by the cgroup CPU quota (a pod on a large host sees
+    every core in omp_get_max_threads(); a team that size on a small quota spends its time being throttled)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            quota, period = f.read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(quota) // int(period)))
+    except (OSError, ValueError):
+        try:
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as f:
+                quota = int(f.read())
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f:
+                period = int(f.read())
+            if quota > 0 and period > 0:
+                n = min(n, max(1, quota // period))
+        except (OSError, ValueError):
+            pass
+    return max(1, n)
+
+
 def lib():
     global _lib
     if _lib is None:
@@ -60,6 +82,7 @@ def lib():
         L.orc_row_normalize.restype = None
         L.orc_num_threads.restype = ctypes.c_int
         L.orc_set_num_threads.argtypes = [ctypes.c_int]
+        L.orc_set_num_threads(min(L.orc_num_threads(), _usable_cpus()))
         if hasattr(L, "orc_tn"):
             L.orc_tn.argtypes = [c_f, i64, i64, ctypes.POINTER(TNParams), c_i32, i64]
             L.orc_tn.restype = i64

@@ -80,7 +80,9 @@ static inline void l2_panel(const float *q, const float *rt, int64_t d, float *a
 void orc_scores(const float *q, int64_t nq, const float *r, int64_t nr, int64_t d, int metric,
                 float *out) {
     const int64_t npanel = (nr + JB - 1) / JB;
-#pragma omp parallel
+    /* (a few rows: one thread -- waking a team costs more than the work, and far more in a container whose CPU
+     * quota is below the host's core count) */
+#pragma omp parallel if (npanel > 1 && nq * nr * d >= (1 << 20))
     {
         float *rt = (float *)malloc(sizeof(float) * (size_t)(d > 0 ? d : 1) * JB);
         float acc[JB];

@@ -105,3 +105,15 @@ def g9_inputs(fg_type):
         return (x / np.linalg.norm(x, axis=-1, keepdims=True)).astype(np.float32)
 
     return q, r, [fine(v) for v in q], [fine(v) for v in r]
+
+
+def pair_scores(orc, a, b, metric=None, chunk=256):
+    """score(a[k], b[k]) for every k through the oracle's score matrix (its diagonal, in chunks): one oracle call per
+    256 pairs instead of one per pair."""
+    import numpy as np
+
+    out = np.empty(len(a), dtype=np.float32)
+    for k0 in range(0, len(a), chunk):
+        m = orc.scores(a[k0:k0 + chunk], b[k0:k0 + chunk]) if metric is None else orc.scores(a[k0:k0 + chunk], b[k0:k0 + chunk], metric)
+        out[k0:k0 + chunk] = np.diagonal(m)
+    return out

@@ -4,6 +4,8 @@ score 4e11 pairs)."""
 import numpy as np
 import pytest
 
+from helpers import pair_scores
+
 pytestmark = pytest.mark.gpu
 
 
@@ -45,7 +47,7 @@ def test_fullsize_search_properties(fullsize, orc):
     pick = rng.choice(K, 2000, replace=False)
     q_rows = queries[torch.from_numpy(i[pick]).long().to(queries.device)].cpu().numpy()
     r_rows = refs[torch.from_numpy(j[pick]).long().to(refs.device)].cpu().numpy()
-    exact = np.array([orc.scores(q_rows[k:k + 1], r_rows[k:k + 1])[0, 0] for k in range(len(pick))], dtype=np.float32)
+    exact = pair_scores(orc, q_rows, r_rows)
     assert np.array_equal(exact.view(np.uint32), s[pick].view(np.uint32))
     # completeness on a sample of rows: every score above the K-th best hit of the search is a hit
     rows = rng.choice(n_qv * qf, 24, replace=False)
@@ -110,7 +112,7 @@ def test_fullsize_knn_properties(fullsize, orc):
     sub = orc.scores(qs, refs[lo : lo + 200000].cpu().numpy())
     for a, row in enumerate(rows):
         listed = refs[torch.from_numpy(I20[row]).long().to(refs.device)].cpu().numpy()
-        exact = np.array([orc.scores(qs[a : a + 1], listed[b : b + 1])[0, 0] for b in range(20)], dtype=np.float32)
+        exact = pair_scores(orc, np.repeat(qs[a : a + 1], 20, axis=0), listed)
         assert np.array_equal(exact.view(np.uint32), D20[row].view(np.uint32)), row
         better = np.nonzero(sub[a] > D20[row, -1])[0] + lo
         assert set(better.tolist()) <= set(I20[row].tolist()), row
@@ -173,7 +175,7 @@ def test_fullsize_score_normalised_path(fullsize, orc):
     pick = rng.choice(K, 1000, replace=False)
     a = qn[torch.from_numpy(i[pick]).long().to(dev)].cpu().numpy()
     b = rn[torch.from_numpy(j[pick]).long().to(dev)].cpu().numpy()
-    exact = np.array([orc.scores(a[k:k + 1], b[k:k + 1])[0, 0] for k in range(len(pick))], dtype=np.float32)
+    exact = pair_scores(orc, a, b)
     assert np.array_equal(exact.view(np.uint32), s[pick].view(np.uint32))
     sub = orc.scores(got, rn[:200000].cpu().numpy())
     hits_set = set(zip(i.tolist(), j.tolist()))

@@ -557,6 +557,9 @@ static int pack_queries(vsc_index* idx, const float* q, int64_t nq, int q_mem, f
     return VSC_OK;
 }
 
+// entries of each candidate array for a candidate capacity of ccap (segments + chunked tail, see ensure_hit_buffers)
+static inline int64_t cand_entries(int64_t ccap) { return 4 * ccap + 2048 * 128; }
+
 // cap: kept hits (list A, and the compaction target B of the thresholded search); ccap: candidates of ONE
 // pre-filter launch (defaults to cap)
 static int ensure_hit_buffers(vsc_index* idx, int64_t cap, int64_t ccap = -1, bool need_b = true) {
@@ -566,10 +569,12 @@ static int ensure_hit_buffers(vsc_index* idx, int64_t cap, int64_t ccap = -1, bo
         if (need_b) VSC_TRY(idx->ws.hB[c].reserve((size_t)cap * 4));
     }
     if (idx->prefilter) {
-        // candidate list: `ccap` entries in per-wave segments + a shared tail of `ccap` entries, so any
-        // distribution of <= ccap candidates over the waves fits
-        VSC_TRY(idx->ws.ci.reserve((size_t)ccap * 8));
-        VSC_TRY(idx->ws.cj.reserve((size_t)ccap * 8));
+        // candidate list: `ccap` entries in per-wave segments + a shared tail.  The tail is handed out in chunks
+        // (cand_list.h): a wave closes a chunk when its next group of <= 64 candidates does not fit, so a chunk is at
+        // least half used on average, and every wave leaves one chunk partly filled -- 3 ccap + 128 entries per wave
+        // hold any distribution of <= ccap candidates over the waves
+        VSC_TRY(idx->ws.ci.reserve((size_t)cand_entries(ccap) * 4));
+        VSC_TRY(idx->ws.cj.reserve((size_t)cand_entries(ccap) * 4));
         VSC_TRY(idx->ws.segcnt.reserve(2048 * sizeof(int)));
     }
     VSC_TRY(idx->ws.ctl.reserve(sizeof(SelectCtl)));
@@ -676,7 +681,7 @@ static int enqueue_f16(vsc_index* idx, const float* qpacked, int64_t i0, int64_t
             f.out_j = cand_j;
             seg_cap = (int)std::min<int64_t>(ccap / (grid * 8), 0x7fffffff);
             tail_base = (int64_t)seg_cap * grid * 8;
-            tail_cap = 2 * ccap - tail_base;
+            tail_cap = cand_entries(ccap) - tail_base;
             f.seg_cap = seg_cap;
             f.seg_count = idx->ws.segcnt.as<int>();
             f.tail_base = tail_base;
@@ -709,7 +714,7 @@ static int enqueue_f16(vsc_index* idx, const float* qpacked, int64_t i0, int64_t
             f.out_j = cand_j;
             seg_cap = (int)std::min<int64_t>(ccap / (grid * 8), 0x7fffffff);
             tail_base = (int64_t)seg_cap * grid * 8;
-            tail_cap = 2 * ccap - tail_base;
+            tail_cap = cand_entries(ccap) - tail_base;
             f.seg_cap = seg_cap;
             f.seg_count = idx->ws.segcnt.as<int>();
             f.tail_base = tail_base;
@@ -742,7 +747,7 @@ static int enqueue_f16(vsc_index* idx, const float* qpacked, int64_t i0, int64_t
             grid = sim_f16_grid(f.tq, f.tr);
             seg_cap = (int)std::min<int64_t>(ccap / (grid * 8), 0x7fffffff);
             tail_base = (int64_t)seg_cap * grid * 8;
-            tail_cap = 2 * ccap - tail_base;
+            tail_cap = cand_entries(ccap) - tail_base;
             f.seg_cap = seg_cap;
             f.seg_count = idx->ws.segcnt.as<int>();
             f.tail_base = tail_base;
@@ -789,7 +794,7 @@ static int enqueue_f16(vsc_index* idx, const float* qpacked, int64_t i0, int64_t
         // segments as they are.
         static const bool by_ref = !(getenv("VSC_RESCORE_SORT") && getenv("VSC_RESCORE_SORT")[0] == '0');
         if (by_ref) {
-            const size_t cap_e = (size_t)2 * (size_t)ccap;
+            const size_t cap_e = (size_t)cand_entries(ccap);  // (an overflowing launch may store more than ccap)
             for (auto& b : idx->ws.cs) VSC_TRY(b.reserve(cap_e * sizeof(uint32_t)));
             VSC_TRY(idx->ws.csn.reserve(sizeof(unsigned long long)));
             const int n_chunks_max = (int)std::min<long long>((tail_cap >> tail_shift) + 1, 1 << 20);

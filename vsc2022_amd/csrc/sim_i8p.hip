@@ -41,6 +41,31 @@ __device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rsrc, int voff, cha
 __device__ __forceinline__ i32x4 bload(__amdgpu_buffer_rsrc_t rs, int voff, int soff) {
     return __builtin_bit_cast(i32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, 0));
 }
+#ifndef VSC_I8P_ASMLOAD
+#define VSC_I8P_ASMLOAD 1  // r03: +5 % without candidates (2601 -> 2735 TOP/s), +1 % on the bench, the k-NN passes and config 4
+#endif
+// The reference stream with hand-placed waits: the loads are opaque to the compiler's s_waitcnt insertion, which
+// otherwise (a) drains the whole stream with vmcnt(0) at the start of every tile -- it loses count of the outstanding
+// loads across the emission branches -- and (b) waits vmcnt(3) where the ring allows vmcnt(4).  A load's destination
+// must not be touched before ring_wait has named it (the "+v" ties keep every use behind the wait).
+__device__ __forceinline__ void bload_asm0(i32x4& dst, __amdgpu_buffer_rsrc_t rs, int voff, int soff) {
+    asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=&v"(dst) : "v"(voff), "s"(rs), "s"(soff) : "memory");
+}
+__device__ __forceinline__ void bload_asm1(i32x4& dst, __amdgpu_buffer_rsrc_t rs, int voff, int soff) {
+    asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen offset:1024" : "=&v"(dst) : "v"(voff), "s"(rs), "s"(soff) : "memory");
+}
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void gload_asm(f32x4v& dst, const float4* p) {
+    asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(dst) : "v"(p) : "memory");
+}
+template <int N>
+__device__ __forceinline__ void meta_wait(f32x4v& m0, f32x4v& m1) {
+    asm volatile("s_waitcnt vmcnt(%2)" : "+v"(m0), "+v"(m1) : "n"(N));
+}
+template <int N>
+__device__ __forceinline__ void ring_wait(i32x4& b0, i32x4& b1) {
+    asm volatile("s_waitcnt vmcnt(%2)" : "+v"(b0), "+v"(b1) : "n"(N));
+}
 __device__ __forceinline__ const char* uniform_ptr(const char* p) {
     const uint64_t v = reinterpret_cast<uint64_t>(p);
     const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
@@ -65,18 +90,29 @@ __device__ __forceinline__ void tile_mma(const char* smem, const int (&abase)[8]
         const int so = (t < NKS) ? so_tile + t * 2048 : so_next + (t - NKS) * 2048;
         const int kn = (ks + 1) % NKS;  // A fragments of the next k-step (the next tile starts at 0 again)
         const char* anext = smem + (kn >> 3) * 32768 + abase[kn & 7];
+#if VSC_I8P_ASMLOAD
+        // both fragments of this k-step have landed once at most the 2 (PF - 2) loads of the younger k-steps are out
+        ring_wait<2 * (PF - 2)>(ring[ks % PF][0], ring[ks % PF][1]);
+#endif
 #pragma unroll
         for (int m = 0; m < 4; ++m) {
             acc[m][0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[m], ring[ks % PF][0], ks == 0 ? zero : acc[m][0], 0, 0, 0);
             acc[m][1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[m], ring[ks % PF][1], ks == 0 ? zero : acc[m][1], 0, 0, 0);
             a[m] = *reinterpret_cast<const i32x4*>(anext + m * 8192);
+#if VSC_I8P_ASMLOAD
+            if (m == 0) bload_asm0(ring[(ks + PF - 1) % PF][0], rs, lane16, so);
+            if (m == 1) bload_asm1(ring[(ks + PF - 1) % PF][1], rs, lane16, so);
+#else
             if (m < 2) ring[(ks + PF - 1) % PF][m] = bload(rs, lane16 + m * 1024, so);
+#endif
         }
 #pragma unroll
         for (int m = 0; m < 4; ++m) {
             __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
             __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+#if !VSC_I8P_ASMLOAD
             if (m < 2) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+#endif
         }
     }
 }
@@ -310,8 +346,13 @@ __global__ __launch_bounds__(512) void sim_i8p_kernel(SimI8PArgs a) {
         i32x4 ring[PF][2];
 #pragma unroll
         for (int dd = 0; dd < PF - 1; ++dd) {
+#if VSC_I8P_ASMLOAD
+            bload_asm0(ring[dd][0], rs, lane16, so_tile + dd * 2048);
+            bload_asm1(ring[dd][1], rs, lane16, so_tile + dd * 2048);
+#else
             ring[dd][0] = bload(rs, lane16, so_tile + dd * 2048);
             ring[dd][1] = bload(rs, lane16 + 1024, so_tile + dd * 2048);
+#endif
         }
         i32x4 afr[4];
 #pragma unroll
@@ -319,10 +360,21 @@ __global__ __launch_bounds__(512) void sim_i8p_kernel(SimI8PArgs a) {
         for (int cs = cs0; cs < cs1; ++cs) {
             const int col0 = cs * CSW + wave * 64;
             // {1 / s_r, E_r, N_r, N'_r} of the lane's two columns (the table is padded to whole col-steps)
+#if VSC_I8P_ASMLOAD
+            // (issued behind the stream loads of the previous tile, ahead of this tile's: after the K loop only the
+            // 2 (PF - 1) stream loads of the next tile are younger)
+            f32x4v m0, m1;
+            gload_asm(m0, a.rmeta + col0 + (lane & 31));
+            gload_asm(m1, a.rmeta + col0 + 32 + (lane & 31));
+#else
             const float4 m0 = a.rmeta[col0 + (lane & 31)], m1 = a.rmeta[col0 + 32 + (lane & 31)];
+#endif
             i32x16 acc[4][2];
             tile_mma<NKC>(smem, abase, afr, ring, rs, so_tile, so_tile + 8 * TILEB, lane16, acc);
             so_tile += 8 * TILEB;
+#if VSC_I8P_ASMLOAD
+            meta_wait<2 * (PF - 1)>(m0, m1);
+#endif
             const float eps[2] = {(coef_k * m0.w + coef_e * m0.y + coef_n * m0.z) * 1.001f,
                                   (coef_k * m1.w + coef_e * m1.y + coef_n * m1.z) * 1.001f};
             const float inv[2] = {inv_sq * m0.x, inv_sq * m1.x};
@@ -372,6 +424,9 @@ __global__ __launch_bounds__(512) void sim_i8p_kernel(SimI8PArgs a) {
             }
         }
     }
+#if VSC_I8P_ASMLOAD
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the stream ran a few k-steps past its end)
+#endif
     tail_close(a.tail_base, a.tail_shift, a.tail_fill, lane, &tail_sh[wave]);
     if (lane == 0) a.seg_count[seg] = count;
 }
