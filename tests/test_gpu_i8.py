@@ -310,3 +310,15 @@ def test_parity_suites_with_forced_int8():
                         "and not chosen_by_size"],
                        cwd=ROOT, env=e, capture_output=True, text=True, timeout=1800)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+
+
+@pytest.mark.gpu
+def test_int8_route_with_the_fp16_screen():
+    """VSC_I8_SCREEN=1 (off by default: measured neutral on the bench): the int8 candidates pass `f16_screen_kernel`
+    before the exact stage.  This file's oracle tests and the search suite again with it on, int8 forced."""
+    e = dict(os.environ, VSC_PREFILTER="2", VSC_I8="2", VSC_I8_SCREEN="1")
+    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", "tests/test_gpu_search.py",
+                        "tests/test_gpu_i8.py", "tests/test_gpu_prefilter.py", "-k",
+                        "not forced_ and not fp32_path_at_scale and not chosen_by and not fp16_screen and not ring_kernel"],
+                       cwd=ROOT, env=e, capture_output=True, text=True, timeout=1800)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]

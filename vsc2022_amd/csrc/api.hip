@@ -796,7 +796,7 @@ static int enqueue_f16(vsc_index* idx, const float* qpacked, int64_t i0, int64_t
         if (by_ref) {
             const size_t cap_e = (size_t)cand_entries(ccap);  // (an overflowing launch may store more than ccap)
             for (auto& b : idx->ws.cs) VSC_TRY(b.reserve(cap_e * sizeof(uint32_t)));
-            VSC_TRY(idx->ws.csn.reserve(sizeof(unsigned long long)));
+            VSC_TRY(idx->ws.csn.reserve(2 * sizeof(unsigned long long)));
             const int n_chunks_max = (int)std::min<long long>((tail_cap >> tail_shift) + 1, 1 << 20);
             VSC_TRY(launch_cand_compact(r, n_chunks_max, idx->ws.cs[0].as<uint32_t>(), idx->ws.cs[2].as<uint32_t>(),
                                         idx->ws.csn.as<unsigned long long>(), idx->stream));
@@ -806,7 +806,44 @@ static int enqueue_f16(vsc_index* idx, const float* qpacked, int64_t i0, int64_t
             const uint32_t *sj = nullptr, *si = nullptr;
             VSC_TRY(sort_candidates_by_ref(idx->ws.cs[0].as<uint32_t>(), idx->ws.cs[1].as<uint32_t>(), idx->ws.cs[2].as<uint32_t>(),
                                            idx->ws.cs[3].as<uint32_t>(), (int64_t)n_c, nrefs, idx->ws.cstmp, &sj, &si, idx->stream));
-            VSC_TRY(launch_rescore_dense(r, sj, si, (long long)n_c, idx->stream));
+            // VSC_I8_SCREEN=1: int8 launches pass an fp16 screen first (sim_f16.hip: f16_screen_kernel).  Measured
+            // neutral and therefore OFF by default: 29 % of the int8 candidates survive it (bench, 128 M -> 37 M per
+            // step), the screen moves half the bytes per pair (23.8 ms) and the exact stage then costs 35.6 instead of
+            // 59.8 ms -- both stages gather one query row per pair from the Infinity Cache at ~6 TB/s, which is the
+            // bound (profiles/r03_prefilter_attribution.md).  Kept because it pays once the survivor share drops
+            // (descriptors with outlier coordinates widen the int8 bound, not the fp16 one).
+            static const bool screen = getenv("VSC_I8_SCREEN") && getenv("VSC_I8_SCREEN")[0] == '1';
+            if (pcls == 5 && screen && n_c > 0) {
+                VSC_TRY(idx->ws.csn.reserve(2 * sizeof(unsigned long long)));
+                ScreenArgs sa;
+                sa.Qh = idx->ws.qh.as<_Float16>();
+                sa.qn = idx->ws.qn.as<float>();
+                sa.Rh = idx->refh.as<_Float16>();
+                sa.rn = idx->refn.as<float>();
+                sa.dpadh = idx->dpadh;
+                sa.frag = idx->frag ? 1 : 0;
+                sa.c1 = c1; sa.c2 = c2; sa.c3 = c3;
+                sa.radius = &ctl->radius;
+                sa.row_thr = row_thr;
+                sa.sj = sj;
+                sa.si = si;
+                sa.n = (long long)n_c;
+                sa.out_j = sj == idx->ws.cs[0].as<uint32_t>() ? idx->ws.cs[1].as<uint32_t>() : idx->ws.cs[0].as<uint32_t>();
+                sa.out_i = si == idx->ws.cs[2].as<uint32_t>() ? idx->ws.cs[3].as<uint32_t>() : idx->ws.cs[2].as<uint32_t>();
+                sa.n_out = idx->ws.csn.as<unsigned long long>() + 1;
+                sa.n_cand_total = &ctl->n_cand_total;
+                sa.overflow = &ctl->overflow;
+                VSC_TRY(launch_f16_screen(sa, idx->stream));
+                VSC_TRY(launch_rescore_dense(r, sa.out_j, sa.out_i, (long long)n_c, idx->stream, sa.n_out));
+                if (getenv("VSC_DEBUG_SCREEN")) {
+                    unsigned long long n_s = 0;
+                    VSC_HIP(hipMemcpyAsync(&n_s, sa.n_out, sizeof(n_s), hipMemcpyDeviceToHost, idx->stream));
+                    VSC_HIP(hipStreamSynchronize(idx->stream));
+                    fprintf(stderr, "[vscmi] fp16 screen: %llu of %llu int8 candidates left (rows %d)\n", n_s, n_c, nqb);
+                }
+            } else {
+                VSC_TRY(launch_rescore_dense(r, sj, si, (long long)n_c, idx->stream));
+            }
         } else {
             VSC_TRY(launch_rescore(r, idx->stream));
         }

@@ -87,6 +87,19 @@ struct RescoreArgs {
     unsigned long long* counter; long long cap; int* overflow;
     const float* row_thr;  // k-NN mode: keep score >= row_thr[global row] (nullptr: score > *radius)
 };
+// fp16 screen of the int8 route's candidates (sim_f16.hip): the pair list sorted by reference row in, the pairs whose
+// fp16 score + error bound still reaches the threshold out
+struct ScreenArgs {
+    const _Float16* Qh; const float* qn;  // row-major fp16 query image, norm bounds (absolute rows)
+    const _Float16* Rh; const float* rn;  // reference image: fragment-major (frag) or row-major
+    int dpadh; int frag;
+    float c1, c2, c3;                     // |fp16 score - exact score| <= c1 |q||r| + c2 (|q| + |r|) + c3
+    const float* radius; const float* row_thr;
+    const uint32_t* sj; const uint32_t* si; long long n;
+    uint32_t* out_j; uint32_t* out_i; unsigned long long* n_out;
+    unsigned long long* n_cand_total;     // statistics: += n
+    const int* overflow;
+};
 struct SimKnnArgs {
     const float* Q; const float* R; int dpad; int nq; int nr; int tq; int tr; int nchunk; int k;
     float* part_s; int32_t* part_j;
@@ -124,7 +137,9 @@ int launch_sim_f16(const SimF16Args&, hipStream_t);
 int sim_f16_grid(int tq, int tr);
 int launch_rescore(const RescoreArgs&, hipStream_t);
 int launch_cand_compact(const RescoreArgs&, int, uint32_t*, uint32_t*, unsigned long long*, hipStream_t);
-int launch_rescore_dense(const RescoreArgs&, const uint32_t*, const uint32_t*, long long, hipStream_t);
+int launch_rescore_dense(const RescoreArgs&, const uint32_t*, const uint32_t*, long long, hipStream_t,
+                         const unsigned long long* n_dev = nullptr);
+int launch_f16_screen(const ScreenArgs&, hipStream_t);
 int sort_candidates_by_ref(uint32_t*, uint32_t*, uint32_t*, uint32_t*, int64_t, int64_t, DevBuf&, const uint32_t**,
                            const uint32_t**, hipStream_t);
 void sim_f16p_plan(int64_t nq, int64_t nr, int* npanel, int* nsteps, int* slice, int* grid);

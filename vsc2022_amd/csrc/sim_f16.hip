@@ -640,9 +640,99 @@ __global__ __launch_bounds__(256) void cand_compact_kernel(RescoreArgs a, uint32
     }
 }
 
-__global__ __launch_bounds__(256) void rescore_dense_kernel(RescoreArgs a, const uint32_t* __restrict__ sj,
-                                                            const uint32_t* __restrict__ si, long long n) {
+// fp16 screen between the int8 pre-filter and the exact stage.  The int8 bound is wide (one scale per row / panel:
+// ~5-10 candidates per pair that really reaches the threshold); the fp16 bound is ~30x narrower, and an fp16 row is
+// half the bytes of the fp32 row the exact stage gathers.  One candidate per quad: lane g takes the 16-byte pieces
+// g, g + 4, ... of both rows (any summation order is inside the bound: products of two fp16 values are exact in fp32,
+// each fma rounds once), the quad's sum is compared like the fp16 pre-filter compares its scores
+// (sim_f16p.hip: candidate_edge).  Survivors are collected per wave in LDS and appended 49-64 at a time; the
+// list stays (roughly) in reference-row order.
+struct WavePairs {
+    uint32_t i[64];
+    uint32_t j[64];
+};
+
+__device__ __forceinline__ float screen_edge(float t, float eps) { return (t - eps) - 2.4e-7f * (fabsf(t) + eps); }
+
+template <bool FRAG>
+__global__ __launch_bounds__(256) void f16_screen_kernel(ScreenArgs a) {
     if (*a.overflow) return;
+    typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+    __shared__ WavePairs wave_pairs[4];
+    WavePairs& buf = wave_pairs[threadIdx.x >> 6];
+    int pend = 0;
+    const int lane = threadIdx.x & 63, g = lane & 3;
+    const long long n_thr = (4 * a.n + 63) & ~63ll;
+    const int npiece = a.dpadh / 8, nks = a.dpadh / 16;
+    const float radius = a.row_thr ? 0.0f : *a.radius;
+    const f16x8* __restrict__ Rp = reinterpret_cast<const f16x8*>(a.Rh);
+    auto flush = [&]() {
+        if (pend == 0) return;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        unsigned long long base = 0;
+        if (lane == 0) base = atomicAdd(a.n_out, (unsigned long long)pend);
+        base = __shfl(base, 0);
+        if (lane < pend) {
+            a.out_i[base + lane] = buf.i[lane];
+            a.out_j[base + lane] = buf.j[lane];
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        pend = 0;
+    };
+    for (long long x = (long long)blockIdx.x * 256 + threadIdx.x; x < n_thr; x += (long long)gridDim.x * 256) {
+        const long long c = x >> 2;
+        const bool valid = c < a.n;
+        const uint32_t i = valid ? a.si[c] : 0u, j = valid ? a.sj[c] : 0u;
+        const f16x8* __restrict__ q = reinterpret_cast<const f16x8*>(a.Qh + (int64_t)i * a.dpadh);
+        const int64_t rbase = FRAG ? (int64_t)(j >> 6) * nks * 128 + ((j >> 5) & 1) * 64 + (j & 31)
+                                   : (int64_t)j * npiece;
+        float s0 = 0.0f, s1 = 0.0f;
+#pragma unroll 8
+        for (int p = g; p < npiece; p += 4) {
+            const f16x8 qv = q[p];
+            const f16x8 rv = FRAG ? Rp[rbase + (int64_t)(p >> 1) * 128 + (p & 1) * 32] : Rp[rbase + p];
+#pragma unroll
+            for (int e = 0; e < 8; e += 2) {
+                s0 = __fmaf_rn((float)qv[e], (float)rv[e], s0);
+                s1 = __fmaf_rn((float)qv[e + 1], (float)rv[e + 1], s1);
+            }
+        }
+        float acc = s0 + s1;
+        acc += __shfl_xor(acc, 1);
+        acc += __shfl_xor(acc, 2);
+        const float eps = (a.c1 * a.qn[i] * a.rn[j] + a.c2 * (a.qn[i] + a.rn[j]) + a.c3) * 1.001f;
+        const bool pass = valid && g == 0 &&
+                          (!(eps < INFINITY) || (a.row_thr ? acc >= screen_edge(a.row_thr[i], eps) : acc > screen_edge(radius, eps)));
+        const unsigned long long m = __ballot(pass);  // <= 16 per pass
+        if (pass) {
+            const int p = pend + __popcll(m & ((1ull << lane) - 1));
+            buf.i[p] = i;
+            buf.j[p] = j;
+        }
+        pend += __popcll(m);
+        if (pend > 48) flush();
+    }
+    flush();
+    if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(a.n_cand_total, (unsigned long long)a.n);
+}
+
+int launch_f16_screen(const ScreenArgs& a, hipStream_t stream) {
+    VSC_HIP(hipMemsetAsync(a.n_out, 0, sizeof(unsigned long long), stream));
+    if (a.n > 0) {
+        const unsigned grid = (unsigned)std::min<long long>(16384, (a.n * 4 + 255) / 256);
+        if (a.frag) hipLaunchKernelGGL(f16_screen_kernel<true>, dim3(grid), dim3(256), 0, stream, a);
+        else hipLaunchKernelGGL(f16_screen_kernel<false>, dim3(grid), dim3(256), 0, stream, a);
+        VSC_HIP(hipGetLastError());
+    }
+    return VSC_OK;
+}
+
+// n_dev: the list's length lives on the device (the fp16 screen's survivors; n = an upper bound for the grid)
+__global__ __launch_bounds__(256) void rescore_dense_kernel(RescoreArgs a, const uint32_t* __restrict__ sj,
+                                                            const uint32_t* __restrict__ si, long long n,
+                                                            const unsigned long long* __restrict__ n_dev) {
+    if (*a.overflow) return;
+    if (n_dev) n = (long long)*n_dev;
     __shared__ WaveHits wave_hits[4];
     WaveHits& buf = wave_hits[threadIdx.x >> 6];
     int pend = 0;
@@ -651,7 +741,7 @@ __global__ __launch_bounds__(256) void rescore_dense_kernel(RescoreArgs a, const
     rescore_list(a, radius, reinterpret_cast<const int32_t*>(si), reinterpret_cast<const int32_t*>(sj), n,
                  (long long)blockIdx.x * 256 + threadIdx.x, (long long)gridDim.x * 256, buf, pend);
     flush_hits(a, buf, pend);
-    if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(a.n_cand_total, (unsigned long long)n);
+    if (blockIdx.x == 0 && threadIdx.x == 0 && !n_dev) atomicAdd(a.n_cand_total, (unsigned long long)n);
 }
 
 int launch_cand_compact(const RescoreArgs& a, int n_chunks_max, uint32_t* key_j, uint32_t* val_i, unsigned long long* n_out,
@@ -662,10 +752,11 @@ int launch_cand_compact(const RescoreArgs& a, int n_chunks_max, uint32_t* key_j,
     return VSC_OK;
 }
 
-int launch_rescore_dense(const RescoreArgs& a, const uint32_t* sj, const uint32_t* si, long long n, hipStream_t stream) {
+int launch_rescore_dense(const RescoreArgs& a, const uint32_t* sj, const uint32_t* si, long long n, hipStream_t stream,
+                         const unsigned long long* n_dev) {
     if (n > 0) {
         const unsigned grid = (unsigned)std::min<long long>(16384, (n * 4 + 255) / 256);
-        hipLaunchKernelGGL(rescore_dense_kernel, dim3(grid), dim3(256), 0, stream, a, sj, si, n);
+        hipLaunchKernelGGL(rescore_dense_kernel, dim3(grid), dim3(256), 0, stream, a, sj, si, n, n_dev);
     }
     hipLaunchKernelGGL(tail_reset_kernel, dim3(1), dim3(1), 0, stream, a.tail_count);
     VSC_HIP(hipGetLastError());
