@@ -215,6 +215,15 @@ int vsc_aux_profile_read(int cls, double* ms, int64_t* calls, double* bytes, int
  * the exact stage, and (reserved) hits. */
 int vsc_index_search_stats(vsc_index_t* idx, int64_t* candidates, int64_t* hits);
 
+/* ------------------------------------------------- frame inference
+ * Epilogue of one convolution of the SSCD trunk with its BatchNorm folded in (what
+ * vsc/baseline/inference_impl.py:210-239 runs through TorchScript as conv -> bn -> (+ identity) -> relu):
+ * y[r, c] = act(y[r, c] + bias[c] (+ res[r, c])), bf16 device arrays [rows, cols] (NHWC activations, cols =
+ * channels, a multiple of 8), fp32 bias, fp32 arithmetic with one rounding; res may be NULL; relu != 0 applies
+ * max(., 0).  In place on y, on the HIP stream `hip_stream` (NULL = the default stream).  Device pointers only. */
+int vsc_bias_act_bf16(void* y, const void* res, const float* bias, int64_t rows, int64_t cols, int relu,
+                      void* hip_stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -224,8 +224,40 @@ def test_batchnorm_folding_keeps_the_function():
 
 
 @pytest.mark.gpu
-def test_fast_inference_configuration_against_fp32_eager(gpu):
-    """Accuracy gate of the configuration that profiles/r0*_config3_inference.md TIMES -- bf16 autocast, frames of
+def test_bias_act_epilogue_kernel_is_one_exact_rounding(gpu):
+    """`vsc_bias_act_bf16` (csrc/eltwise.hip): y = act(y + bias (+ res)) on bf16 matrices, fp32 arithmetic in the order
+    (y + bias) + res, one round-to-nearest-even: bit-identical to the same expression in torch, NaN / inf kept."""
+    from vsc2022_amd.vsc.baseline.inference import _bias_act
+
+    dev = torch.device("cuda", 0)
+    g = torch.Generator(device=dev)
+    g.manual_seed(3)
+    for rows, cols in ((1, 8), (37, 64), (4099, 256), (100000, 72)):
+        y = (torch.randn((rows, cols), generator=g, device=dev) * 3).to(torch.bfloat16)
+        r = (torch.randn((rows, cols), generator=g, device=dev) * 3).to(torch.bfloat16)
+        b = torch.randn(cols, generator=g, device=dev)
+        if rows > 30:
+            y[5, 3], y[6, 1], y[7, 2], r[8, 0] = float("nan"), float("inf"), float("-inf"), float("nan")
+            y[9, 4], b[5] = 3.0e38, 3.0e38                                          # overflows to +inf in bf16
+        for res in (None, r):
+            for relu in (False, True):
+                want = y.float() + b
+                if res is not None:
+                    want = want + res.float()
+                if relu:
+                    want = torch.relu(want)
+                want = want.to(torch.bfloat16)
+                got = _bias_act(y.clone(), b, res, relu)
+                assert torch.equal(got.view(torch.int16), want.view(torch.int16)), (rows, cols, res is not None, relu)
+    with pytest.raises(ValueError):
+        _bias_act(torch.zeros((4, 12), device=dev, dtype=torch.bfloat16), torch.zeros(12, device=dev), None, True)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("config", ["fast_sscd", "autocast_folded"])
+def test_fast_inference_configuration_against_fp32_eager(gpu, config):
+    """Accuracy gate of the configurations that profiles/r0*_config3_inference.md TIME -- `FastSSCD` (round 3: trunk in
+    bf16, 1x1 convolutions as GEMMs, fused epilogues) and round 2's bf16 autocast over the folded network; frames of
     consecutive videos packed into batches of 256, channels-last, BatchNorms folded into the convolutions -- against
     what the reference runs (vsc/baseline/inference_impl.py:210-239: fp32, eager, one video per batch), on 256
     synthetic videos x 25 frames of structured content (low-frequency patterns: iid noise frames would all map to
@@ -233,8 +265,8 @@ def test_fast_inference_configuration_against_fp32_eager(gpu):
     the fp32 descriptors of ALL frames is the frame itself (identical top-1 retrieval), searched on the engine."""
     from dataclasses import dataclass
 
-    from vsc2022_amd.vsc.baseline.inference import SyntheticVideos, build_sscd_model, fold_batchnorm, run_inference, \
-        run_inference_packed, to_flat
+    from vsc2022_amd.vsc.baseline.inference import FastSSCD, SyntheticVideos, build_sscd_model, fold_batchnorm, \
+        run_inference, run_inference_packed, to_flat
     from vsc2022_amd.vsc.index import FlatIndex
 
     @dataclass
@@ -271,8 +303,11 @@ def test_fast_inference_configuration_against_fp32_eager(gpu):
             model(preprocess(src.video(1000 + v, 25, dev)))
     model.eval()
     slow, off, ids = to_flat(run_inference(model, src, dev, batch_size=32, autocast_dtype=None))
-    fast, off2, ids2 = to_flat(run_inference_packed(fold_batchnorm(model), src, dev, batch_size=256,
-                                                    autocast_dtype=torch.bfloat16))
+    if config == "fast_sscd":
+        fast, off2, ids2 = to_flat(run_inference_packed(FastSSCD(model).to(dev), src, dev, batch_size=256))
+    else:
+        fast, off2, ids2 = to_flat(run_inference_packed(fold_batchnorm(model), src, dev, batch_size=256,
+                                                        autocast_dtype=torch.bfloat16))
     assert ids == ids2 and np.array_equal(off, off2) and slow.shape == fast.shape == (256 * 25, 512)
     assert torch.isfinite(slow).all() and torch.isfinite(fast).all()
     cos = torch.nn.functional.cosine_similarity(slow, fast, dim=1)

@@ -20,6 +20,7 @@ What differs, deliberately:
 from dataclasses import dataclass
 from typing import Iterator, List, Optional, Tuple
 
+import os
 import numpy as np
 import torch
 import torch.nn as nn
@@ -108,6 +109,110 @@ def fold_batchnorm(model: "SSCDModel") -> "SSCDModel":
     for p in m.parameters():
         p.requires_grad_(False)
     return m
+
+
+def _bias_act(y2d: torch.Tensor, bias: torch.Tensor, res2d: Optional[torch.Tensor], relu: bool) -> torch.Tensor:
+    """In place y = act(y + bias (+ res)) on [rows, channels] bf16 device matrices: `vsc_bias_act_bf16`
+    (csrc/eltwise.hip), on torch's current stream."""
+    from vsc2022_amd import _lib
+
+    assert y2d.is_cuda and y2d.dtype == torch.bfloat16 and y2d.is_contiguous() and bias.dtype == torch.float32
+    assert res2d is None or (res2d.dtype == torch.bfloat16 and res2d.is_contiguous() and res2d.shape == y2d.shape)
+    _lib.check(_lib.lib().vsc_bias_act_bf16(y2d.data_ptr(), 0 if res2d is None else res2d.data_ptr(), bias.data_ptr(),
+                                            y2d.shape[0], y2d.shape[1], 1 if relu else 0,
+                                            torch.cuda.current_stream(y2d.device).cuda_stream))
+    return y2d
+
+
+def _rows(x: torch.Tensor) -> torch.Tensor:
+    """[N, C, H, W] in channels-last memory -> the [N*H*W, C] matrix over the same bytes."""
+    n, c, h, w = x.shape
+    return x.permute(0, 2, 3, 1).reshape(n * h * w, c)
+
+
+# conv1's bias + ReLU inside hipBLASLt's epilogue (`torch._addmm_activation`, bf16 bias): +4 % on the forward pass.
+# VSC_FAST_GEMM_EPILOGUE=0: a plain GEMM followed by `vsc_bias_act_bf16` like the other convolutions (fp32 bias).
+# Measured and dropped: `aten::miopen_convolution_relu` for conv2 (falls onto a path 200x slower here); `addmm` with the
+# identity as its C matrix (torch copies C into the output first: a whole extra pass).
+_GEMM_EPILOGUE = os.environ.get("VSC_FAST_GEMM_EPILOGUE", "1") != "0"
+
+
+class FastBottleneck(nn.Module):
+    """One bottleneck of the folded trunk, bf16 activations in NHWC memory, for inference on the GPU:
+    the 1x1 convolutions are plain GEMMs over the [N*H*W, C] view (hipBLASLt through torch; MIOpen's 1x1 kernels
+    run them 1.3x slower), and what follows a convolution -- bias, identity, ReLU -- is ONE in-place pass of
+    `vsc_bias_act_bf16` (csrc/eltwise.hip) instead of stock PyTorch's separate bias / add / relu passes: at batch 256
+    the trunk is bound by the HBM traffic of its activations, not by its matrix products (profiles/r03_config3_inference.md)."""
+
+    def __init__(self, blk: "Bottleneck"):
+        super().__init__()
+        bf = torch.bfloat16
+
+        def gemm_w(conv):  # [Cout, Cin] -> [Cin, Cout] bf16, bias fp32
+            w = conv.weight.detach().reshape(conv.out_channels, conv.in_channels)
+            return nn.Parameter(w.t().contiguous().to(bf), requires_grad=False), \
+                nn.Parameter(conv.bias.detach().float().clone(), requires_grad=False)
+
+        self.w1, self.b1 = gemm_w(blk.conv1)
+        self.w3, self.b3 = gemm_w(blk.conv3)
+        c2 = blk.conv2
+        self.stride = c2.stride[0]
+        self.w2 = nn.Parameter(c2.weight.detach().to(bf).contiguous(memory_format=torch.channels_last), requires_grad=False)
+        self.b2 = nn.Parameter(c2.bias.detach().float().clone(), requires_grad=False)
+        self.b1h = nn.Parameter(self.b1.detach().to(bf), requires_grad=False)
+        self.has_down = blk.down is not None
+        if self.has_down:
+            self.down_stride = blk.down[0].stride[0]
+            self.wd, self.bd = gemm_w(blk.down[0])
+
+    def forward(self, x):
+        n, _, h, w = x.shape
+        x2 = _rows(x)
+        if self.has_down:
+            xs = x if self.down_stride == 1 else x[:, :, :: self.down_stride, :: self.down_stride].contiguous(
+                memory_format=torch.channels_last)
+            idt = _bias_act(torch.mm(_rows(xs), self.wd), self.bd, None, False)
+        else:
+            idt = x2
+        if _GEMM_EPILOGUE:
+            y = torch._addmm_activation(self.b1h, x2, self.w1)                            # conv1 + bias + relu (GEMM epilogue)
+        else:
+            y = _bias_act(torch.mm(x2, self.w1), self.b1, None, True)                     # conv1, + bias + relu
+        y = y.view(n, h, w, -1).permute(0, 3, 1, 2)
+        y = F.conv2d(y, self.w2, None, self.stride, 1)                                    # conv2 (3x3, MIOpen)
+        n2, _, h2, w2 = y.shape
+        y = _bias_act(_rows(y), self.b2, None, True)                                      # + bias + relu
+        out = _bias_act(torch.mm(y, self.w3), self.b3, idt, True)                         # conv3, + bias + identity + relu
+        return out.view(n2, h2, w2, -1).permute(0, 3, 1, 2)
+
+
+class FastSSCD(nn.Module):
+    """`SSCDModel` prepared for inference on the GPU: BatchNorms folded, stem and trunk in bf16 (NHWC), blocks as
+    `FastBottleneck`; GeM and the embedding stay in fp32.  Takes the fp32 frames `preprocess` returns.  The accuracy
+    gate against the fp32 eager network is tests/test_inference.py::test_fast_inference_configuration_against_fp32_eager."""
+
+    def __init__(self, model: "SSCDModel"):
+        super().__init__()
+        m = fold_batchnorm(model)
+        self.stem_conv = m.stem[0].to(torch.bfloat16).to(memory_format=torch.channels_last)
+        self.stem_bias = nn.Parameter(self.stem_conv.bias.detach().float().clone(), requires_grad=False)
+        self.stem_conv.bias = None
+        self.pool = m.stem[3]
+        self.blocks = nn.ModuleList(FastBottleneck(b) for b in m.trunk)
+        self.gem_p = m.gem_p
+        self.embed = m.embed
+        for p in self.parameters():
+            p.requires_grad_(False)
+
+    def forward(self, x):
+        x = self.stem_conv(x.to(torch.bfloat16).contiguous(memory_format=torch.channels_last))
+        n, _, h, w = x.shape
+        x = _bias_act(_rows(x), self.stem_bias, None, True).view(n, h, w, -1).permute(0, 3, 1, 2)
+        x = self.pool(x)
+        for b in self.blocks:
+            x = b(x)
+        x = x.float().clamp(min=1e-6).pow(self.gem_p).mean(dim=(2, 3)).pow(1.0 / self.gem_p)
+        return self.embed(x)
 
 
 def build_sscd_model(dims: int = 512, seed: int = 0, device="cpu", channels_last: bool = True) -> SSCDModel:
