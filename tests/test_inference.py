@@ -203,6 +203,99 @@ def test_inference_cli_on_the_gpu(gpu, tmp_path):
     assert np.allclose(direct, vfs[1].feature, rtol=1e-3, atol=1e-4)
 
 
+def _torchvision_like(model):
+    """The SSCD torchvision export's layout (adapt_sscd_model.py:64-70: backbone / pool / project, torchvision's
+    Bottleneck with `downsample`), holding `model`'s weights: other names, same parameter order."""
+    import collections
+
+    import torch.nn as nn
+
+    class TVBottleneck(nn.Module):
+        def __init__(self, b):
+            super().__init__()
+            self.conv1, self.bn1, self.conv2, self.bn2, self.conv3, self.bn3 = b.conv1, b.bn1, b.conv2, b.bn2, b.conv3, b.bn3
+            self.relu = nn.ReLU()
+            self.downsample = b.down
+
+        def forward(self, x):
+            idt = x if self.downsample is None else self.downsample(x)
+            out = self.relu(self.bn1(self.conv1(x)))
+            out = self.relu(self.bn2(self.conv2(out)))
+            return self.relu(self.bn3(self.conv3(out)) + idt)
+
+    class GeM(nn.Module):
+        def forward(self, x):
+            return x.clamp(min=1e-6).pow(3.0).mean(dim=(2, 3)).pow(1.0 / 3.0)
+
+    blocks = [TVBottleneck(b) for b in model.trunk]
+    backbone = nn.Sequential(collections.OrderedDict(
+        conv1=model.stem[0], bn1=model.stem[1], relu=nn.ReLU(), maxpool=model.stem[3],
+        layer1=nn.Sequential(*blocks[:3]), layer2=nn.Sequential(*blocks[3:7]), layer3=nn.Sequential(*blocks[7:13]),
+        layer4=nn.Sequential(*blocks[13:])))
+    return nn.Sequential(collections.OrderedDict(backbone=backbone, pool=GeM(), project=model.embed)).eval()
+
+
+def test_sscd_weights_are_recovered_from_a_torchscript_export(tmp_path):
+    """`sscd_from_module`: a traced torchvision-style export (other parameter names) -> SSCDModel with the same function;
+    a different architecture -> None."""
+    from vsc2022_amd.vsc.baseline.inference import build_sscd_model, sscd_from_module
+
+    model = build_sscd_model(dims=64, seed=5, device="cpu", channels_last=False)
+    g = torch.Generator().manual_seed(1)
+    for mod in model.modules():
+        if isinstance(mod, torch.nn.BatchNorm2d):
+            mod.running_mean.copy_(torch.randn(mod.running_mean.shape, generator=g) * 0.1)
+            mod.running_var.copy_(torch.rand(mod.running_var.shape, generator=g) + 0.5)
+    tv = _torchvision_like(model)
+    assert list(tv.state_dict())[0] == "backbone.conv1.weight" and "backbone.layer2.0.downsample.1.running_var" in tv.state_dict()
+    path = str(tmp_path / "tv.torchscript.pt")
+    torch.jit.trace(tv, torch.zeros(2, 3, 64, 64)).save(path)
+    loaded = torch.jit.load(path)
+    back = sscd_from_module(loaded)
+    assert back is not None
+    x = torch.randn((3, 3, 96, 96), generator=g)
+    with torch.no_grad():
+        assert torch.allclose(back(x), loaded(x), rtol=1e-4, atol=1e-5) and torch.allclose(back(x), model(x), rtol=1e-4, atol=1e-5)
+    assert sscd_from_module(torch.jit.script(_TinyNet())) is None
+    # same shapes, another function (a BatchNorm's statistics swapped): refused by the check on a random batch
+    tv.backbone.bn1.running_var.mul_(4.0)
+    wrong = sscd_from_module(tv)
+    with torch.no_grad():
+        assert wrong is None or torch.allclose(wrong(x), tv(x), rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.gpu
+def test_inference_cli_fast_flag_on_the_gpu(gpu, tmp_path):
+    """`--fast` (extension): the CLI converts the TorchScript export back into SSCDModel and runs FastSSCD; descriptors
+    within cosine 0.999 of the plain CLI run on every frame; a non-ResNet model is refused."""
+    from vsc2022_amd.vsc.baseline import inference_cli as cli
+    from vsc2022_amd.vsc.baseline.inference import build_sscd_model
+    from vsc2022_amd.vsc.storage import load_features
+
+    data = tmp_path / "videos"
+    data.mkdir()
+    _make_dataset(data, n=4)
+    model = build_sscd_model(device="cuda", channels_last=False)
+    for blk in model.trunk:
+        blk.bn3.weight.fill_(0.25)
+    path = str(tmp_path / "tv.torchscript.pt")
+    torch.jit.trace(_torchvision_like(model), torch.zeros(2, 3, 320, 320, device="cuda")).save(path)
+    base = ["--torchscript_path", path, "--accelerator", "cuda", "--dataset_path", str(data), "--video_extensions", "npy",
+            "--video_reader", "NPY"]
+    cli.main(cli.build_parser().parse_args(base + ["--output_file", str(tmp_path / "slow.npz")]))
+    cli.main(cli.build_parser().parse_args(base + ["--fast", "--output_file", str(tmp_path / "fast.npz")]))
+    slow, fast = load_features(str(tmp_path / "slow.npz")), load_features(str(tmp_path / "fast.npz"))
+    assert [v.video_id for v in slow] == [v.video_id for v in fast]
+    for a, b in zip(slow, fast):
+        assert np.array_equal(a.timestamps, b.timestamps) and a.feature.shape == b.feature.shape
+        cos = (a.feature * b.feature).sum(1) / np.linalg.norm(a.feature, axis=1) / np.linalg.norm(b.feature, axis=1)
+        assert cos.min() >= 0.999, cos.min()
+    tiny = str(tmp_path / "tiny.torchscript.pt")
+    torch.jit.script(_TinyNet()).save(tiny)
+    with pytest.raises(Exception, match="--fast"):
+        cli.main(cli.build_parser().parse_args(["--torchscript_path", tiny, "--fast"] + base[2:] + ["--output_file", str(tmp_path / "x.npz")]))
+
+
 def test_batchnorm_folding_keeps_the_function():
     from vsc2022_amd.vsc.baseline.inference import build_sscd_model, fold_batchnorm
 

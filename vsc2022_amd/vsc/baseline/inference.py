@@ -215,6 +215,43 @@ class FastSSCD(nn.Module):
         return self.embed(x)
 
 
+def sscd_from_module(module, check_tol: float = 1e-3) -> Optional["SSCDModel"]:
+    """An `SSCDModel` holding the weights of `module` -- a TorchScript (or eager) ResNet-50 trunk + GeM + Linear such as
+    the torchvision SSCD models after `adapt_sscd_model.py:54-77` removed the L2 norm -- or None when it is not that
+    architecture.  Parameter NAMES differ between exports (backbone.layer1.0.downsample.0.weight, ...); their ORDER and
+    shapes are those of a ResNet-50 (conv1, bn1, per bottleneck conv1 bn1 conv2 bn2 conv3 bn3 [downsample conv bn],
+    projection), so the tensors are matched by position and shape and the result is verified: both networks must agree
+    on a random batch (squared distance of the descriptors <= check_tol, the reference's own criterion in
+    adapt_sscd_model.py:45-51) or None is returned.  This is what lets `FastSSCD` run real SSCD weights."""
+    try:
+        src = [(k, v) for k, v in module.state_dict().items() if not k.endswith("num_batches_tracked")]
+    except Exception:
+        return None
+    if not src or src[-1][1].dim() != 1 or src[-2][1].dim() != 2:
+        return None
+    dims = int(src[-2][1].shape[0])
+    model = SSCDModel(dims).eval()
+    dst = [(k, v) for k, v in model.state_dict().items() if not k.endswith("num_batches_tracked")]
+    if len(src) != len(dst) or any(a[1].shape != b[1].shape for a, b in zip(src, dst)):
+        return None
+    with torch.no_grad():
+        for (_, a), (_, b) in zip(src, dst):
+            b.copy_(a.detach().to(device=b.device, dtype=b.dtype))
+        dev = src[0][1].device
+        model = model.to(dev)
+        g = torch.Generator().manual_seed(0)
+        x = torch.randn((2, 3, 64, 64), generator=g).to(dev)
+        try:
+            d = (module(x).float() - model(x).float()).pow(2).sum(dim=1)
+        except Exception:
+            return None
+    if not bool(torch.isfinite(d).all()) or float(d.max()) > check_tol:
+        return None
+    for p in model.parameters():
+        p.requires_grad_(False)
+    return model
+
+
 def build_sscd_model(dims: int = 512, seed: int = 0, device="cpu", channels_last: bool = True) -> SSCDModel:
     torch.manual_seed(seed)
     model = SSCDModel(dims).eval().to(device)

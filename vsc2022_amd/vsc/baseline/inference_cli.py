@@ -214,7 +214,19 @@ def load_model(args, device):
     else:
         logger.warning("no --torchscript_path: RANDOM-INIT network of the SSCD architecture (benchmarks only)")
         model = build_sscd_model(device=device, channels_last=False)
-    return model.eval().to(device)
+    model = model.eval().to(device)
+    if getattr(args, "fast", False):
+        # (not a reference flag) the same weights through FastSSCD: bf16 NHWC trunk, GEMM 1x1, fused epilogues
+        from vsc2022_amd.vsc.baseline.inference import FastSSCD, SSCDModel, sscd_from_module
+
+        if device.type != "cuda":
+            raise Exception("--fast needs --accelerator cuda")
+        eager = model if isinstance(model, SSCDModel) else sscd_from_module(model)
+        if eager is None:
+            raise Exception("--fast: the model is not a ResNet-50 trunk + GeM + Linear (or does not reproduce on a "
+                            "random batch after conversion); run without --fast")
+        model = FastSSCD(eager).to(device).eval()
+    return model
 
 
 def worker_process(args, rank: int, world_size: int, output_filename: str):
@@ -248,6 +260,8 @@ def build_parser() -> argparse.ArgumentParser:
     g.add_argument("--output_file", required=True)
     g.add_argument("--scratch_path", required=False)
     g.add_argument("--store_fp16", action="store_true")
+    g.add_argument("--fast", action="store_true",
+                   help="(extension) run a ResNet-50 SSCD model through FastSSCD: bf16 trunk, fused kernels; cuda only")
     d = p.add_argument_group("Dataset")
     d.add_argument("--dataset_path", required=True)
     d.add_argument("--fps", default=1, type=float)
