@@ -223,6 +223,13 @@ int vsc_index_search_stats(vsc_index_t* idx, int64_t* candidates, int64_t* hits)
  * max(., 0).  In place on y, on the HIP stream `hip_stream` (NULL = the default stream).  Device pointers only. */
 int vsc_bias_act_bf16(void* y, const void* res, const float* bias, int64_t rows, int64_t cols, int relu,
                       void* hip_stream);
+/* A 1x1 convolution of that trunk with its epilogue in one kernel:
+ * out[m, n] = act(sum_k a[m, k] * w[n, k] + bias[n] (+ res[m, n])); a [M, K] = NHWC activations (M = batch * H * W),
+ * w [N, K] = the convolution's weight as stored (Cout x Cin), res / out [M, N]: bf16 device arrays, bias fp32;
+ * fp32 accumulation on the matrix cores, one rounding.  N and K multiples of 64; res may be NULL; out must not
+ * alias a.  Same stream convention. */
+int vsc_gemm_bias_act_bf16(const void* a, const void* w, const float* bias, const void* res, void* out,
+                           int64_t M, int64_t N, int64_t K, int relu, void* hip_stream);
 
 #ifdef __cplusplus
 }

@@ -347,6 +347,44 @@ def test_bias_act_epilogue_kernel_is_one_exact_rounding(gpu):
 
 
 @pytest.mark.gpu
+def test_fused_1x1_convolution_kernel_against_fp64(gpu):
+    """`vsc_gemm_bias_act_bf16` (csrc/gemm_epi.hip): act(a @ w.T + bias (+ res)) with bf16 operands, fp32 accumulation and
+    one rounding: every output within one bf16 rounding (2^-8 relative, + the fp32 accumulation's noise) of the same
+    expression in fp64, for row counts that end inside a 64-row tile, every wave arrangement (N = 64, 128, 256, 512),
+    with / without identity and ReLU; invalid shapes are refused."""
+    from vsc2022_amd.vsc.baseline.inference import _gemm_bias_act
+
+    dev = torch.device("cuda", 0)
+    g = torch.Generator(device=dev)
+    g.manual_seed(9)
+    for M, K, N in ((1, 64, 64), (63, 64, 128), (64, 128, 256), (65, 64, 512), (1000, 128, 64), (4133, 192, 256), (70001, 64, 256)):
+        a = (torch.randn((M, K), generator=g, device=dev)).to(torch.bfloat16)
+        w = (torch.randn((N, K), generator=g, device=dev) / K ** 0.5).to(torch.bfloat16)
+        bias = torch.randn(N, generator=g, device=dev)
+        res = torch.randn((M, N), generator=g, device=dev).to(torch.bfloat16)
+        for r in (None, res):
+            for relu in (False, True):
+                got = _gemm_bias_act(a, w, bias, r, relu).double()
+                want = a.double() @ w.double().t() + bias.double()
+                if r is not None:
+                    want = want + r.double()
+                if relu:
+                    want = want.relu()
+                tol = want.abs() * 2.0 ** -8 + 1e-4 * (K ** 0.5)
+                bad = (got - want).abs() > tol
+                assert not bool(bad.any()), (M, K, N, r is not None, relu, int(bad.sum()))
+    # the accumulation is exact where it can be: small integers
+    a = torch.randint(-4, 5, (200, 64), generator=g, device=dev).to(torch.bfloat16)
+    w = torch.randint(-4, 5, (64, 64), generator=g, device=dev).to(torch.bfloat16)
+    zero = torch.zeros(64, device=dev)
+    assert torch.equal(_gemm_bias_act(a, w, zero, None, False).float(), (a.float() @ w.float().t()).to(torch.bfloat16).float())
+    for M, K, N in ((10, 32, 64), (10, 64, 96)):
+        with pytest.raises(ValueError):
+            _gemm_bias_act(torch.zeros((M, K), device=dev, dtype=torch.bfloat16), torch.zeros((N, K), device=dev, dtype=torch.bfloat16),
+                           torch.zeros(N, device=dev), None, True)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("config", ["fast_sscd", "autocast_folded"])
 def test_fast_inference_configuration_against_fp32_eager(gpu, config):
     """Accuracy gate of the configurations that profiles/r0*_config3_inference.md TIME -- `FastSSCD` (round 3: trunk in

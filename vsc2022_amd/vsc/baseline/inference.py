@@ -124,6 +124,22 @@ def _bias_act(y2d: torch.Tensor, bias: torch.Tensor, res2d: Optional[torch.Tenso
     return y2d
 
 
+def _gemm_bias_act(a2d: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, res2d: Optional[torch.Tensor], relu: bool):
+    """act(a2d @ w.T + bias (+ res)) as one kernel: `vsc_gemm_bias_act_bf16` (csrc/gemm_epi.hip); a2d [M, K], w [N, K],
+    res2d [M, N] bf16 on the device, bias fp32."""
+    from vsc2022_amd import _lib
+
+    assert a2d.is_cuda and a2d.dtype == w.dtype == torch.bfloat16 and a2d.is_contiguous() and w.is_contiguous()
+    assert bias.dtype == torch.float32 and a2d.shape[1] == w.shape[1] and bias.shape[0] == w.shape[0]
+    assert res2d is None or (res2d.dtype == torch.bfloat16 and res2d.is_contiguous() and tuple(res2d.shape) == (a2d.shape[0], w.shape[0]))
+    out = torch.empty((a2d.shape[0], w.shape[0]), dtype=torch.bfloat16, device=a2d.device)
+    _lib.check(_lib.lib().vsc_gemm_bias_act_bf16(a2d.data_ptr(), w.data_ptr(), bias.data_ptr(),
+                                                 0 if res2d is None else res2d.data_ptr(), out.data_ptr(), a2d.shape[0],
+                                                 w.shape[0], a2d.shape[1], 1 if relu else 0,
+                                                 torch.cuda.current_stream(a2d.device).cuda_stream))
+    return out
+
+
 def _rows(x: torch.Tensor) -> torch.Tensor:
     """[N, C, H, W] in channels-last memory -> the [N*H*W, C] matrix over the same bytes."""
     n, c, h, w = x.shape
@@ -135,35 +151,54 @@ def _rows(x: torch.Tensor) -> torch.Tensor:
 # Measured and dropped: `aten::miopen_convolution_relu` for conv2 (falls onto a path 200x slower here); `addmm` with the
 # identity as its C matrix (torch copies C into the output first: a whole extra pass).
 _GEMM_EPILOGUE = os.environ.get("VSC_FAST_GEMM_EPILOGUE", "1") != "0"
+# largest Cin for which a 1x1 convolution runs as `vsc_gemm_bias_act_bf16` (0: never); see _Conv1x1
+_FUSED_GEMM_MAX_K = int(os.environ.get("VSC_FAST_FUSED_GEMM_MAX_K", "128"))
+
+
+class _Conv1x1(nn.Module):
+    """A folded 1x1 convolution on the [N*H*W, Cin] view, with what follows it (bias, identity, ReLU).
+    Cin <= 128 (layer1, layer2's last convolutions: ~1 GB of activations per call, hardly any arithmetic): ONE kernel,
+    `vsc_gemm_bias_act_bf16` (csrc/gemm_epi.hip) -- 0.50 instead of 0.78 ms for layer1's conv3 at batch 256.  Larger
+    Cin: hipBLASLt through torch (a plain library GEMM; it reuses its operands through LDS, the kernel above does not
+    and loses from Cin = 256 on) followed by one pass of `vsc_bias_act_bf16`, or, when there is no identity, with bias +
+    ReLU in hipBLASLt's own epilogue (`torch._addmm_activation`)."""
+
+    def __init__(self, conv: nn.Conv2d):
+        super().__init__()
+        bf = torch.bfloat16
+        w = conv.weight.detach().reshape(conv.out_channels, conv.in_channels)
+        self.fused = conv.in_channels <= _FUSED_GEMM_MAX_K and conv.in_channels % 64 == 0 and conv.out_channels % 64 == 0
+        self.w = nn.Parameter((w if self.fused else w.t()).contiguous().to(bf), requires_grad=False)  # [Cout, Cin] / [Cin, Cout]
+        self.bias = nn.Parameter(conv.bias.detach().float().clone(), requires_grad=False)
+        self.bias_h = nn.Parameter(self.bias.detach().to(bf), requires_grad=False)
+
+    def forward(self, x2d, res2d, relu: bool):
+        if self.fused:
+            return _gemm_bias_act(x2d, self.w, self.bias, res2d, relu)
+        if res2d is None and relu and _GEMM_EPILOGUE:
+            return torch._addmm_activation(self.bias_h, x2d, self.w)
+        return _bias_act(torch.mm(x2d, self.w), self.bias, res2d, relu)
 
 
 class FastBottleneck(nn.Module):
     """One bottleneck of the folded trunk, bf16 activations in NHWC memory, for inference on the GPU:
-    the 1x1 convolutions are plain GEMMs over the [N*H*W, C] view (hipBLASLt through torch; MIOpen's 1x1 kernels
-    run them 1.3x slower), and what follows a convolution -- bias, identity, ReLU -- is ONE in-place pass of
+    the 1x1 convolutions are GEMMs over the [N*H*W, C] view (`_Conv1x1`; MIOpen's 1x1 kernels run them 1.3x slower),
+    and what follows a convolution -- bias, identity, ReLU -- is the epilogue of that GEMM or ONE in-place pass of
     `vsc_bias_act_bf16` (csrc/eltwise.hip) instead of stock PyTorch's separate bias / add / relu passes: at batch 256
     the trunk is bound by the HBM traffic of its activations, not by its matrix products (profiles/r03_config3_inference.md)."""
 
     def __init__(self, blk: "Bottleneck"):
         super().__init__()
-        bf = torch.bfloat16
-
-        def gemm_w(conv):  # [Cout, Cin] -> [Cin, Cout] bf16, bias fp32
-            w = conv.weight.detach().reshape(conv.out_channels, conv.in_channels)
-            return nn.Parameter(w.t().contiguous().to(bf), requires_grad=False), \
-                nn.Parameter(conv.bias.detach().float().clone(), requires_grad=False)
-
-        self.w1, self.b1 = gemm_w(blk.conv1)
-        self.w3, self.b3 = gemm_w(blk.conv3)
+        self.c1, self.c3 = _Conv1x1(blk.conv1), _Conv1x1(blk.conv3)
         c2 = blk.conv2
         self.stride = c2.stride[0]
-        self.w2 = nn.Parameter(c2.weight.detach().to(bf).contiguous(memory_format=torch.channels_last), requires_grad=False)
+        self.w2 = nn.Parameter(c2.weight.detach().to(torch.bfloat16).contiguous(memory_format=torch.channels_last),
+                               requires_grad=False)
         self.b2 = nn.Parameter(c2.bias.detach().float().clone(), requires_grad=False)
-        self.b1h = nn.Parameter(self.b1.detach().to(bf), requires_grad=False)
         self.has_down = blk.down is not None
         if self.has_down:
             self.down_stride = blk.down[0].stride[0]
-            self.wd, self.bd = gemm_w(blk.down[0])
+            self.cd = _Conv1x1(blk.down[0])
 
     def forward(self, x):
         n, _, h, w = x.shape
@@ -171,18 +206,15 @@ class FastBottleneck(nn.Module):
         if self.has_down:
             xs = x if self.down_stride == 1 else x[:, :, :: self.down_stride, :: self.down_stride].contiguous(
                 memory_format=torch.channels_last)
-            idt = _bias_act(torch.mm(_rows(xs), self.wd), self.bd, None, False)
+            idt = self.cd(_rows(xs), None, False)
         else:
             idt = x2
-        if _GEMM_EPILOGUE:
-            y = torch._addmm_activation(self.b1h, x2, self.w1)                            # conv1 + bias + relu (GEMM epilogue)
-        else:
-            y = _bias_act(torch.mm(x2, self.w1), self.b1, None, True)                     # conv1, + bias + relu
+        y = self.c1(x2, None, True)                                                       # conv1 + bias + relu
         y = y.view(n, h, w, -1).permute(0, 3, 1, 2)
         y = F.conv2d(y, self.w2, None, self.stride, 1)                                    # conv2 (3x3, MIOpen)
         n2, _, h2, w2 = y.shape
         y = _bias_act(_rows(y), self.b2, None, True)                                      # + bias + relu
-        out = _bias_act(torch.mm(y, self.w3), self.b3, idt, True)                         # conv3, + bias + identity + relu
+        out = self.c3(y, idt, True)                                                       # conv3 + bias + identity + relu
         return out.view(n2, h2, w2, -1).permute(0, 3, 1, 2)
 
 
