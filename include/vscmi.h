@@ -223,6 +223,10 @@ int vsc_index_search_stats(vsc_index_t* idx, int64_t* candidates, int64_t* hits)
  * max(., 0).  In place on y, on the HIP stream `hip_stream` (NULL = the default stream).  Device pointers only. */
 int vsc_bias_act_bf16(void* y, const void* res, const float* bias, int64_t rows, int64_t cols, int relu,
                       void* hip_stream);
+/* The stem's tail in one pass: out = maxpool3x3(stride 2, padding 1)(relu(x + bias)); x [N, H, W, C], out
+ * [N, (H-1)/2+1, (W-1)/2+1, C] bf16 NHWC device arrays, C a multiple of 8; bit-identical to the two separate passes. */
+int vsc_pool3x3s2_bias_relu_bf16(const void* x, const float* bias, void* out, int64_t N, int64_t H, int64_t W,
+                                 int64_t C, void* hip_stream);
 /* A 1x1 convolution of that trunk with its epilogue in one kernel:
  * out[m, n] = act(sum_k a[m, k] * w[n, k] + bias[n] (+ res[m, n])); a [M, K] = NHWC activations (M = batch * H * W),
  * w [N, K] = the convolution's weight as stored (Cout x Cin), res / out [M, N]: bf16 device arrays, bias fp32;

@@ -347,6 +347,29 @@ def test_bias_act_epilogue_kernel_is_one_exact_rounding(gpu):
 
 
 @pytest.mark.gpu
+def test_fused_stem_pool_kernel_is_bit_identical_to_the_separate_passes(gpu):
+    """`vsc_pool3x3s2_bias_relu_bf16` == nn.MaxPool2d(3, 2, 1)(relu(x + bias) rounded to bf16), bit for bit, odd and even
+    sizes, NaN propagated."""
+    from vsc2022_amd.vsc.baseline.inference import _pool_bias_relu
+
+    dev = torch.device("cuda", 0)
+    g = torch.Generator(device=dev)
+    g.manual_seed(4)
+    pool = torch.nn.MaxPool2d(3, stride=2, padding=1)
+    for n, c, h, w in ((1, 8, 1, 1), (2, 64, 7, 9), (3, 16, 10, 6), (4, 64, 160, 160)):
+        x = (torch.randn((n, c, h, w), generator=g, device=dev) * 2).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+        if h > 5:
+            x[0, 3, 2, 3] = float("nan")
+            x[1, 1, 0, 0] = float("inf")
+        b = torch.randn(c, generator=g, device=dev)
+        want = pool(torch.relu(x.float() + b.view(1, -1, 1, 1)).to(torch.bfloat16))
+        got = _pool_bias_relu(x, b)
+        assert got.shape == want.shape
+        assert torch.equal(torch.isnan(got), torch.isnan(want))
+        assert torch.equal(torch.nan_to_num(got.float(), nan=7.0), torch.nan_to_num(want.float(), nan=7.0)), (n, c, h, w)
+
+
+@pytest.mark.gpu
 def test_fused_1x1_convolution_kernel_against_fp64(gpu):
     """`vsc_gemm_bias_act_bf16` (csrc/gemm_epi.hip): act(a @ w.T + bias (+ res)) with bf16 operands, fp32 accumulation and
     one rounding: every output within one bf16 rounding (2^-8 relative, + the fp32 accumulation's noise) of the same

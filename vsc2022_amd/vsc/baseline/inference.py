@@ -140,6 +140,20 @@ def _gemm_bias_act(a2d: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, res2d
     return out
 
 
+def _pool_bias_relu(x: torch.Tensor, bias: torch.Tensor) -> torch.Tensor:
+    """maxpool3x3/2(relu(x + bias)) of an NHWC bf16 tensor in one pass: `vsc_pool3x3s2_bias_relu_bf16` (csrc/eltwise.hip)."""
+    from vsc2022_amd import _lib
+
+    n, c, h, w = x.shape
+    xl = x.permute(0, 2, 3, 1)
+    assert x.is_cuda and x.dtype == torch.bfloat16 and xl.is_contiguous() and bias.dtype == torch.float32
+    ho, wo = (h - 1) // 2 + 1, (w - 1) // 2 + 1
+    out = torch.empty((n, ho, wo, c), dtype=torch.bfloat16, device=x.device)
+    _lib.check(_lib.lib().vsc_pool3x3s2_bias_relu_bf16(xl.data_ptr(), bias.data_ptr(), out.data_ptr(), n, h, w, c,
+                                                       torch.cuda.current_stream(x.device).cuda_stream))
+    return out.permute(0, 3, 1, 2)
+
+
 def _rows(x: torch.Tensor) -> torch.Tensor:
     """[N, C, H, W] in channels-last memory -> the [N*H*W, C] matrix over the same bytes."""
     n, c, h, w = x.shape
@@ -151,6 +165,7 @@ def _rows(x: torch.Tensor) -> torch.Tensor:
 # Measured and dropped: `aten::miopen_convolution_relu` for conv2 (falls onto a path 200x slower here); `addmm` with the
 # identity as its C matrix (torch copies C into the output first: a whole extra pass).
 _GEMM_EPILOGUE = os.environ.get("VSC_FAST_GEMM_EPILOGUE", "1") != "0"
+_FUSED_POOL = os.environ.get("VSC_FAST_FUSED_POOL", "1") != "0"  # the stem's bias + ReLU + max-pool as one kernel
 # largest Cin for which a 1x1 convolution runs as `vsc_gemm_bias_act_bf16` (0: never); see _Conv1x1
 _FUSED_GEMM_MAX_K = int(os.environ.get("VSC_FAST_FUSED_GEMM_MAX_K", "128"))
 
@@ -238,9 +253,12 @@ class FastSSCD(nn.Module):
 
     def forward(self, x):
         x = self.stem_conv(x.to(torch.bfloat16).contiguous(memory_format=torch.channels_last))
-        n, _, h, w = x.shape
-        x = _bias_act(_rows(x), self.stem_bias, None, True).view(n, h, w, -1).permute(0, 3, 1, 2)
-        x = self.pool(x)
+        if _FUSED_POOL and x.permute(0, 2, 3, 1).is_contiguous():
+            x = _pool_bias_relu(x, self.stem_bias)                                        # bias + relu + max-pool, one pass
+        else:
+            n, _, h, w = x.shape
+            x = _bias_act(_rows(x), self.stem_bias, None, True).view(n, h, w, -1).permute(0, 3, 1, 2)
+            x = self.pool(x)
         for b in self.blocks:
             x = b(x)
         x = x.float().clamp(min=1e-6).pow(self.gem_p).mean(dim=(2, 3)).pow(1.0 / self.gem_p)
