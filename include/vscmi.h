@@ -223,6 +223,13 @@ int vsc_index_search_stats(vsc_index_t* idx, int64_t* candidates, int64_t* hits)
  * max(., 0).  In place on y, on the HIP stream `hip_stream` (NULL = the default stream).  Device pointers only. */
 int vsc_bias_act_bf16(void* y, const void* res, const float* bias, int64_t rows, int64_t cols, int relu,
                       void* hip_stream);
+/* A 3x3 (padding 1, stride 1 or 2; taps = 9) or 1x1 (taps = 1, stride 1) convolution of that trunk as an implicit GEMM
+ * on the matrix cores with the epilogue inside: out[b, ho, wo, n] = act(sum x[b, hi, wi, c] * w[n, tap, c] + bias[n]
+ * (+ res[b, ho, wo, n])); x [B, H, W, C] NHWC, w [N, taps, C] (= the channels-last memory of the PyTorch weight
+ * [N, C, kh, kw]), res / out [B, Ho, Wo, N] with Ho = (H - 1) / stride + 1: bf16 device arrays; bias fp32; C and N
+ * multiples of 64.  fp32 accumulation, one rounding.  Same stream convention. */
+int vsc_conv_bias_act_bf16(const void* x, const void* w, const float* bias, const void* res, void* out, int64_t B,
+                           int64_t H, int64_t W, int64_t C, int64_t N, int taps, int stride, int relu, void* hip_stream);
 /* The stem's tail in one pass: out = maxpool3x3(stride 2, padding 1)(relu(x + bias)); x [N, H, W, C], out
  * [N, (H-1)/2+1, (W-1)/2+1, C] bf16 NHWC device arrays, C a multiple of 8; bit-identical to the two separate passes. */
 int vsc_pool3x3s2_bias_relu_bf16(const void* x, const float* bias, void* out, int64_t N, int64_t H, int64_t W,

@@ -370,6 +370,55 @@ def test_fused_stem_pool_kernel_is_bit_identical_to_the_separate_passes(gpu):
 
 
 @pytest.mark.gpu
+def test_implicit_gemm_convolution_kernel_against_fp64(gpu):
+    """`vsc_conv_bias_act_bf16` (csrc/conv_gemm.hip): 3x3 / padding 1 / stride 1 and 2 and 1x1 convolutions with bias,
+    identity and ReLU inside, against the same expression in fp64 on the same bf16 values: within one bf16 rounding;
+    image sizes that are odd, smaller than the kernel, pixel counts that end inside a 64-pixel tile, both channel-block
+    widths (Cout = 64 / 128k), taps that fall outside the image on every side; invalid arguments are refused."""
+    import torch.nn.functional as F
+
+    from vsc2022_amd.vsc.baseline.inference import _conv1x1_rows, _conv_bias_act
+
+    dev = torch.device("cuda", 0)
+    g = torch.Generator(device=dev)
+    g.manual_seed(12)
+
+    def cl(t):
+        return t.contiguous(memory_format=torch.channels_last)
+
+    cases = [(2, 64, 5, 7, 64, 3, 1), (3, 128, 9, 6, 128, 3, 2), (1, 64, 1, 1, 64, 3, 1), (1, 64, 2, 2, 128, 3, 2), (5, 192, 17, 13, 64, 3, 2),
+             (2, 64, 40, 40, 256, 3, 1), (7, 128, 21, 20, 192, 3, 1), (2, 64, 12, 12, 256, 1, 1), (2, 256, 8, 8, 512, 1, 1)]
+    for b, c, h, w, n, k, stride in cases:
+        x = cl(torch.randn((b, c, h, w), generator=g, device=dev).to(torch.bfloat16))
+        wt = cl((torch.randn((n, c, k, k), generator=g, device=dev) / (k * k * c) ** 0.5).to(torch.bfloat16))
+        bias = torch.randn(n, generator=g, device=dev)
+        base = F.conv2d(x.double(), wt.double(), bias.double(), stride, k // 2)
+        res = cl(torch.randn(base.shape, generator=g, device=dev).to(torch.bfloat16))
+        for r in (None, res):
+            for relu in (False, True):
+                want = base if r is None else base + r.double()
+                want = want.relu() if relu else want
+                got = _conv_bias_act(x, wt, bias, r, stride, relu)
+                assert tuple(got.shape) == tuple(want.shape) and got.permute(0, 2, 3, 1).is_contiguous()
+                bad = (got.double() - want).abs() > want.abs() * 2.0 ** -8 + 1e-4 * (k * k * c) ** 0.5
+                assert not bool(bad.any()), (b, c, h, w, n, k, stride, r is not None, relu, int(bad.sum()))
+    # the [M, K] view used for the 1x1 convolutions of the trunk
+    a = torch.randn((70001, 256), generator=g, device=dev).to(torch.bfloat16)
+    w2 = (torch.randn((512, 256), generator=g, device=dev) / 16).to(torch.bfloat16)
+    bias = torch.randn(512, generator=g, device=dev)
+    r2 = torch.randn((70001, 512), generator=g, device=dev).to(torch.bfloat16)
+    got = _conv1x1_rows(a, w2, bias, r2, True).double()
+    want = (a.double() @ w2.double().t() + bias.double() + r2.double()).relu()
+    assert not bool(((got - want).abs() > want.abs() * 2.0 ** -8 + 2e-3).any())
+    with pytest.raises(ValueError):
+        _conv_bias_act(cl(torch.zeros((1, 32, 4, 4), device=dev, dtype=torch.bfloat16)), cl(torch.zeros((64, 32, 3, 3), device=dev, dtype=torch.bfloat16)),
+                       torch.zeros(64, device=dev), None, 1, True)
+    with pytest.raises(ValueError):
+        _conv_bias_act(cl(torch.zeros((1, 64, 4, 4), device=dev, dtype=torch.bfloat16)), cl(torch.zeros((64, 64, 3, 3), device=dev, dtype=torch.bfloat16)),
+                       torch.zeros(64, device=dev), None, 3, True)
+
+
+@pytest.mark.gpu
 def test_fused_1x1_convolution_kernel_against_fp64(gpu):
     """`vsc_gemm_bias_act_bf16` (csrc/gemm_epi.hip): act(a @ w.T + bias (+ res)) with bf16 operands, fp32 accumulation and
     one rounding: every output within one bf16 rounding (2^-8 relative, + the fp32 accumulation's noise) of the same

@@ -39,7 +39,7 @@ EXPORTS = (
     "vsc_index_range_search", "vsc_index_global_topk", "vsc_index_candidates", "vsc_pair_max", "vsc_row_normalize",
     "vsc_tn_create", "vsc_tn_set_queries", "vsc_tn_destroy", "vsc_tn_localize", "vsc_tn_forward_sim", "vsc_tn_similarity",
     "vsc_index_profile", "vsc_index_profile_read", "vsc_index_profile_read_class", "vsc_index_search_stats",
-    "vsc_aux_profile", "vsc_aux_profile_read", "vsc_bias_act_bf16", "vsc_gemm_bias_act_bf16", "vsc_pool3x3s2_bias_relu_bf16",
+    "vsc_aux_profile", "vsc_aux_profile_read", "vsc_bias_act_bf16", "vsc_gemm_bias_act_bf16", "vsc_pool3x3s2_bias_relu_bf16", "vsc_conv_bias_act_bf16",
 )
 
 
@@ -156,6 +156,7 @@ def lib():
         L.vsc_bias_act_bf16.argtypes = [vp, vp, vp, i64, i64, i32, vp]
         L.vsc_gemm_bias_act_bf16.argtypes = [vp, vp, vp, vp, vp, i64, i64, i64, i32, vp]
         L.vsc_pool3x3s2_bias_relu_bf16.argtypes = [vp, vp, vp, i64, i64, i64, i64, vp]
+        L.vsc_conv_bias_act_bf16.argtypes = [vp, vp, vp, vp, vp, i64, i64, i64, i64, i64, i32, i32, i32, vp]
         for name in EXPORTS:
             fn = getattr(L, name)
             if fn.restype is ctypes.c_int and name not in ("vsc_version", "vsc_device_count"):

@@ -140,6 +140,40 @@ def _gemm_bias_act(a2d: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, res2d
     return out
 
 
+def _conv_bias_act(x: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, res: Optional[torch.Tensor], stride: int, relu: bool):
+    """act(conv(x, w) + bias (+ res)) for a 3x3 / padding 1 (or 1x1) convolution as one kernel: `vsc_conv_bias_act_bf16`
+    (csrc/conv_gemm.hip).  x [B, C, H, W] and w [N, C, kh, kw] bf16 in channels-last memory, res / result [B, N, Ho, Wo]
+    likewise; bias fp32."""
+    from vsc2022_amd import _lib
+
+    b, c, h, wd = x.shape
+    n, _, kh, kw = w.shape
+    assert x.is_cuda and x.dtype == w.dtype == torch.bfloat16 and bias.dtype == torch.float32 and (kh, kw) in ((1, 1), (3, 3))
+    assert x.permute(0, 2, 3, 1).is_contiguous() and w.permute(0, 2, 3, 1).is_contiguous()
+    ho, wo = (h - 1) // stride + 1, (wd - 1) // stride + 1
+    out = torch.empty((b, ho, wo, n), dtype=torch.bfloat16, device=x.device)
+    if res is not None:
+        assert res.dtype == torch.bfloat16 and tuple(res.shape) == (b, n, ho, wo) and res.permute(0, 2, 3, 1).is_contiguous()
+    _lib.check(_lib.lib().vsc_conv_bias_act_bf16(x.data_ptr(), w.data_ptr(), bias.data_ptr(), 0 if res is None else res.data_ptr(),
+                                                 out.data_ptr(), b, h, wd, c, n, kh * kw, stride, 1 if relu else 0,
+                                                 torch.cuda.current_stream(x.device).cuda_stream))
+    return out.permute(0, 3, 1, 2)
+
+
+def _conv1x1_rows(a2d: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, res2d: Optional[torch.Tensor], relu: bool):
+    """The same kernel for a 1x1 convolution on the [M, K] view (M "images" of one pixel): a2d [M, K], w [N, K], res2d [M, N]."""
+    from vsc2022_amd import _lib
+
+    assert a2d.is_cuda and a2d.dtype == w.dtype == torch.bfloat16 and a2d.is_contiguous() and w.is_contiguous()
+    assert bias.dtype == torch.float32 and a2d.shape[1] == w.shape[1]
+    assert res2d is None or (res2d.dtype == torch.bfloat16 and res2d.is_contiguous() and tuple(res2d.shape) == (a2d.shape[0], w.shape[0]))
+    out = torch.empty((a2d.shape[0], w.shape[0]), dtype=torch.bfloat16, device=a2d.device)
+    _lib.check(_lib.lib().vsc_conv_bias_act_bf16(a2d.data_ptr(), w.data_ptr(), bias.data_ptr(), 0 if res2d is None else res2d.data_ptr(),
+                                                 out.data_ptr(), a2d.shape[0], 1, 1, a2d.shape[1], w.shape[0], 1, 1, 1 if relu else 0,
+                                                 torch.cuda.current_stream(a2d.device).cuda_stream))
+    return out
+
+
 def _pool_bias_relu(x: torch.Tensor, bias: torch.Tensor) -> torch.Tensor:
     """maxpool3x3/2(relu(x + bias)) of an NHWC bf16 tensor in one pass: `vsc_pool3x3s2_bias_relu_bf16` (csrc/eltwise.hip)."""
     from vsc2022_amd import _lib
@@ -166,29 +200,46 @@ def _rows(x: torch.Tensor) -> torch.Tensor:
 # identity as its C matrix (torch copies C into the output first: a whole extra pass).
 _GEMM_EPILOGUE = os.environ.get("VSC_FAST_GEMM_EPILOGUE", "1") != "0"
 _FUSED_POOL = os.environ.get("VSC_FAST_FUSED_POOL", "1") != "0"  # the stem's bias + ReLU + max-pool as one kernel
+# the 3x3 convolutions and the 1x1 shapes of _CONV_KERNEL_1X1 through `vsc_conv_bias_act_bf16` (0: MIOpen / hipBLASLt + passes)
+_FUSED_CONV = os.environ.get("VSC_FAST_FUSED_CONV", "1") != "0"
 # largest Cin for which a 1x1 convolution runs as `vsc_gemm_bias_act_bf16` (0: never); see _Conv1x1
-_FUSED_GEMM_MAX_K = int(os.environ.get("VSC_FAST_FUSED_GEMM_MAX_K", "128"))
+_FUSED_GEMM_MAX_K = int(os.environ.get("VSC_FAST_FUSED_GEMM_MAX_K", "128"))  # (layer2's (128, 512) goes to the conv kernel)
+
+
+# 1x1 convolutions (Cin, Cout) that run faster through the implicit-GEMM kernel (`vsc_conv_bias_act_bf16`, taps = 1) than
+# through hipBLASLt + an epilogue pass, measured at batch 256 on 320 x 320 frames (profiles/r03_config3_inference.md: the
+# kernel keeps its epilogue inside but reaches 0.55-0.64 PFLOP/s, so the deep, arithmetic-heavy shapes stay with hipBLASLt)
+_CONV_KERNEL_1X1 = {(256, 64), (512, 128), (128, 512), (256, 512), (256, 1024), (512, 1024), (512, 2048)}
 
 
 class _Conv1x1(nn.Module):
-    """A folded 1x1 convolution on the [N*H*W, Cin] view, with what follows it (bias, identity, ReLU).
-    Cin <= 128 (layer1, layer2's last convolutions: ~1 GB of activations per call, hardly any arithmetic): ONE kernel,
-    `vsc_gemm_bias_act_bf16` (csrc/gemm_epi.hip) -- 0.50 instead of 0.78 ms for layer1's conv3 at batch 256.  Larger
-    Cin: hipBLASLt through torch (a plain library GEMM; it reuses its operands through LDS, the kernel above does not
-    and loses from Cin = 256 on) followed by one pass of `vsc_bias_act_bf16`, or, when there is no identity, with bias +
-    ReLU in hipBLASLt's own epilogue (`torch._addmm_activation`)."""
+    """A folded 1x1 convolution on the [N*H*W, Cin] view, with what follows it (bias, identity, ReLU).  Three routes:
+    `gemm`  Cin = 64 (layer1: ~1 GB of activations per call, hardly any arithmetic): `vsc_gemm_bias_act_bf16`
+            (csrc/gemm_epi.hip), operands straight from global memory, epilogue inside;
+    `conv`  the shapes of _CONV_KERNEL_1X1: `vsc_conv_bias_act_bf16` (csrc/conv_gemm.hip) with one tap, epilogue inside;
+    `blas`  the rest: hipBLASLt through torch (a plain library GEMM) followed by one pass of `vsc_bias_act_bf16`, or, when
+            there is no identity, with bias + ReLU in hipBLASLt's own epilogue (`torch._addmm_activation`)."""
 
     def __init__(self, conv: nn.Conv2d):
         super().__init__()
         bf = torch.bfloat16
-        w = conv.weight.detach().reshape(conv.out_channels, conv.in_channels)
-        self.fused = conv.in_channels <= _FUSED_GEMM_MAX_K and conv.in_channels % 64 == 0 and conv.out_channels % 64 == 0
-        self.w = nn.Parameter((w if self.fused else w.t()).contiguous().to(bf), requires_grad=False)  # [Cout, Cin] / [Cin, Cout]
+        k, n = conv.in_channels, conv.out_channels
+        w = conv.weight.detach().reshape(n, k)
+        ok = k % 64 == 0 and n % 64 == 0
+        if ok and _FUSED_CONV and (k, n) in _CONV_KERNEL_1X1:
+            self.route = "conv"
+        elif ok and k <= _FUSED_GEMM_MAX_K:
+            self.route = "gemm"
+        else:
+            self.route = "blas"
+        self.w = nn.Parameter((w.t() if self.route == "blas" else w).contiguous().to(bf), requires_grad=False)  # [Cin, Cout] / [Cout, Cin]
         self.bias = nn.Parameter(conv.bias.detach().float().clone(), requires_grad=False)
         self.bias_h = nn.Parameter(self.bias.detach().to(bf), requires_grad=False)
 
     def forward(self, x2d, res2d, relu: bool):
-        if self.fused:
+        if self.route == "conv":
+            return _conv1x1_rows(x2d, self.w, self.bias, res2d, relu)
+        if self.route == "gemm":
             return _gemm_bias_act(x2d, self.w, self.bias, res2d, relu)
         if res2d is None and relu and _GEMM_EPILOGUE:
             return torch._addmm_activation(self.bias_h, x2d, self.w)
@@ -226,9 +277,14 @@ class FastBottleneck(nn.Module):
             idt = x2
         y = self.c1(x2, None, True)                                                       # conv1 + bias + relu
         y = y.view(n, h, w, -1).permute(0, 3, 1, 2)
-        y = F.conv2d(y, self.w2, None, self.stride, 1)                                    # conv2 (3x3, MIOpen)
-        n2, _, h2, w2 = y.shape
-        y = _bias_act(_rows(y), self.b2, None, True)                                      # + bias + relu
+        if _FUSED_CONV and y.shape[1] % 64 == 0 and self.w2.shape[0] % 64 == 0:
+            y = _conv_bias_act(y, self.w2, self.b2, None, self.stride, True)              # conv2 (3x3) + bias + relu, one kernel
+            n2, _, h2, w2 = y.shape
+            y = _rows(y)
+        else:
+            y = F.conv2d(y, self.w2, None, self.stride, 1)                                # conv2 (3x3, MIOpen)
+            n2, _, h2, w2 = y.shape
+            y = _bias_act(_rows(y), self.b2, None, True)                                  # + bias + relu
         out = self.c3(y, idt, True)                                                       # conv3 + bias + identity + relu
         return out.view(n2, h2, w2, -1).permute(0, 3, 1, 2)
 
