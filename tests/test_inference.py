@@ -370,6 +370,30 @@ def test_fused_stem_pool_kernel_is_bit_identical_to_the_separate_passes(gpu):
 
 
 @pytest.mark.gpu
+def test_fast_sscd_on_other_frame_sizes(gpu):
+    """FastSSCD against the fp32 eager network on frame sizes other than 320 x 320 (the CLI's 224-square transform, odd
+    and non-square sizes whose feature maps end inside a 64-pixel tile, a single frame): cosine >= 0.999 per frame."""
+    from vsc2022_amd.vsc.baseline.inference import FastSSCD, build_sscd_model, preprocess
+
+    dev = torch.device("cuda", 0)
+    model = build_sscd_model(device=dev)
+    for blk in model.trunk:
+        blk.bn3.weight.fill_(0.25)
+    fast = FastSSCD(model).to(dev)
+    g = torch.Generator(device=dev)
+    g.manual_seed(21)
+    for b, h, w in ((3, 224, 224), (2, 250, 190), (1, 64, 64), (5, 97, 131), (1, 320, 320)):
+        base = torch.rand((b, 3, 5, 5), generator=g, device=dev)
+        frames = torch.nn.functional.interpolate(base, size=(h, w), mode="bilinear") + 0.05 * torch.rand((b, 3, h, w), generator=g, device=dev)
+        x = preprocess((frames.clamp(0, 1) * 255).to(torch.uint8))
+        with torch.no_grad():
+            want, got = model(x).float(), fast(x).float()
+        assert got.shape == want.shape == (b, 512) and torch.isfinite(got).all()
+        cos = torch.nn.functional.cosine_similarity(want, got, dim=1)
+        assert cos.min().item() >= 0.999, (b, h, w, cos.min().item())
+
+
+@pytest.mark.gpu
 def test_implicit_gemm_convolution_kernel_against_fp64(gpu):
     """`vsc_conv_bias_act_bf16` (csrc/conv_gemm.hip): 3x3 / padding 1 / stride 1 and 2 and 1x1 convolutions with bias,
     identity and ReLU inside, against the same expression in fp64 on the same bf16 values: within one bf16 rounding;
