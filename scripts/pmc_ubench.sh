@@ -13,7 +13,7 @@ for grp in "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_BUSY_CYCL
            "TCC_HIT_sum TCC_MISS_sum"; do
   i=$((i+1))
   d=/tmp/pmc_${tag}_$i; rm -rf $d
-  (cd /tmp && timeout 600 rocprofv3 --pmc $grp --kernel-trace -d $d -o r -- "$@" > $out/run_$i.log 2>&1)
+  bin=$(readlink -f "$1"); shift; set -- "$bin" "$@"; (cd /tmp && timeout 600 rocprofv3 --pmc $grp --kernel-trace -d $d -o r -- "$@" > $out/run_$i.log 2>&1)
   db=$(find $d -name "*.db" | head -1)
   echo "## $grp" >> $out/pmc.md
   if [ -n "$db" ]; then python $PWD/scripts/pmc_summary.py $db >> $out/pmc.md; else echo "(no db; see run_$i.log)" >> $out/pmc.md; tail -5 $out/run_$i.log >> $out/pmc.md; fi

@@ -1,0 +1,489 @@
+// Micro-benchmark of wave-tile / instruction variants for the int8 panel pre-filter (csrc/sim_i8p.hip), gfx950.
+// "prototype both in scripts/ubench first, ship the winner".  All variants keep the product's
+// data flow -- query panel resident in LDS (swizzled, conflict-free ds_read_b128), reference fragments streamed
+// straight into registers from a fragment-major image, (slice, panel) work items behind one atomic counter in
+// slice-major order, block-max epilogue with (rare) candidate emission -- and differ in
+//   MI     0: v_mfma_i32_32x32x32_i8   1: v_mfma_i32_16x16x64_i8
+//   PRW    panel rows (128: 64 KiB, 256: 128 KiB of LDS at 512-d)
+//   NWAVE  waves per workgroup (8 = two per SIMD, 4 = one per SIMD)
+//   RSPLIT wave groups along the panel rows (waves of different groups stream the SAME reference columns)
+//   WM, WN wave tile in 32-row / 32-column blocks
+// Operands are random bytes; only timing is read here (the results of variants whose fragment layout differs from
+// the image's are meaningless) -- exactness of the shipped variant is the product's test suite.
+//   hipcc -O3 --offload-arch=gfx950 -mllvm -pragma-unroll-threshold=200000 -o i8_tiles i8_tiles.hip && ./i8_tiles
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x16 __attribute__((ext_vector_type(16)));
+
+#define CK(x)                                                                             \
+    do {                                                                                  \
+        hipError_t e_ = (x);                                                              \
+        if (e_ != hipSuccess) {                                                           \
+            printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); \
+            exit(1);                                                                      \
+        }                                                                                 \
+    } while (0)
+
+__device__ inline uint32_t hash32(uint32_t x) {
+    x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+    return x;
+}
+// bytes ~ round(N(0, 40^2)) clipped to int8 (the toggling statistics of quantised descriptors)
+__global__ void gen_bytes(int8_t* x, int64_t n, uint32_t seed) {
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) {
+        uint32_t h = hash32((uint32_t)e * 2654435761u + seed);
+        float s = 0;
+        for (int t = 0; t < 4; ++t) { h = hash32(h + t); s += (h >> 8) * (1.0f / 16777216.0f); }
+        x[e] = (int8_t)fminf(127.f, fmaxf(-127.f, rintf((s - 2.0f) * 1.7320508f * 40.f)));
+    }
+}
+
+struct Args {
+    const char* Q;   // natural [rows][ROWB bytes]
+    const char* Rf;  // fragment-major image: 64-row tiles of NKS x 2 KiB
+    int nq, nr, npanel, nsteps, slice;
+    int thr;
+    int32_t* out_i; int32_t* out_j; int seg_cap; int* seg_count; int* next_item;
+};
+
+__device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rsrc, int voff, char* lds) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)lds, 16, voff, 0, 0, 0);
+}
+__device__ __forceinline__ i32x4 bload(__amdgpu_buffer_rsrc_t rs, int voff, int soff) {
+    return __builtin_bit_cast(i32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, 0));
+}
+__device__ __forceinline__ const char* uniform_ptr(const char* p) {
+    const uint64_t v = reinterpret_cast<uint64_t>(p);
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+    return reinterpret_cast<const char*>(((uint64_t)hi << 32) | lo);
+}
+
+constexpr int NKC = 2;  // 512-d int8 rows: 2 chunks of 256 B
+constexpr int NKS = NKC * 8, ROWB = NKC * 256, TILEB = NKS * 2048;
+
+// ------------------------------------------------------------------ MI = 0: 32x32x32
+template <int PRW, int NWAVE, int RSPLIT, int WM, int WN, int PF, int EPI = 0>
+__global__ __launch_bounds__(NWAVE * 64) void k32(Args a) {
+    static_assert(PRW == RSPLIT * WM * 32, "panel rows");
+    constexpr int NT = NWAVE * 64, CG = NWAVE / RSPLIT, CSW = CG * WN * 32, T64 = WN / 2;  // 64-row image tiles per wave tile
+    static_assert(WN % 2 == 0, "whole image tiles");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    __shared__ int item_sh[2];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int rgrp = wave / CG, cgrp = wave % CG;
+    const int lane16 = lane * 16;
+    int abase[8];
+    {
+        const int hi = lane >> 5, r15 = lane & 15, rl = lane & 31;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) abase[u] = (rgrp * WM * 32 + rl) * 256 + ((((2 * u) | hi) ^ r15) << 4);
+    }
+    const int seg = blockIdx.x * NWAVE + wave;
+    const int64_t seg_base = (int64_t)seg * a.seg_cap;
+    int count = 0;
+    const int nslice = (a.nsteps + a.slice - 1) / a.slice;
+    int cur_panel = -1;
+    for (;;) {
+        __syncthreads();
+        if (wave == 0) {
+            int t = 0;
+            if (lane == 0) t = atomicAdd(a.next_item, 1);
+            t = __shfl(t, 0);
+            int p = -1, s = 0;
+            if (t < nslice * a.npanel) { s = t / a.npanel; p = t - s * a.npanel; }
+            if (lane == 0) { item_sh[0] = p; item_sh[1] = s; }
+        }
+        __syncthreads();
+        const int panel = item_sh[0], sl = item_sh[1];
+        if (panel < 0) break;
+        const int cs0 = sl * a.slice, cs1 = min(a.nsteps, cs0 + a.slice);
+        if (panel != cur_panel) {
+            __syncthreads();
+            const __amdgpu_buffer_rsrc_t qrs = __builtin_amdgcn_make_buffer_rsrc(
+                (void*)uniform_ptr(a.Q + (int64_t)panel * PRW * ROWB), 0, PRW * ROWB, 0x00020000);
+            // LDS image [k chunk of 256 B][row][slot ^ (row & 15)]
+#pragma unroll
+            for (int n = 0; n < PRW * ROWB / 16 / NT; ++n) {
+                const int p = n * NT + tid;
+                const int kc = p / (PRW * 16), row = (p >> 4) % PRW, slot = p & 15;
+                const int c = kc * 16 + (slot ^ (row & 15));
+                dma16(qrs, row * ROWB + c * 16, smem + (n * NT + wave * 64) * 16);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            cur_panel = panel;
+        }
+        // the wave's stream: T64 image tiles per col-step; col-step cs, column group cgrp -> image tile (cs * CG + cgrp) * T64 + t
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+            (void*)uniform_ptr(a.Rf + (int64_t)cs0 * CG * T64 * TILEB), 0, (cs1 - cs0) * CG * T64 * TILEB, 0x00020000);
+        int so_tile = cgrp * T64 * TILEB;
+        i32x4 ring[PF][WN];
+#pragma unroll
+        for (int dd = 0; dd < PF - 1; ++dd)
+#pragma unroll
+            for (int n = 0; n < WN; ++n) ring[dd][n] = bload(rs, lane16 + (n & 1) * 1024, so_tile + (n >> 1) * TILEB + dd * 2048);
+        i32x4 afr[WM];
+#pragma unroll
+        for (int m = 0; m < WM; ++m) afr[m] = *reinterpret_cast<const i32x4*>(smem + abase[0] + m * 8192);
+        i32x16 acc[WM][WN] = {};
+        for (int cs = cs0; cs < cs1; ++cs) {
+            const int col0 = cs * CSW + cgrp * WN * 32;
+            const i32x16 zero = {};
+            const int so_next = so_tile + CG * T64 * TILEB;
+#pragma unroll
+            for (int ks = 0; ks < NKS; ++ks) {
+                const int t = ks + PF - 1;
+                const int so = (t < NKS) ? so_tile + t * 2048 : so_next + (t - NKS) * 2048;
+                const int kn = (ks + 1) % NKS;
+                const char* anext = smem + (kn >> 3) * (PRW * 256) + abase[kn & 7];
+#pragma unroll
+                for (int m = 0; m < WM; ++m) {
+#pragma unroll
+                    for (int n = 0; n < WN; ++n)
+                        acc[m][n] = __builtin_amdgcn_mfma_i32_32x32x32_i8(afr[m], ring[ks % PF][n], (ks == 0 && !EPI) ? zero : acc[m][n], 0, 0, 0);
+                    afr[m] = *reinterpret_cast<const i32x4*>(anext + m * 8192);
+                    if (m < WN) ring[(ks + PF - 1) % PF][m] = bload(rs, lane16 + (m & 1) * 1024, so + (m >> 1) * TILEB);
+                }
+#pragma unroll
+                for (int m = 0; m < WM; ++m) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, WN, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                    if (m < WN) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                }
+            }
+            so_tile = so_next;
+            if (EPI && cs + 1 < cs1) continue;
+            int bm[WM][WN];
+            int any = 0x80000000;
+#pragma unroll
+            for (int m = 0; m < WM; ++m)
+#pragma unroll
+                for (int n = 0; n < WN; ++n) {
+                    int x = max(max(acc[m][n][0], acc[m][n][1]), acc[m][n][2]);
+#pragma unroll
+                    for (int r = 3; r < 15; r += 2) x = max(max(x, acc[m][n][r]), acc[m][n][r + 1]);
+                    bm[m][n] = max(x, acc[m][n][15]);
+                    any = max(any, bm[m][n]);
+                }
+            if (__any(any > a.thr)) {
+                const int row_base = panel * PRW + rgrp * WM * 32 + 4 * (lane >> 5);
+#pragma unroll
+                for (int m = 0; m < WM; ++m)
+#pragma unroll
+                    for (int n = 0; n < WN; ++n) {
+                        if (!__any(bm[m][n] > a.thr)) continue;
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const bool c = acc[m][n][r] > a.thr;
+                            const unsigned long long ok = __ballot(c);
+                            if (ok == 0ull) continue;
+                            const int total = __popcll(ok);
+                            if (count + total <= a.seg_cap) {
+                                if (c) {
+                                    const int64_t pos = seg_base + count + __popcll(ok & ((1ull << lane) - 1));
+                                    a.out_i[pos] = row_base + m * 32 + (r & 3) + 8 * (r >> 2);
+                                    a.out_j[pos] = col0 + n * 32 + (lane & 31);
+                                }
+                                count += total;
+                            }
+                        }
+                    }
+            }
+        }
+    }
+    if (lane == 0) a.seg_count[seg] = count;
+}
+
+// ------------------------------------------------------------------ MI = 1: 16x16x64 (WM, WN still in units of 32)
+template <int PRW, int NWAVE, int RSPLIT, int WM, int WN, int PF, int EPI = 0, int STUB = 0>
+__global__ __launch_bounds__(NWAVE * 64) void k16(Args a) {
+    static_assert(PRW == RSPLIT * WM * 32, "panel rows");
+    constexpr int NT = NWAVE * 64, CG = NWAVE / RSPLIT, CSW = CG * WN * 32, T64 = WN / 2;
+    constexpr int MB = WM * 2, CB = WN * 2, NK4 = NKS / 2;  // 16-row / 16-col blocks, 64-k steps
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    __shared__ int item_sh[2];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int rgrp = wave / CG, cgrp = wave % CG;
+    const int lane16 = lane * 16;
+    // A operand of block mb at 64-k step k4: row = mb * 16 + (lane & 15), 16-byte piece 4 (k4 & 3) + (lane >> 4) of chunk k4 >> 2
+    int abase[4];
+    {
+        const int kp = lane >> 4, r15 = lane & 15;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) abase[u] = (rgrp * WM * 32 + r15) * 256 + ((((4 * u) | kp) ^ r15) << 4);
+    }
+    const int seg = blockIdx.x * NWAVE + wave;
+    const int64_t seg_base = (int64_t)seg * a.seg_cap;
+    int count = 0;
+    const int nslice = (a.nsteps + a.slice - 1) / a.slice;
+    int cur_panel = -1;
+    for (;;) {
+        __syncthreads();
+        if (wave == 0) {
+            int t = 0;
+            if (lane == 0) t = atomicAdd(a.next_item, 1);
+            t = __shfl(t, 0);
+            int p = -1, s = 0;
+            if (t < nslice * a.npanel) { s = t / a.npanel; p = t - s * a.npanel; }
+            if (lane == 0) { item_sh[0] = p; item_sh[1] = s; }
+        }
+        __syncthreads();
+        const int panel = item_sh[0], sl = item_sh[1];
+        if (panel < 0) break;
+        const int cs0 = sl * a.slice, cs1 = min(a.nsteps, cs0 + a.slice);
+        if (panel != cur_panel) {
+            __syncthreads();
+            const __amdgpu_buffer_rsrc_t qrs = __builtin_amdgcn_make_buffer_rsrc(
+                (void*)uniform_ptr(a.Q + (int64_t)panel * PRW * ROWB), 0, PRW * ROWB, 0x00020000);
+#pragma unroll
+            for (int n = 0; n < PRW * ROWB / 16 / NT; ++n) {
+                const int p = n * NT + tid;
+                const int kc = p / (PRW * 16), row = (p >> 4) % PRW, slot = p & 15;
+                const int c = kc * 16 + (slot ^ (row & 15));
+                dma16(qrs, row * ROWB + c * 16, smem + (n * NT + wave * 64) * 16);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            cur_panel = panel;
+        }
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+            (void*)uniform_ptr(a.Rf + (int64_t)cs0 * CG * T64 * TILEB), 0, (cs1 - cs0) * CG * T64 * TILEB, 0x00020000);
+        int so_tile = cgrp * T64 * TILEB;
+        // a 64-k step of a 64-column image tile = 4 KiB = the B operands of its 4 column blocks
+        i32x4 ring[PF][CB];
+#pragma unroll
+        for (int dd = 0; dd < PF - 1; ++dd)
+#pragma unroll
+            for (int n = 0; n < CB; ++n) ring[dd][n] = bload(rs, lane16 + (n & 3) * 1024, so_tile + (n >> 2) * TILEB + dd * 4096);
+        i32x4 afr[MB];
+#pragma unroll
+        for (int m = 0; m < MB; ++m) afr[m] = *reinterpret_cast<const i32x4*>(smem + abase[0] + m * 4096);
+        i32x4 acc[MB][CB] = {};
+        for (int cs = cs0; cs < cs1; ++cs) {
+            const int col0 = cs * CSW + cgrp * WN * 32;
+            const i32x4 zero = {};
+            const int so_next = so_tile + CG * T64 * TILEB;
+#pragma unroll
+            for (int k4 = 0; k4 < NK4; ++k4) {
+                const int t = k4 + PF - 1;
+                const int so = (t < NK4) ? so_tile + t * 4096 : so_next + (t - NK4) * 4096;
+                const int kn = (k4 + 1) % NK4;
+                const char* anext = smem + (kn >> 2) * (PRW * 256) + abase[kn & 3];
+#pragma unroll
+                for (int m = 0; m < MB; ++m) {
+#pragma unroll
+                    for (int n = 0; n < CB; ++n)
+                        acc[m][n] = __builtin_amdgcn_mfma_i32_16x16x64_i8(afr[m], ring[k4 % PF][n], (k4 == 0 && !EPI) ? zero : acc[m][n], 0, 0, 0);
+                    if (!(STUB & 2)) afr[m] = *reinterpret_cast<const i32x4*>(anext + m * 4096);
+                    if (m < CB && !(STUB & 1)) ring[(k4 + PF - 1) % PF][m] = bload(rs, lane16 + (m & 3) * 1024, so + (m >> 2) * TILEB);
+                    if (m < CB && (STUB & 1)) ring[(k4 + PF - 1) % PF][m] = ring[k4 % PF][m];
+                }
+#pragma unroll
+                for (int m = 0; m < MB; ++m) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, CB, 0);
+                    if (!(STUB & 2)) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                    if (m < CB && !(STUB & 1)) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                }
+            }
+            so_tile = so_next;
+            if (EPI && cs + 1 < cs1) continue;
+            // per column block: one max over the wave tile's rows (the radius threshold is per column)
+            int cm[CB];
+            int any = 0x80000000;
+#pragma unroll
+            for (int n = 0; n < CB; ++n) {
+                int x = 0x80000000;
+#pragma unroll
+                for (int m = 0; m < MB; ++m) {
+                    x = max(max(x, acc[m][n][0]), acc[m][n][1]);
+                    x = max(max(x, acc[m][n][2]), acc[m][n][3]);
+                }
+                cm[n] = x;
+                any = max(any, x);
+            }
+            if (__any(any > a.thr)) {
+                const int row_base = panel * PRW + rgrp * WM * 32 + 4 * (lane >> 4);
+#pragma unroll
+                for (int n = 0; n < CB; ++n) {
+                    if (!__any(cm[n] > a.thr)) continue;
+#pragma unroll
+                    for (int m = 0; m < MB; ++m)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const bool c = acc[m][n][r] > a.thr;
+                            const unsigned long long ok = __ballot(c);
+                            if (ok == 0ull) continue;
+                            const int total = __popcll(ok);
+                            if (count + total <= a.seg_cap) {
+                                if (c) {
+                                    const int64_t pos = seg_base + count + __popcll(ok & ((1ull << lane) - 1));
+                                    a.out_i[pos] = row_base + m * 16 + r;
+                                    a.out_j[pos] = col0 + n * 16 + (lane & 15);
+                                }
+                                count += total;
+                            }
+                        }
+                }
+            }
+        }
+    }
+    if (lane == 0) a.seg_count[seg] = count;
+}
+
+template <typename K>
+void run(const char* name, K kern, Args a, int prw, int nwave, int csw, int slice_cols, int reps) {
+    const int lds = prw * ROWB;
+    CK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    a.npanel = (a.nq + prw - 1) / prw;
+    a.nsteps = (a.nr + csw - 1) / csw;
+    a.slice = slice_cols / csw;
+    const int grid = 256;
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0));
+    CK(hipEventCreate(&e1));
+    for (int w = 0; w < 2; ++w) {
+        CK(hipMemsetAsync(a.next_item, 0, 4, 0));
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(nwave * 64), lds, 0, a);
+    }
+    CK(hipDeviceSynchronize());
+    CK(hipGetLastError());
+    CK(hipEventRecord(e0));
+    for (int r = 0; r < reps; ++r) {
+        CK(hipMemsetAsync(a.next_item, 0, 4, 0));
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(nwave * 64), lds, 0, a);
+    }
+    CK(hipEventRecord(e1));
+    CK(hipEventSynchronize(e1));
+    float ms;
+    CK(hipEventElapsedTime(&ms, e0, e1));
+    ms /= reps;
+    std::vector<int> sc(grid * nwave);
+    CK(hipMemcpy(sc.data(), a.seg_count, grid * nwave * 4, hipMemcpyDeviceToHost));
+    long long tot = 0;
+    for (int v : sc) tot += v;
+    printf("%-58s thr=%-7d %7.2f ms %7.1f TOP/s  cand %lld (%.3g)\n", name, a.thr, ms, 2.0 * a.nq * (double)a.nr * 512 / ms / 1e9, tot,
+           (double)tot / ((double)a.nq * a.nr));
+    fflush(stdout);
+}
+
+template <int MODE>
+__global__ __launch_bounds__(512) void mfma_only(const i32x4* src, int* out, int iters) {
+    const int tid = threadIdx.x;
+    i32x4 a[4], b[2];
+    for (int m = 0; m < 4; ++m) a[m] = src[(blockIdx.x * 6 + m) * 512 + tid];
+    for (int n = 0; n < 2; ++n) b[n] = src[(blockIdx.x * 6 + 4 + n) * 512 + tid];
+    int s = 0;
+    if (MODE == 1) {
+        i32x16 acc[4][2] = {};
+        for (int it = 0; it < iters; ++it)
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int m = 0; m < 4; ++m)
+#pragma unroll
+                    for (int n = 0; n < 2; ++n) acc[m][n] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[m], b[n], acc[m][n], 0, 0, 0);
+        for (int m = 0; m < 4; ++m) for (int n = 0; n < 2; ++n) for (int r = 0; r < 16; ++r) s += acc[m][n][r];
+    } else {
+        i32x4 acc[4][2] = {};
+        for (int it = 0; it < iters; ++it)
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int m = 0; m < 4; ++m)
+#pragma unroll
+                    for (int n = 0; n < 2; ++n) acc[m][n] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[m], b[n], acc[m][n], 0, 0, 0);
+        for (int m = 0; m < 4; ++m) for (int n = 0; n < 2; ++n) for (int r = 0; r < 4; ++r) s += acc[m][n][r];
+    }
+    out[blockIdx.x * 512 + tid] = s;
+}
+
+int main(int argc, char** argv) {
+    const int nq = argc > 1 ? atoi(argv[1]) : 32768;
+    const int nr = argc > 2 ? atoi(argv[2]) : 1000000;
+    const int64_t nr_pad = ((int64_t)nr + 1023) / 1024 * 1024 + 4096;
+    const int nq_pad = (nq + 255) / 256 * 256;
+    char *Q, *Rf;
+    CK(hipMalloc(&Q, (size_t)nq_pad * ROWB));
+    CK(hipMalloc(&Rf, (size_t)nr_pad * ROWB + (1 << 20)));
+    hipLaunchKernelGGL(gen_bytes, dim3(4096), dim3(256), 0, 0, (int8_t*)Q, (int64_t)nq_pad * ROWB, 1u);
+    hipLaunchKernelGGL(gen_bytes, dim3(4096), dim3(256), 0, 0, (int8_t*)Rf, nr_pad * ROWB, 77u);
+    CK(hipDeviceSynchronize());
+    {
+        int* out;
+        CK(hipMalloc(&out, 256 * 512 * 4));
+        hipEvent_t e0, e1;
+        CK(hipEventCreate(&e0));
+        CK(hipEventCreate(&e1));
+        for (int rep = 0; rep < 2; ++rep)
+            for (int mode = 1; mode < 3; ++mode) {
+                const int iters = 60000;
+                CK(hipEventRecord(e0));
+                if (mode == 1) hipLaunchKernelGGL(mfma_only<1>, dim3(256), dim3(512), 0, 0, (const i32x4*)Rf, out, iters);
+                if (mode == 2) hipLaunchKernelGGL(mfma_only<2>, dim3(256), dim3(512), 0, 0, (const i32x4*)Rf, out, iters);
+                CK(hipEventRecord(e1));
+                CK(hipEventSynchronize(e1));
+                float ms;
+                CK(hipEventElapsedTime(&ms, e0, e1));
+                const double per = mode == 1 ? 2.0 * 32 * 32 * 32 : 2.0 * 16 * 16 * 64;
+                printf("mfma-only %-18s rep %d: %.1f ms  %.1f TOP/s\n", mode == 1 ? "i32_32x32x32_i8" : "i32_16x16x64_i8", rep, ms,
+                       256.0 * 8 * iters * 32.0 * per / ms / 1e9);
+            }
+        fflush(stdout);
+    }
+    Args a;
+    a.Q = Q; a.Rf = Rf; a.nq = nq; a.nr = nr;
+    a.seg_cap = 1 << 15;
+    CK(hipMalloc(&a.out_i, (size_t)256 * 8 * a.seg_cap * 4));
+    CK(hipMalloc(&a.out_j, (size_t)256 * 8 * a.seg_cap * 4));
+    CK(hipMalloc(&a.seg_count, 256 * 8 * 4));
+    CK(hipMalloc(&a.next_item, 4096));
+    const float sig = 1600.f * sqrtf(512.f);
+    const int slice_cols = 8192;  // the product's 16 col-steps of 512
+    const int mode = argc > 3 ? atoi(argv[3]) : 0;
+    if (mode == 0)
+    for (int rep = 0; rep < 2; ++rep)
+        for (int dens = 0; dens < 2; ++dens) {
+            a.thr = (int)((dens == 0 ? 9.f : 3.5f) * sig);
+            const int R = 4;
+            //                     PRW NW RS WM WN PF
+            run("V0  32x32x32 P128 8w  128x64  PF4 (shipped shape)", k32<128, 8, 1, 4, 2, 4>, a, 128, 8, 512, slice_cols, R);
+            run("V1  16x16x64 P128 8w  128x64  PF2", k16<128, 8, 1, 4, 2, 2>, a, 128, 8, 512, slice_cols, R);
+            run("V4  32x32x32 P256 8w  2x(128x64) shared cols PF4", k32<256, 8, 2, 4, 2, 4>, a, 256, 8, 256, slice_cols, R);
+        }
+    if (mode == 1) {
+        // where the skeleton's gap to the MFMA-only loop is: hand-over amortisation (slice size) and the epilogue
+        a.thr = (int)(9.f * sig);
+        const int R = 4;
+        for (int rep = 0; rep < 2; ++rep)
+            for (int sc = 2048; sc <= 524288; sc *= 4) {
+                char nm[96];
+                snprintf(nm, sizeof nm, "V0 32x32x32 slice %d cols", sc);
+                run(nm, k32<128, 8, 1, 4, 2, 4>, a, 128, 8, 512, sc, R);
+                snprintf(nm, sizeof nm, "V0 32x32x32 slice %d cols, epilogue per item only", sc);
+                run(nm, k32<128, 8, 1, 4, 2, 4, 1>, a, 128, 8, 512, sc, R);
+                snprintf(nm, sizeof nm, "V1 16x16x64 slice %d cols", sc);
+                run(nm, k16<128, 8, 1, 4, 2, 2>, a, 128, 8, 512, sc, R);
+                snprintf(nm, sizeof nm, "V1 16x16x64 slice %d cols, epilogue per item only", sc);
+                run(nm, k16<128, 8, 1, 4, 2, 2, 1>, a, 128, 8, 512, sc, R);
+            }
+    }
+    if (mode == 2) {
+        a.thr = (int)(9.f * sig);
+        const int R = 3;
+        run("V0 32x32x32", k32<128, 8, 1, 4, 2, 4>, a, 128, 8, 512, 32768, R);
+        run("V1 16x16x64", k16<128, 8, 1, 4, 2, 2>, a, 128, 8, 512, 32768, R);
+        run("V1 16x16x64 no B stream", k16<128, 8, 1, 4, 2, 2, 0, 1>, a, 128, 8, 512, 32768, R);
+        run("V1 16x16x64 no A reads", k16<128, 8, 1, 4, 2, 2, 0, 2>, a, 128, 8, 512, 32768, R);
+        run("V1 16x16x64 neither", k16<128, 8, 1, 4, 2, 2, 0, 3>, a, 128, 8, 512, 32768, R);
+    }
+    return 0;
+}

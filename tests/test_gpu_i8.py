@@ -1,6 +1,6 @@
 """int8 pre-filter (csrc/sim_i8p.hip + quant_i8.hip) must be INVISIBLE in the results, like the fp16 one.
 
-Batches whose hits are sparse run on v_mfma_i32_32x32x32_i8 over 8-bit images of the rows (one scale per
+Batches whose hits are sparse run on v_mfma_i32_16x16x64_i8 over 8-bit images of the rows (one scale per
 reference row, one per 128-row query panel); a pair goes to the exact fp32 stage when its integer score exceeds
 a rigorous lower bound of (radius - eps) / (s_q s_r), eps built from the quantisation residuals that were
 actually produced.  Hits, order and fp32 bit patterns must equal the CPU oracle's (vsc/index.py:142-165 and

@@ -9,8 +9,9 @@
 // pre-filter then hands every pair of that row to the exact stage.
 //
 //   quant_ref_frag    reference rows: one scale per ROW (max |x| / 127), fragment-major image (the B operand of one
-//                     v_mfma_i32_32x32x32_i8 -- lane l: row l & 31, k bytes 16 (l >> 5) .. + 15 -- is 1 KiB of
-//                     consecutive memory), meta[row] = {1 / s, E, N, N'}
+//                     v_mfma_i32_16x16x64_i8 -- lane l: row l & 15, k bytes 16 (l >> 4) .. + 15 of a 64-k step -- is
+//                     1 KiB of consecutive memory; a 64-row tile's step is 4 KiB: [16-row block][k piece][row]),
+//                     meta[row] = {1 / s, E, N, N'}
 //   quant_query_panels  query rows of ONE launch: one scale per 128-row PANEL (the kernel's epilogue compares the
 //                     integer accumulators of a whole panel against one threshold per reference column), natural
 //                     image [panel rows][dpad8], pstat[panel] = {1 / s, max E, max N, max N'}
@@ -54,7 +55,7 @@ __global__ __launch_bounds__(256) void quant_ref_frag_kernel(const float* __rest
     const int64_t rel = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (rel >= rows) return;
     const int64_t row = row0 + rel;
-    const int npiece = dpad8 / 16, nks = dpad8 / 32;
+    const int npiece = dpad8 / 16, nk4 = dpad8 / 64;
     float v[16];
     float amax = 0.0f, ss_n = 0.0f, ss_k = 0.0f;
     bool bad = false;
@@ -98,8 +99,8 @@ __global__ __launch_bounds__(256) void quant_ref_frag_kernel(const float* __rest
 #pragma unroll
         for (int c = 0; c < 4; ++c)
             w[c] = (b[4 * c] & 255) | ((b[4 * c + 1] & 255) << 8) | ((b[4 * c + 2] & 255) << 16) | ((b[4 * c + 3] & 255) << 24);
-        const int ks = lane >> 1, hh = lane & 1;
-        image[((row >> 6) * nks + ks) * 128 + ((row >> 5) & 1) * 64 + hh * 32 + (row & 31)] = w;
+        const int k4 = lane >> 2, kp = lane & 3;
+        image[((row >> 6) * nk4 + k4) * 256 + ((row >> 4) & 3) * 64 + kp * 16 + (row & 15)] = w;
     }
     if (lane == 0) {
         float4 m;

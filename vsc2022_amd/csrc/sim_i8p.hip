@@ -3,68 +3,79 @@
 // Same contract as sim_f16p.hip -- candidates = a superset of the pairs whose exact fp32 score reaches the
 // threshold; vsc/index.py:142-165 semantics are restored by the exact stage (rescore_kernel) -- and the same data
 // flow (128-row query panel resident in LDS, reference fragments streamed straight into registers from a
-// fragment-major image, 8 waves x (4 x 2) blocks of 32x32, work items behind one atomic counter per panel), on
-// v_mfma_i32_32x32x32_i8: twice the k per instruction at the same issue cadence.  Measured on the power-capped
-// parts of this pool (scripts/ubench/i8_panel.hip, profiles/r03_i8_ubench.md): the skeleton sustains 2930 TOP/s
-// against 1440 TFLOP/s of the fp16 one on the same box.
+// fragment-major image, 8 waves x (128 rows x 64 columns), work items behind one atomic counter), on
+// v_mfma_i32_16x16x64_i8.
+//
+// Why 16x16x64 and not 32x32x32 (round 4, scripts/ubench/i8_tiles.hip, profiles/r04_i8_tiles_ubench.md): on this
+// pool the kernel is POWER-bound, not issue-bound -- the 32x32x32 skeleton keeps the matrix pipe busy 92 % of the
+// cycles and the clock drops to 1.50 GHz (MFMA-only loop: 1.74 GHz).  The 16x16x64 form reads and writes a quarter
+// of the accumulator registers per instruction (K = 64 per pass over a 16x16 block): the MFMA-only loop holds
+// 2.08 GHz (4300 vs 3550 TOP/s), the same skeleton 3100-3200 vs 2900 TOP/s.  Operand bytes per MFMA cycle are
+// unchanged (per 64 k: 8 ds_read_b128 + 4 buffer_load_dwordx4 for 32 MFMAs of 16 cycles).
 //
 // Why this is still exact: the integer accumulators are EXACT dot products of the quantised rows, so the only
 // error is quantisation, and quant_i8.hip records per row what was actually lost:
 //     x = s (q + e),  E >= ||x - s q||,  N >= ||x||   =>   | x.y - s_x s_y (q_x . q_y) | <= E_x N_y + (N_x + E_x) E_y
 // plus c_acc N_x N_y for the rounding of the exact fp32 chain itself.  (Coordinates on which all references agree are
-// kept out of the images and enter through per-row thresholds instead: quant_i8.hip, "EXCLUDED coordinates".)  A pair whose exact score exceeds the radius
-// therefore has   q_x . q_y  >  (radius - eps_xy) / (s_x s_y);   the kernel tests the integer accumulator against
-// the floor of a lower bound of that quotient, per reference column (one scale per reference ROW, one scale and the
-// largest E / N per query PANEL).  With 8 bits the bound is ~16x looser than the fp16 one (eps ~ 0.018 for unit
-// 512-d rows: 4-5x as many candidates), which is why api.hip uses this kernel only where hits are sparse.
+// kept out of the images and enter through per-row thresholds instead: quant_i8.hip, "EXCLUDED coordinates".)  A pair
+// whose exact score exceeds the radius therefore has   q_x . q_y  >  (radius - eps_xy) / (s_x s_y);   the kernel tests
+// the integer accumulator against the floor of a lower bound of that quotient, per reference column (one scale per
+// reference ROW, one scale and the largest E / N per query PANEL).  With 8 bits the bound is ~16x looser than the
+// fp16 one (eps ~ 0.018 for unit 512-d rows: 4-5x as many candidates), which is why api.hip uses this kernel only
+// where hits are sparse.
+//
+// Epilogue.  C layout of the 16x16 MFMA: lane l holds column l & 15, rows 4 (l >> 4) + r of the block, r = 0..3.  A
+// wave tile is 8 row blocks x 4 column blocks; lane l owns the threshold arithmetic of ONE column, col0 + l (one
+// coalesced 16-byte meta load per lane and tile), and the four columns it holds accumulators of get their integer
+// threshold by ds_bpermute.  The common path is 64 v_max3 (one maximum per lane and column block) + 4 compares.
+// Per-row thresholds (k-NN, excluded coordinates): the rows of a launch arrive sorted by threshold (sortpairs.hip);
+// the common path tests against the PANEL's smallest threshold, and only a column block that passes is re-tested
+// per 16-row block against that block's smallest threshold (integer compares only, the arithmetic of 8 thresholds
+// per column block on the rare path instead of 8 per tile on the common one).
 #include "kernels.h"
 
 namespace vscmi {
 
 typedef int i32x4 __attribute__((ext_vector_type(4)));
-typedef int i32x16 __attribute__((ext_vector_type(16)));
 
 namespace i8p {
 
 constexpr int PR = F16P_PANEL_ROWS;  // 128
 constexpr int CSW = F16P_COL_STEP;   // 512
 #ifndef VSC_I8P_PF
-#define VSC_I8P_PF 4
+#define VSC_I8P_PF 2
 #endif
-constexpr int PF = VSC_I8P_PF;       // register ring: k-steps (PF - 1 in flight, 2 KiB each per wave).  Measured on the
-                                     // bench: 8 loses 3 % (2391 vs 2474 TOP/s); delaying the second wave of every
-                                     // SIMD by 1000-4000 cycles after an item's barrier changes nothing (2431-2435)
+// Register ring of the reference stream in 64-k steps (PF - 1 in flight, 4 KiB each per wave).  PF must divide the
+// steps of a tile (4 per 256 bytes of row): the ring is carried from tile to tile in REGISTERS that asynchronous loads
+// are still writing, so the slot a step lands in must not depend on the tile -- otherwise the compiler rotates the
+// slots with v_mov at the loop's back edge and copies registers whose loads have not landed (seen with PF = 3).
+constexpr int PF = VSC_I8P_PF;
+static_assert(PF == 2 || PF == 4, "the ring must divide the 4 steps of a 256-byte chunk");
+constexpr int MB = 8, CB = 4;   // 16-row / 16-column blocks of a wave tile
+constexpr int AW = 4;           // A operands in registers: a rolling window of AW row blocks (the next AW blocks of the m-major order)
 
 __device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rsrc, int voff, char* lds) {
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)lds, 16, voff, 0, 0, 0);
 }
-__device__ __forceinline__ i32x4 bload(__amdgpu_buffer_rsrc_t rs, int voff, int soff) {
-    return __builtin_bit_cast(i32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, 0));
-}
-#ifndef VSC_I8P_ASMLOAD
-#define VSC_I8P_ASMLOAD 1  // r03: +5 % without candidates (2601 -> 2735 TOP/s), +1 % on the bench, the k-NN passes and config 4
-#endif
-// The reference stream with hand-placed waits: the loads are opaque to the compiler's s_waitcnt insertion, which
-// otherwise (a) drains the whole stream with vmcnt(0) at the start of every tile -- it loses count of the outstanding
-// loads across the emission branches -- and (b) waits vmcnt(3) where the ring allows vmcnt(4).  A load's destination
-// must not be touched before ring_wait has named it (the "+v" ties keep every use behind the wait).
-__device__ __forceinline__ void bload_asm0(i32x4& dst, __amdgpu_buffer_rsrc_t rs, int voff, int soff) {
-    asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=&v"(dst) : "v"(voff), "s"(rs), "s"(soff) : "memory");
-}
-__device__ __forceinline__ void bload_asm1(i32x4& dst, __amdgpu_buffer_rsrc_t rs, int voff, int soff) {
-    asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen offset:1024" : "=&v"(dst) : "v"(voff), "s"(rs), "s"(soff) : "memory");
+// The reference stream with hand-placed waits (round 3: the loads are opaque to the compiler's s_waitcnt insertion,
+// which otherwise drains the whole stream with vmcnt(0) at the start of every tile -- it loses count of the
+// outstanding loads across the emission branches).  A load's destination must not be touched before ring_wait has
+// named it (the "+v" ties keep every use behind the wait).
+template <int OFF>
+__device__ __forceinline__ void bload_asm(i32x4& dst, __amdgpu_buffer_rsrc_t rs, int voff, int soff) {
+    asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen offset:%4" : "=&v"(dst) : "v"(voff), "s"(rs), "s"(soff), "n"(OFF) : "memory");
 }
 typedef float f32x4v __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void gload_asm(f32x4v& dst, const float4* p) {
     asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(dst) : "v"(p) : "memory");
 }
 template <int N>
-__device__ __forceinline__ void meta_wait(f32x4v& m0, f32x4v& m1) {
-    asm volatile("s_waitcnt vmcnt(%2)" : "+v"(m0), "+v"(m1) : "n"(N));
+__device__ __forceinline__ void meta_wait(f32x4v& m) {
+    asm volatile("s_waitcnt vmcnt(%1)" : "+v"(m) : "n"(N));
 }
 template <int N>
-__device__ __forceinline__ void ring_wait(i32x4& b0, i32x4& b1) {
-    asm volatile("s_waitcnt vmcnt(%2)" : "+v"(b0), "+v"(b1) : "n"(N));
+__device__ __forceinline__ void ring_wait(i32x4 (&b)[CB]) {
+    asm volatile("s_waitcnt vmcnt(%4)" : "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]) : "n"(N));
 }
 __device__ __forceinline__ const char* uniform_ptr(const char* p) {
     const uint64_t v = reinterpret_cast<uint64_t>(p);
@@ -74,45 +85,48 @@ __device__ __forceinline__ const char* uniform_ptr(const char* p) {
 __device__ __forceinline__ float uniform_f(float x) {
     return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, x)));
 }
+__device__ __forceinline__ float lane_f(float x, int l) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), l));
+}
 
-// One output tile (128 panel rows x the wave's 64 columns, K = NKC x 256): A fragments from the LDS panel one
-// k-step ahead, B fragments from the ring, refilled PF-1 k-steps ahead; the stream continues into the wave's next
-// tile at `so_next`.  Straight-line code, every LDS address = base register + immediate; issue order pinned.
+// One output tile (128 panel rows x the wave's 64 columns, K = NKC x 256) in steps of 64 k: the A operand of row
+// block m (rows 16 m + (lane & 15), k bytes 16 (lane >> 4) .. + 15 of the step) comes from the LDS panel through a
+// rolling window of AW registers quadruples -- the operand of the block AW places further on in the (step, m) order is
+// loaded into a slot right behind the slot's last use, 4 AW MFMAs ahead of its own --; the B operands of a step are
+// 4 KiB of consecutive image (column block n: 1 KiB at n * 1024), refilled PF - 1 steps ahead; the stream continues
+// into the wave's next tile at `so_next`.  Straight-line code, every LDS address = base register + immediate; issue
+// order pinned.
 template <int NKC>
-__device__ __forceinline__ void tile_mma(const char* smem, const int (&abase)[8], i32x4 (&a)[4], i32x4 (&ring)[PF][2],
+__device__ __forceinline__ void tile_mma(const char* smem, const int (&abase)[4], i32x4 (&a)[AW], i32x4 (&ring)[PF][CB],
                                          __amdgpu_buffer_rsrc_t rs, int so_tile, int so_next, int lane16,
-                                         i32x16 (&acc)[4][2]) {
-    const i32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    constexpr int NKS = NKC * 8;
+                                         i32x4 (&acc)[MB][CB]) {
+    const i32x4 zero = {0, 0, 0, 0};
+    constexpr int NK4 = NKC * 4;
 #pragma unroll
-    for (int ks = 0; ks < NKS; ++ks) {
-        const int t = ks + PF - 1;  // k-step that goes into the ring slot freed by k-step ks - 1
-        const int so = (t < NKS) ? so_tile + t * 2048 : so_next + (t - NKS) * 2048;
-        const int kn = (ks + 1) % NKS;  // A fragments of the next k-step (the next tile starts at 0 again)
-        const char* anext = smem + (kn >> 3) * 32768 + abase[kn & 7];
-#if VSC_I8P_ASMLOAD
-        // both fragments of this k-step have landed once at most the 2 (PF - 2) loads of the younger k-steps are out
-        ring_wait<2 * (PF - 2)>(ring[ks % PF][0], ring[ks % PF][1]);
-#endif
+    for (int k4 = 0; k4 < NK4; ++k4) {
+        const int t = k4 + PF - 1;  // step that goes into the ring slot freed by step k4 - 1
+        const int so = (t < NK4) ? so_tile + t * 4096 : so_next + (t - NK4) * 4096;
+        // all four fragments of this step have landed once at most the 4 (PF - 2) loads of the younger steps are out
+        ring_wait<4 * (PF - 2)>(ring[k4 % PF]);
 #pragma unroll
-        for (int m = 0; m < 4; ++m) {
-            acc[m][0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[m], ring[ks % PF][0], ks == 0 ? zero : acc[m][0], 0, 0, 0);
-            acc[m][1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[m], ring[ks % PF][1], ks == 0 ? zero : acc[m][1], 0, 0, 0);
-            a[m] = *reinterpret_cast<const i32x4*>(anext + m * 8192);
-#if VSC_I8P_ASMLOAD
-            if (m == 0) bload_asm0(ring[(ks + PF - 1) % PF][0], rs, lane16, so);
-            if (m == 1) bload_asm1(ring[(ks + PF - 1) % PF][1], rs, lane16, so);
-#else
-            if (m < 2) ring[(ks + PF - 1) % PF][m] = bload(rs, lane16 + m * 1024, so);
-#endif
+        for (int m = 0; m < MB; ++m) {
+#pragma unroll
+            for (int n = 0; n < CB; ++n)
+                acc[m][n] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[m % AW], ring[k4 % PF][n], k4 == 0 ? zero : acc[m][n], 0, 0, 0);
+            {
+                // the block AW places on (the next tile starts at step 0 again)
+                const int kn = (k4 + (m + AW) / MB) % NK4, mn = (m + AW) % MB;
+                a[m % AW] = *reinterpret_cast<const i32x4*>(smem + (kn >> 2) * 32768 + abase[kn & 3] + mn * 4096);
+            }
+            if (m == 0) bload_asm<0>(ring[(k4 + PF - 1) % PF][0], rs, lane16, so);
+            if (m == 1) bload_asm<1024>(ring[(k4 + PF - 1) % PF][1], rs, lane16, so);
+            if (m == 2) bload_asm<2048>(ring[(k4 + PF - 1) % PF][2], rs, lane16, so);
+            if (m == 3) bload_asm<3072>(ring[(k4 + PF - 1) % PF][3], rs, lane16, so);
         }
 #pragma unroll
-        for (int m = 0; m < 4; ++m) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+        for (int m = 0; m < MB; ++m) {
+            __builtin_amdgcn_sched_group_barrier(0x008, CB, 0);
             __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-#if !VSC_I8P_ASMLOAD
-            if (m < 2) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
-#endif
         }
     }
 }
@@ -129,40 +143,61 @@ __device__ __forceinline__ float quotient_low(float edge, float inv) {
     if (!(fabsf(t) < INFINITY)) return t;  // +-inf thresholds (rows past the batch: +inf) stay what they are; NaN too
     return t - fabsf(t) * 2e-6f - 1e-3f;
 }
-// integer accumulator > t  <=>  accumulator > floor(t); out-of-range thresholds saturate to never / always
+// integer accumulator > t  <=>  accumulator > floor(t); out-of-range thresholds saturate to never / always (|acc| <=
+// 1024 x 127^2 < 2^25), and so does NaN (fmaxf returns its other operand): a NaN threshold passes everything
 __device__ __forceinline__ int floor_sat(float t) { return (int)floorf(fminf(fmaxf(t, -2.1e9f), 2.1e9f)); }
+constexpr int PASS_ALL = -2100000000;
+
+// The integer threshold of one reference column against an exact threshold t: strict for the radius search (floor of
+// a lower bound of the quotient), non-strict for row thresholds (accumulator >= T  <=  accumulator > floor(T) - 1, so
+// that pairs tied with a row's threshold survive).  eps = +inf marks a column whose arithmetic says nothing -- +inf /
+// NaN bounds (unrepresentable rows), scale products outside the range where their inverse is a normal number -- and
+// passes everything (t = +inf, a row past the batch, wins over it: nothing of such a row is ever a candidate).
+template <bool ROWTHR>
+__device__ __forceinline__ int column_threshold(float t, float eps, float inv) {
+    if (!(eps < INFINITY)) return t == INFINITY ? 2100000000 : PASS_ALL;
+    return floor_sat(quotient_low(candidate_edge(t, eps), inv)) - (ROWTHR ? 1 : 0);
+}
 
 __device__ __forceinline__ int lane_now() {
     int l;
     asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
     return l;
 }
+__device__ __forceinline__ int bperm(int src_lane, int v) { return __builtin_amdgcn_ds_bpermute(src_lane << 2, v); }
 
 // Candidates of one wave tile -> the wave's private segment (no atomics; the wave's chunk of the shared tail when the
-// segment is full).  ti[m][n] = integer threshold of 32-row block m x the lane's column of block column n: an
-// accumulator above it is a candidate.  Radius search: the same threshold for all four row blocks.  Per-row
-// thresholds (k-NN, excluded coordinates): the threshold of the block's SMALLEST row threshold -- the rows of a
-// launch arrive sorted by threshold (sortpairs.hip), so a block's 32 thresholds are next to equal and testing all
-// of its rows against the smallest one passes a few candidates more instead of costing a float comparison per
-// accumulator.  General form: edge tiles, full segments, pass-everything columns.
-__device__ __forceinline__ void emit_candidates(const SimI8PArgs& a, const bool (&all)[2], const int (&ti)[4][2], int row0,
-                                                int col0, bool interior, const i32x16 (&acc)[4][2],
-                                                const int (&bm)[4][2], int64_t seg_base, int& count, TailExt* ext) {
-    // C layout of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
+// segment is full).  tc[n] = integer threshold of the lane's column of column block n at the tile's common threshold
+// (the radius; the panel's smallest row threshold).  ROWTHR: a column block that passes is re-tested per 16-row
+// block against rt16[m], the block's smallest row threshold, with the column's own (eps, inv) fetched from the lane
+// that owns it.  General form: edge tiles, full segments, pass-everything columns.
+template <bool ROWTHR>
+__device__ __forceinline__ void emit_candidates(const SimI8PArgs& a, const int (&tc)[CB], const int (&cm)[CB],
+                                                const float (&rt16)[MB], float eps_own, float inv_own, int row0, int col0,
+                                                bool interior, const i32x4 (&acc)[MB][CB], int64_t seg_base, int& count,
+                                                TailExt* ext) {
 #pragma unroll
-    for (int m = 0; m < 4; ++m)
+    for (int n = 0; n < CB; ++n) {
+        if (!__any(cm[n] > tc[n])) continue;
+        float eps_c = 0.f, inv_c = 0.f;
+        if (ROWTHR) {
+            const int src = n * 16 + (lane_now() & 15);
+            eps_c = __builtin_bit_cast(float, bperm(src, __builtin_bit_cast(int, eps_own)));
+            inv_c = __builtin_bit_cast(float, bperm(src, __builtin_bit_cast(int, inv_own)));
+        }
 #pragma unroll
-        for (int n = 0; n < 2; ++n) {
-            if (!__any(all[n] || bm[m][n] > ti[m][n])) continue;
+        for (int m = 0; m < MB; ++m) {
+            const int tb = ROWTHR ? column_threshold<true>(rt16[m], eps_c, inv_c) : tc[n];
+            const int bmx = max(max(acc[m][n][0], acc[m][n][1]), max(acc[m][n][2], acc[m][n][3]));
+            if (!__any(bmx > tb)) continue;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int rb = m * 32 + (r & 3) + 8 * (r >> 2);  // + 4 * (lane >> 5) = row inside the panel
-                const bool hit = all[n] || acc[m][n][r] > ti[m][n];
+            for (int r = 0; r < 4; ++r) {
+                const bool hit = acc[m][n][r] > tb;
                 const unsigned long long hits = __ballot(hit);
                 if (hits == 0ull) continue;
                 const int ln = lane_now();
-                const int i = row0 + rb + 4 * (ln >> 5);
-                const int j = col0 + n * 32 + (ln & 31);
+                const int i = row0 + m * 16 + 4 * (ln >> 4) + r;
+                const int j = col0 + n * 16 + (ln & 15);
                 const bool mine = hit && (interior || (i < a.nq && j < a.nr));
                 const unsigned long long ok = interior ? hits : __ballot(mine);
                 if (ok == 0ull) continue;
@@ -183,37 +218,49 @@ __device__ __forceinline__ void emit_candidates(const SimI8PArgs& a, const bool 
                 }
             }
         }
+    }
 }
 
 // The fast path: interior tile, room for a whole tile (8192 entries) left in the wave's segment: position = count +
 // (lanes of this register's ballot below me), two buffer stores with a 32-bit offset.
-__device__ __forceinline__ void emit_candidates_seg(const SimI8PArgs& a, const int (&ti)[4][2], int row0, int col0,
-                                                    const i32x16 (&acc)[4][2], const int (&bm)[4][2],
-                                                    __amdgpu_buffer_rsrc_t rs_i, __amdgpu_buffer_rsrc_t rs_j, int& count) {
+template <bool ROWTHR>
+__device__ __forceinline__ void emit_candidates_seg(const SimI8PArgs& a, const int (&tc)[CB], const int (&cm)[CB],
+                                                    const float (&rt16)[MB], float eps_own, float inv_own, int row0,
+                                                    int col0, const i32x4 (&acc)[MB][CB], __amdgpu_buffer_rsrc_t rs_i,
+                                                    __amdgpu_buffer_rsrc_t rs_j, int& count) {
 #pragma unroll
-    for (int m = 0; m < 4; ++m)
+    for (int n = 0; n < CB; ++n) {
+        if (!__any(cm[n] > tc[n])) continue;
+        const int ln = lane_now();  // (live inside the column block only: the register file is full)
+        const int pbase = row0 + 4 * (ln >> 4);
+        const int j = col0 + n * 16 + (ln & 15);
+        float eps_c = 0.f, inv_c = 0.f;
+        if (ROWTHR) {
+            const int src = n * 16 + (ln & 15);
+            eps_c = __builtin_bit_cast(float, bperm(src, __builtin_bit_cast(int, eps_own)));
+            inv_c = __builtin_bit_cast(float, bperm(src, __builtin_bit_cast(int, inv_own)));
+        }
 #pragma unroll
-        for (int n = 0; n < 2; ++n) {
-            if (!__any(bm[m][n] > ti[m][n])) continue;
-            const int ln = lane_now();  // (live inside the block only: the register file is full)
-            const int pbase = row0 + m * 32 + 4 * (ln >> 5);
-            const int j = col0 + n * 32 + (ln & 31);
+        for (int m = 0; m < MB; ++m) {
+            const int tb = ROWTHR ? column_threshold<true>(rt16[m], eps_c, inv_c) : tc[n];
+            const int bmx = max(max(acc[m][n][0], acc[m][n][1]), max(acc[m][n][2], acc[m][n][3]));
+            if (!__any(bmx > tb)) continue;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const bool cand = acc[m][n][r] > ti[m][n];
+            for (int r = 0; r < 4; ++r) {
+                const bool cand = acc[m][n][r] > tb;
                 const unsigned long long hits = __ballot(cand);
                 if (hits == 0ull) continue;
                 if (cand) {
                     const int off = (count + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(hits >> 32),
                                                                             __builtin_amdgcn_mbcnt_lo((unsigned)hits, 0u)))
                                     << 2;
-                    const int p = pbase + (r & 3) + 8 * (r >> 2);
-                    __builtin_amdgcn_raw_buffer_store_b32(a.i0 + p, rs_i, off, 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b32(a.i0 + pbase + m * 16 + r, rs_i, off, 0, 0);
                     __builtin_amdgcn_raw_buffer_store_b32(j, rs_j, off, 0, 0);
                 }
                 count += __popcll(hits);
             }
         }
+    }
 }
 
 }  // namespace i8p
@@ -227,15 +274,18 @@ __global__ __launch_bounds__(512) void sim_i8p_kernel(SimI8PArgs a) {
     __shared__ TailExt tail_sh[8];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    constexpr int NKS = NKC * 8;
+    constexpr int NK4 = NKC * 4;
     constexpr int ROWB = NKC * 256;    // bytes per int8 row
-    constexpr int TILEB = NKS * 2048;  // bytes per 64-row wave tile of the fragment-major image
+    constexpr int TILEB = NK4 * 4096;  // bytes per 64-row wave tile of the fragment-major image
     const int lane16 = lane * 16;
-    int abase[8];
+    // A operand of row block m at step k4: row 16 m + (lane & 15), 16-byte piece 4 (k4 & 3) + (lane >> 4) of chunk
+    // k4 >> 2; LDS image [k chunk of 256 B][row][piece ^ (row & 15)] (conflict-free: the 16 lanes of a ds_read_b128
+    // phase hold 16 different pieces ^ rows)
+    int abase[4];
     {
-        const int hi = lane >> 5, r15 = lane & 15, rl = lane & 31;
+        const int kp = lane >> 4, r15 = lane & 15;
 #pragma unroll
-        for (int u = 0; u < 8; ++u) abase[u] = rl * 256 + ((((2 * u) | hi) ^ r15) << 4);
+        for (int u = 0; u < 4; ++u) abase[u] = r15 * 256 + ((((4 * u) | kp) ^ r15) << 4);
     }
     const float radius = ROWTHR ? 0.0f : *a.radius;
     const int seg = blockIdx.x * 8 + wave;  // this wave's private segment of the candidate list
@@ -250,7 +300,8 @@ __global__ __launch_bounds__(512) void sim_i8p_kernel(SimI8PArgs a) {
     int cur_panel = -1;
     // per panel (wave-uniform): 1 / s_q and the coefficients of N'_r, E_r and N_r in eps
     float inv_sq = 1.0f, coef_k = 0.0f, coef_e = 0.0f, coef_n = 0.0f;
-    float rtmin[4] = {0.f, 0.f, 0.f, 0.f};
+    float rt16[MB] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};  // smallest row threshold per 16-row block
+    float rt_panel = 0.f;                                        // ... and of the whole panel
     int panel = blockIdx.x % a.npanel;
     for (;;) {
         // ---- next work item: a slice of this workgroup's panel, else of the panel with the most left
@@ -260,11 +311,7 @@ __global__ __launch_bounds__(512) void sim_i8p_kernel(SimI8PArgs a) {
             // a launch whose candidate list has overflowed is lost (the host reruns the batch on the fp16 kernel or
             // with larger buffers): stop taking work instead of pushing billions of candidates through the tail's
             // one atomic counter (an 8-bit bound that is too loose for the data can pass most of the matrix)
-#ifndef VSC_NO_LOST_CHECK
             const bool lost = __hip_atomic_load(a.overflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
-#else
-            const bool lost = false;
-#endif
             if (a.order == 1 && !lost) {
                 // slice-major: items (slice, panel) in one global order -- every workgroup of the chip is inside
                 // the same few MB of the reference image, each XCD fetches a slice once; the price is a panel load
@@ -327,14 +374,19 @@ __global__ __launch_bounds__(512) void sim_i8p_kernel(SimI8PArgs a) {
             if (ROWTHR) {
                 float v0 = rt_sh[lane], v1 = rt_sh[64 + lane];
 #pragma unroll
-                for (int off = 16; off > 0; off >>= 1) {
+                for (int off = 8; off > 0; off >>= 1) {
                     v0 = fminf(v0, __shfl_xor(v0, off));
                     v1 = fminf(v1, __shfl_xor(v1, off));
                 }
-                rtmin[0] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v0), 0));
-                rtmin[1] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v0), 32));
-                rtmin[2] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v1), 0));
-                rtmin[3] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v1), 32));
+#pragma unroll
+                for (int m = 0; m < 4; ++m) {
+                    rt16[m] = lane_f(v0, 16 * m);
+                    rt16[4 + m] = lane_f(v1, 16 * m);
+                }
+                rt_panel = fminf(fminf(fminf(rt16[0], rt16[1]), fminf(rt16[2], rt16[3])),
+                                 fminf(fminf(rt16[4], rt16[5]), fminf(rt16[6], rt16[7])));
+                // (NaN row thresholds: fminf drops them unless a whole block holds nothing else -- that block then passes
+                // everything on the re-test; the exact stage keeps nothing of a row whose threshold is NaN either way)
             }
             cur_panel = panel;
         }
@@ -343,90 +395,59 @@ __global__ __launch_bounds__(512) void sim_i8p_kernel(SimI8PArgs a) {
             (void*)uniform_ptr(reinterpret_cast<const char*>(a.Rf) + (int64_t)cs0 * 8 * TILEB), 0, (cs1 - cs0) * 8 * TILEB,
             0x00020000);
         int so_tile = wave * TILEB;
-        i32x4 ring[PF][2];
+        i32x4 ring[PF][CB];
 #pragma unroll
         for (int dd = 0; dd < PF - 1; ++dd) {
-#if VSC_I8P_ASMLOAD
-            bload_asm0(ring[dd][0], rs, lane16, so_tile + dd * 2048);
-            bload_asm1(ring[dd][1], rs, lane16, so_tile + dd * 2048);
-#else
-            ring[dd][0] = bload(rs, lane16, so_tile + dd * 2048);
-            ring[dd][1] = bload(rs, lane16 + 1024, so_tile + dd * 2048);
-#endif
+            bload_asm<0>(ring[dd][0], rs, lane16, so_tile + dd * 4096);
+            bload_asm<1024>(ring[dd][1], rs, lane16, so_tile + dd * 4096);
+            bload_asm<2048>(ring[dd][2], rs, lane16, so_tile + dd * 4096);
+            bload_asm<3072>(ring[dd][3], rs, lane16, so_tile + dd * 4096);
         }
-        i32x4 afr[4];
+        i32x4 afr[AW];
 #pragma unroll
-        for (int m = 0; m < 4; ++m) afr[m] = *reinterpret_cast<const i32x4*>(smem + abase[0] + m * 8192);
+        for (int m = 0; m < AW; ++m) afr[m] = *reinterpret_cast<const i32x4*>(smem + abase[0] + m * 4096);
         for (int cs = cs0; cs < cs1; ++cs) {
             const int col0 = cs * CSW + wave * 64;
-            // {1 / s_r, E_r, N_r, N'_r} of the lane's two columns (the table is padded to whole col-steps)
-#if VSC_I8P_ASMLOAD
-            // (issued behind the stream loads of the previous tile, ahead of this tile's: after the K loop only the
-            // 2 (PF - 1) stream loads of the next tile are younger)
-            f32x4v m0, m1;
-            gload_asm(m0, a.rmeta + col0 + (lane & 31));
-            gload_asm(m1, a.rmeta + col0 + 32 + (lane & 31));
-#else
-            const float4 m0 = a.rmeta[col0 + (lane & 31)], m1 = a.rmeta[col0 + 32 + (lane & 31)];
-#endif
-            i32x16 acc[4][2];
+            // {1 / s_r, E_r, N_r, N'_r} of column col0 + lane (the table is padded to whole col-steps): issued behind the
+            // stream loads of the previous tile, ahead of this tile's -- after the K loop only the 4 (PF - 1) stream
+            // loads of the next tile are younger
+            f32x4v mt;
+            gload_asm(mt, a.rmeta + col0 + lane);
+            i32x4 acc[MB][CB];
             tile_mma<NKC>(smem, abase, afr, ring, rs, so_tile, so_tile + 8 * TILEB, lane16, acc);
             so_tile += 8 * TILEB;
-#if VSC_I8P_ASMLOAD
-            meta_wait<2 * (PF - 1)>(m0, m1);
-#endif
-            const float eps[2] = {(coef_k * m0.w + coef_e * m0.y + coef_n * m0.z) * 1.001f,
-                                  (coef_k * m1.w + coef_e * m1.y + coef_n * m1.z) * 1.001f};
-            const float inv[2] = {inv_sq * m0.x, inv_sq * m1.x};
-            // integer thresholds per (row block, column).  Radius search: strict, floor of a lower bound of the
-            // quotient.  Row thresholds: the block's smallest one, non-strict (accumulator >= T  <=  accumulator >
-            // floor(T) - 1), so that pairs tied with a row's threshold survive.
-            float tl[4][2];
+            meta_wait<4 * (PF - 1)>(mt);
+            // this lane's column: eps, 1 / (s_q s_r); +inf eps = "pass everything" (see column_threshold)
+            float eps_own = (coef_k * mt.w + coef_e * mt.y + coef_n * mt.z) * 1.001f;
+            const float inv_own = inv_sq * mt.x;
+            if (!(eps_own < INFINITY) || !(inv_own >= 1e-30f && inv_own < INFINITY)) eps_own = INFINITY;
+            const int t_own = column_threshold<ROWTHR>(ROWTHR ? rt_panel : radius, eps_own, inv_own);
+            // ... and the thresholds of the four columns this lane holds accumulators of
+            int tc[CB], cm[CB];
+            bool any_col = false;
 #pragma unroll
-            for (int m = 0; m < 4; ++m) {
-                const float t = ROWTHR ? rtmin[m] : radius;
-                tl[m][0] = (ROWTHR || m == 0) ? quotient_low(candidate_edge(t, eps[0]), inv[0]) : tl[0][0];
-                tl[m][1] = (ROWTHR || m == 0) ? quotient_low(candidate_edge(t, eps[1]), inv[1]) : tl[0][1];
+            for (int n = 0; n < CB; ++n) {
+                tc[n] = bperm(n * 16 + (lane & 15), t_own);
+                // the lane's 32 accumulators of this column block (8 row blocks x 4 registers): 16 v_max3
+                int x = max(max(acc[0][n][0], acc[0][n][1]), acc[0][n][2]);
+#pragma unroll
+                for (int k = 3; k < 31; k += 2) x = max(max(x, acc[k >> 2][n][k & 3]), acc[(k + 1) >> 2][n][(k + 1) & 3]);
+                x = max(x, acc[7][n][3]);
+                cm[n] = x;
+                any_col |= x > tc[n];
             }
-            // pass everything where the arithmetic above says nothing: +inf / NaN bounds (unrepresentable rows), scale
-            // products outside the range where their inverse is a normal number, NaN quotients (0 x inf, NaN thresholds)
-            bool all[2] = {!(eps[0] < INFINITY) || !(inv[0] >= 1e-30f && inv[0] < INFINITY),
-                           !(eps[1] < INFINITY) || !(inv[1] >= 1e-30f && inv[1] < INFINITY)};
-            int ti[4][2];
-#pragma unroll
-            for (int m = 0; m < 4; ++m)
-#pragma unroll
-                for (int n = 0; n < 2; ++n) {
-                    all[n] |= !(tl[m][n] == tl[m][n]);
-                    ti[m][n] = floor_sat(tl[m][n]) - (ROWTHR ? 1 : 0);
-                }
-            // candidates are rare: one max per 32x32 block first, one compare for the whole wave tile
-            int bm[4][2];
-#pragma unroll
-            for (int m = 0; m < 4; ++m)
-#pragma unroll
-                for (int n = 0; n < 2; ++n) {
-                    int x = max(max(acc[m][n][0], acc[m][n][1]), acc[m][n][2]);
-#pragma unroll
-                    for (int r = 3; r < 15; r += 2) x = max(max(x, acc[m][n][r]), acc[m][n][r + 1]);
-                    bm[m][n] = max(x, acc[m][n][15]);
-                }
-            bool any_blk = all[0] || all[1];
-#pragma unroll
-            for (int m = 0; m < 4; ++m) any_blk |= bm[m][0] > ti[m][0] || bm[m][1] > ti[m][1];
-            if (__any(any_blk)) {
+            if (__any(any_col)) {
                 const bool interior = panel * PR + PR <= a.nq && col0 + 64 <= a.nr;
-                if (interior && !all[0] && !all[1] && count + 8192 <= a.seg_cap) {
-                    emit_candidates_seg(a, ti, panel * PR, col0, acc, bm, rs_ci, rs_cj, count);
+                if (interior && count + 8192 <= a.seg_cap) {
+                    emit_candidates_seg<ROWTHR>(a, tc, cm, rt16, eps_own, inv_own, panel * PR, col0, acc, rs_ci, rs_cj, count);
                 } else {
-                    emit_candidates(a, all, ti, panel * PR, col0, interior, acc, bm, seg_base, count, &tail_sh[wave]);
+                    emit_candidates<ROWTHR>(a, tc, cm, rt16, eps_own, inv_own, panel * PR, col0, interior, acc, seg_base, count,
+                                            &tail_sh[wave]);
                 }
             }
         }
     }
-#if VSC_I8P_ASMLOAD
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the stream ran a few k-steps past its end)
-#endif
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the stream ran a few steps past its end)
     tail_close(a.tail_base, a.tail_shift, a.tail_fill, lane, &tail_sh[wave]);
     if (lane == 0) a.seg_count[seg] = count;
 }
