@@ -2,27 +2,31 @@
 """bench.py -- headline benchmark of the MI355X matching engine.
 
 metric   : query-videos localized/sec @ 512-d SSCD descriptors (BASELINE.json)
-workload : BASELINE.json configs[1] shape -- per GPU 200k query frames (8000 videos x 25) against
-           2M reference frames (40000 videos x 50), 512-d fp32, L2-normalised, 20% planted copies,
-           1% static videos; one step = the whole hot path on that batch: global-threshold search
-           (K = 1200/video) -> (query, ref) max aggregation -> top 25/video candidates ->
-           Temporal-Network localisation of the top 5/video pairs.
+workload : (default, `--scaling strong`) BASELINE.json configs[3] -- the configuration the metric is quoted on: the
+           full pipeline incl. score normalisation + TN localisation on 40000 query videos x 25 frames (1M frames,
+           split over the N GPUs) against 2M reference frames (40000 videos x 50) and a 2M-row noise set, 512-d fp32,
+           L2-normalised, 20% planted copies, 1% static videos.  One step = one query set through the whole hot path
+           (vsc/baseline/sscd_baseline.py:185-231): score normalisation of the queries (row L2 + 1-NN against the
+           noise index, beta 1.2) -> global-threshold search (K = 1200/video) -> (query, ref) max aggregation ->
+           top 25/video candidates -> Temporal-Network localisation (bias 0.5) of the top 5/video pairs.
+           `--scaling weak`: BASELINE configs[1]'s shape per GPU (8000 query videos = 200k frames, no score
+           normalisation); at N = 1 the default run reports it under "extra".
            All inputs are resident in HBM before the timed region (synthetic, generated on device).
 multi-GPU: one process per GPU, queries sharded, references replicated, the two global cuts resolved over RCCL
            (vsc2022_amd/dist.py).  `--gpus N` without a launcher re-executes itself under
            `python -m torch.distributed.run --nproc-per-node N` (127.0.0.1 rendezvous, free port); under
            torchrun it reads RANK / LOCAL_RANK / WORLD_SIZE.  Two scalings:
-             --scaling weak   (default) every rank brings its own 8000 query videos (configs[1] shape per GPU);
-             --scaling strong BASELINE configs[3] as written: 40000 query videos (1M frames) split N ways,
+             --scaling weak   every rank brings its own 8000 query videos (configs[1] shape per GPU);
+             --scaling strong (default) BASELINE configs[3] as written: 40000 query videos (1M frames) split N ways,
                               score normalisation against a 2M-row noise set INSIDE the timed step
                               (vsc/baseline/sscd_baseline.py:193-204), 2M reference frames replicated.
 
 Prints ONE JSON line on rank 0 (see the driver contract in the task statement); adds
 "roofline" (the dominant kernel, measured live with HIP events on the engine's stream), "kernels"
 (every kernel class of a step: ms, achieved TFLOP/s or GB/s against its peak) and, at N=1,
-"extra" (untimed legs after the headline measurement: the 200k x 2M k-NN of configs[1] as written,
-query-set upload, score normalisation against 2M noise rows, one search on the all-fp32 route, and
-BASELINE configs[3] -- the metric's own configuration -- on this one GPU) and
+"extra" (untimed legs after the headline measurement: BASELINE configs[1]'s shape -- 8000 query videos x 2M reference
+frames without score normalisation, a few steps --, its 200k x 2M k-NN as written, query-set upload, score
+normalisation of 200k rows, one search on the all-fp32 route) and
 "cpu_baseline" (the C oracle on the host cores, bounded sample).
 """
 import argparse
@@ -56,7 +60,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the untimed k-NN / score-norm / all-fp32 legs")
     ap.add_argument("--seed", type=int, default=1)
-    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="strong",
                     help="weak: --query-videos per GPU (configs[1] shape); strong: --total-query-videos split over the "
                          "GPUs with score normalisation in the timed step (configs[3])")
     ap.add_argument("--total-query-videos", type=int, default=40000, help="--scaling strong: query videos of the whole job")
@@ -133,10 +137,11 @@ def plant_copies(torch, dev, seed, q, n_qvid, qf, r, n_rvid, rf, frac=0.2, noise
     return gt
 
 
-def cpu_baseline(args):
-    """The C oracle (oracle/libvscoracle.so: OpenMP, AVX2 fma chains) on the host cores over a
-    bounded sample of the same workload: 64 query videos against 1/10 of the references.  Per-query
-    cost is linear in the number of reference rows, so the rate is scaled by that 1/10."""
+def cpu_baseline(args, strong):
+    """The C oracle (oracle/libvscoracle.so: OpenMP, AVX2 fma chains) on the host cores over a bounded sample of
+    the same workload: a few dozen query videos against 1/10 of the references (and, for configs[3], 1/10 of the
+    noise rows for the score normalisation of the sample).  Per-query cost is linear in the number of reference /
+    noise rows, so the rate is scaled by that 1/10."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import oracle as orc
 
@@ -145,6 +150,7 @@ def cpu_baseline(args):
     # ~10-30 s of CPU work whatever the core count (0.2 s per query video per core at this size)
     n_qv, qf = max(64, 6 * orc.num_threads()), args.query_frames
     n_rv, rf = max(1, args.ref_videos // 10), args.ref_frames
+    n_noise = max(1, (args.noise_rows or args.ref_videos * args.ref_frames) // 10)
     dim = args.dim
 
     def unit(n):
@@ -158,7 +164,20 @@ def cpu_baseline(args):
     row2q = np.repeat(np.arange(n_qv, dtype=np.int32), qf)
     row2r = np.repeat(np.arange(n_rv, dtype=np.int32), rf)
     threads = orc.num_threads()
+    bias = 0.0
+    if strong:
+        # the reference side of the score normalisation is resident state (as on the GPU); the query side is timed
+        noise = unit(n_noise)
+        keep = np.delete(np.arange(dim), int(np.argmin(noise.var(axis=0))))
+        noise_n = orc.row_normalize(noise[:, keep])
+        r = np.concatenate([orc.row_normalize(r[:, keep]), np.ones((len(r), 1), np.float32)], axis=1)
+        bias = 0.5
     t0 = time.perf_counter()
+    if strong:
+        # vsc/baseline/score_normalization.py:31-105 on the sample: drop the weakest dim, row L2, -beta * 1-NN vs noise
+        qn = orc.row_normalize(q[:, keep])
+        best, _ = orc.knn(qn, noise_n, 1)
+        q = np.concatenate([qn, -1.2 * np.asarray(best, dtype=np.float32).reshape(-1, 1)], axis=1)
     hi, hj, hs = orc.global_threshold_search(q, r, 1200 * n_qv)
     pq, pr, ps, _ = orc.pair_max(hi, hj, hs, row2q, row2r)
     n_loc = min(len(ps), 5 * n_qv)
@@ -166,7 +185,7 @@ def cpu_baseline(args):
     for k in range(n_loc):
         a = q[pq[k] * qf : (pq[k] + 1) * qf]
         b = r[pr[k] * rf : (pr[k] + 1) * rf]
-        n_boxes += len(orc.tn(orc.pair_sims(a, b, 0.0), tn_max_step=5, min_length=4))
+        n_boxes += len(orc.tn(orc.pair_sims(a, b, bias), tn_max_step=5, min_length=4))
     dt = time.perf_counter() - t0
     scale = (n_rv * rf) / float(args.ref_videos * args.ref_frames)
     return {
@@ -174,8 +193,10 @@ def cpu_baseline(args):
         "unit": "query-videos/s",
         "cores": threads,
         "kind": "port",
-        "sample": f"{n_qv} query videos x {qf} frames vs {n_rv * rf} ref frames ({dim}-d) in {dt:.2f} s on "
-                  f"{threads} threads; rate scaled by {scale:.3f} (per-query cost is linear in ref rows)",
+        "sample": f"{n_qv} query videos x {qf} frames vs {n_rv * rf} ref frames"
+                  + (f" + score normalisation against {n_noise} noise rows" if strong else "")
+                  + f" ({dim}-d) in {dt:.2f} s on {threads} threads; rate scaled by {scale:.3f} (per-query cost is "
+                    "linear in ref / noise rows)",
     }
 
 
@@ -319,59 +340,50 @@ def cpu_baseline_blas(args):
     }
 
 
-def config4_leg(args, torch, dev, dim):
-    """BASELINE configs[3] -- the configuration the metric is quoted on -- on this ONE GPU, untimed extra leg: 40000
-    query videos x 25 frames, 2M reference + 2M noise frames; per query set: score normalisation (row L2 + 1-NN vs
-    the noise set, beta 1.2) -> query upload -> search K = 48M -> 1M candidates -> 200k pairs localised with bias 0.5
-    (vsc/baseline/sscd_baseline.py:185-231).  One warm-up set, one measured set."""
+def config2_shape_leg(args, torch, dev, dim):
+    """BASELINE configs[1]'s shape on this one GPU, untimed extra leg of the default run: 8000 query videos x 25
+    frames (200k rows) against the 2M reference frames, no score normalisation -- the hot path of one query set
+    (search K = 9.6M -> 200k candidates -> 40k pairs localised), a few steps; then the legs of `extra_legs` on the
+    same matcher (the 200k x 2M k-NN as written, query upload, score normalisation of 200k rows, all-fp32 route)."""
     import time as _t
 
-    from vsc2022_amd.engine import DeviceMatcher, DeviceScoreNormalizer
+    from vsc2022_amd.engine import DeviceMatcher
 
-    n_qv, qf, n_rv, rf = args.total_query_videos, args.query_frames, args.ref_videos, args.ref_frames
-    n_noise = args.noise_rows or n_rv * rf
-    refs = synth_on_device(torch, dev, args.seed + 300, n_rv, rf, dim)
-    queries = synth_on_device(torch, dev, args.seed + 301, n_qv, qf, dim)
-    plant_copies(torch, dev, args.seed + 302, queries, n_qv, qf, refs, n_rv, rf)
-    noise = synth_on_device(torch, dev, args.seed + 310, n_noise, 1, dim, static_frac=0.0)  # (plant_copies draws from seed + 303)
-    norm = DeviceScoreNormalizer(noise, beta=1.2)
-    del noise
-    m = DeviceMatcher(norm.refs(refs), np.arange(n_rv + 1, dtype=np.int64) * rf, dev.index)
+    n_qv, qf, n_rv, rf = args.query_videos, args.query_frames, args.ref_videos, args.ref_frames
+    refs = synth_on_device(torch, dev, args.seed, n_rv, rf, dim)
+    queries = synth_on_device(torch, dev, args.seed + 1000, n_qv, qf, dim)
+    plant_copies(torch, dev, args.seed + 2000, queries, n_qv, qf, refs, n_rv, rf)
+    m = DeviceMatcher(refs, np.arange(n_rv + 1, dtype=np.int64) * rf, dev.index)
     del refs
-    q_off = np.arange(n_qv + 1, dtype=np.int64) * qf
-
-    def one_set():
-        torch.cuda.synchronize()
-        t0 = _t.perf_counter()
-        qn = norm.queries(queries)
-        torch.cuda.synchronize()
-        t1 = _t.perf_counter()
-        m.set_queries(qn, q_off)
-        torch.cuda.synchronize()
-        t2 = _t.perf_counter()
-        res = m.match(bias=0.5)
-        torch.cuda.synchronize()
-        t3 = _t.perf_counter()
-        return (t1 - t0, t2 - t1, t3 - t2), res
-
-    one_set()
+    m.set_queries(queries, np.arange(n_qv + 1, dtype=np.int64) * qf)
+    m.match()
     m.index.profile(True)
     m.index.profile_read(reset=True)
     _aux(0), _aux(1)
-    (ts, tu, tm), res = one_set()
+    steps = 3
+    torch.cuda.synchronize()
+    t0 = _t.perf_counter()
+    for _ in range(steps):
+        res = m.match()
+    torch.cuda.synchronize()
+    dt = (_t.perf_counter() - t0) / steps
     p = m.index.profile_read(reset=True)
-    tn_ms = _aux(1)[0]
-    total = ts + tu + tm
+    tn_ms = _aux(1)[0] / steps
     out = {
-        "workload": f"BASELINE configs[3] on one GPU: {n_qv} query videos ({n_qv * qf} frames) vs {n_rv * rf} reference + "
-                    f"{n_noise} noise frames, {dim}-d",
-        "ms_per_query_set": 1e3 * total, "score_norm_ms": 1e3 * ts, "query_upload_ms": 1e3 * tu, "search_ms": 1e3 * tm - tn_ms,
-        "tn_ms": tn_ms, "query_videos_per_s": n_qv / total, "hits": res.n_hits, "candidates": res.n_candidates,
+        "workload": f"BASELINE configs[1] shape: {n_qv} query videos ({n_qv * qf} frames) vs {n_rv * rf} reference frames, "
+                    f"{dim}-d, no score normalisation, {steps} steps",
+        "ms_per_step": 1e3 * dt, "query_videos_per_s": n_qv / dt, "hits": res.n_hits, "candidates": res.n_candidates,
         "pairs_localized": res.n_localized, "matches": res.n_matches,
-        "search_kernel_ms": {"int8_prefilter": p["i8_ms"], "fp16_prefilter": p["f16_ms"], "exact_fp32": p["sim_ms"],
-                             "exact_rescore": p["rescore_ms"], "select": p["select_ms"], "final_sort": p["sort_ms"]},
+        "kernel_ms_per_step": {"int8_prefilter": p["i8_ms"] / steps, "fp16_prefilter": p["f16_ms"] / steps,
+                               "exact_fp32": p["sim_ms"] / steps, "exact_rescore": p["rescore_ms"] / steps,
+                               "select": p["select_ms"] / steps, "final_sort": p["sort_ms"] / steps, "tn": tn_ms},
+        "int8_prefilter_tops": _rate(p["i8_flops"], p["i8_ms"], 1e12),
     }
-    del m, norm, queries
+    out.update(extra_legs(args, torch, dev, m, queries, n_qv, qf, n_rv, rf, dim))
+    ms_fresh = out["ms_per_step"] + out["set_queries_ms"]
+    out["value_with_fresh_query_set"] = n_qv / (ms_fresh / 1e3)
+    out["value_with_score_norm"] = n_qv / ((ms_fresh + out["score_normalize_queries_ms"]) / 1e3)
+    del m, queries
     torch.cuda.empty_cache()
     return out
 
@@ -510,20 +522,26 @@ def main():
                     "follows)", FP16_MFMA_PEAK_TFLOPS, "TFLOP/s"),
             "sim": ("sim_thresh_kernel (fp32 MFMA similarity + fused threshold compaction)", FP32_MFMA_PEAK_TFLOPS, "TFLOP/s"),
         }
-        dom = max(classes, key=lambda c: prof.get(f"{c}_ms", 0.0))
-        k_ms, k_flops, k_launches = prof[f"{dom}_ms"], prof[f"{dom}_flops"], prof[f"{dom}_launches"]
+        # (configs[3]: the search index and the noise index of the score normalisation launch the same kernels)
+        both = dict(prof)
+        if nprof is not None:
+            for c in classes:
+                for f in ("ms", "flops", "launches"):
+                    both[f"{c}_{f}"] = prof.get(f"{c}_{f}", 0) + nprof.get(f"{c}_{f}", 0)
+        dom = max(classes, key=lambda c: both.get(f"{c}_ms", 0.0))
+        k_ms, k_flops, k_launches = both[f"{dom}_ms"], both[f"{dom}_flops"], both[f"{dom}_launches"]
         peak = classes[dom][1]
         achieved = (k_flops / 1e12) / (k_ms / 1e3) if k_ms > 0 else 0.0
         # HBM-side bytes per launch of the dominant kernel come from the committed PMC passes of the SAME kernel
-        # (FETCH_SIZE / WRITE_SIZE cannot be sampled from inside the process): profiles/r03_roofline.json names the
+        # (FETCH_SIZE / WRITE_SIZE cannot be sampled from inside the process): profiles/r04_roofline.json names the
         # kernel, the commit it was measured at and the rocprofv3 files
         traffic, traffic_src = None, None
         try:
-            with open(os.path.join(ROOT, "profiles", "r03_roofline.json")) as fh:
+            with open(os.path.join(ROOT, "profiles", "r04_roofline.json")) as fh:
                 rj = json.load(fh)
             if rj.get("kernel_class") == dom:
                 traffic = float(rj["hbm_bytes_per_launch"])
-                traffic_src = f"profiles/r03_roofline.json, measured at commit {rj.get('commit', '?')}"
+                traffic_src = f"profiles/r04_roofline.json, measured at commit {rj.get('commit', '?')}"
         except Exception:
             pass
         dpad_bytes = 8 * ((dim + 63) // 64 * 64)  # two packed fp32 rows per re-scored candidate
@@ -617,37 +635,30 @@ def main():
             },
             "kernels": kernels,
         }
-        if world == 1 and not strong:
+        if world == 1:
             # the untimed legs must never cost the headline line: a failure in one of them is reported, not raised
             if not args.no_extra:
                 try:
-                    out["extra"] = extra_legs(args, torch, dev, matcher, queries, n_qv, qf, n_rv, rf, dim)
-                    ms_fresh = out["ms_per_step"] + out["extra"]["set_queries_ms"]
-                    out["extra"]["value_with_fresh_query_set"] = n_qv / (ms_fresh / 1e3)
-                    # the same query set WITH its score normalisation (configs[3]'s extra stage at this shape)
-                    out["value_with_score_norm"] = n_qv / ((ms_fresh + out["extra"]["score_normalize_queries_ms"]) / 1e3)
+                    if strong:
+                        del matcher, norm
+                        torch.cuda.empty_cache()
+                        out["extra"] = {"config2_shape": config2_shape_leg(args, torch, dev, dim)}
+                    else:
+                        out["extra"] = extra_legs(args, torch, dev, matcher, queries, n_qv, qf, n_rv, rf, dim)
+                        ms_fresh = out["ms_per_step"] + out["extra"]["set_queries_ms"]
+                        out["extra"]["value_with_fresh_query_set"] = n_qv / (ms_fresh / 1e3)
+                        out["value_with_score_norm"] = n_qv / ((ms_fresh + out["extra"]["score_normalize_queries_ms"]) / 1e3)
                 except Exception as exc:  # noqa: BLE001
                     out["extra_error"] = f"{type(exc).__name__}: {exc}"
-                try:
-                    del matcher
-                    torch.cuda.empty_cache()
-                    out.setdefault("extra", {})["config4_single_gpu"] = config4_leg(args, torch, dev, dim)
-                except Exception as exc:  # noqa: BLE001
-                    out["config4_error"] = f"{type(exc).__name__}: {exc}"
             if not args.no_cpu_baseline:
                 try:
-                    out["cpu_baseline"] = cpu_baseline(args)
+                    out["cpu_baseline"] = cpu_baseline(args, strong)
                 except Exception as exc:  # noqa: BLE001
                     out["cpu_baseline_error"] = f"{type(exc).__name__}: {exc}"
                 try:
                     out["cpu_baseline_blas_search_only"] = cpu_baseline_blas(args)
                 except Exception as exc:  # noqa: BLE001
                     out["cpu_baseline_blas_error"] = f"{type(exc).__name__}: {exc}"
-        elif world == 1 and not args.no_cpu_baseline:
-            try:
-                out["cpu_baseline"] = cpu_baseline(args)
-            except Exception as exc:  # noqa: BLE001
-                out["cpu_baseline_error"] = f"{type(exc).__name__}: {exc}"
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
