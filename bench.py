@@ -421,7 +421,10 @@ def main():
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
     pg = {"backend": None, "ranks_answered": 1, "devices": [local_rank], "launcher": "none"}
-    if world > 1:
+    # under a launcher (torch.distributed.run sets WORLD_SIZE) the process group is formed even for ONE rank: the
+    # collectives of the timed region and of the final check then run over RCCL exactly as they do for N > 1
+    use_dist = world > 1 or "WORLD_SIZE" in os.environ
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if share_gpu:
             dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -472,7 +475,7 @@ def main():
         return matcher.match(**kw)
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -495,7 +498,7 @@ def main():
     nprof = norm.noise_index.profile_read(reset=True) if norm is not None else None
     pm_ms, pm_calls, pm_bytes = _aux(0)
     tn_ms, tn_calls, tn_bytes = _aux(1)
-    if world > 1:
+    if use_dist:
         t = torch.tensor([dt], dtype=torch.float64, device="cpu" if share_gpu else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -660,7 +663,7 @@ def main():
                 except Exception as exc:  # noqa: BLE001
                     out["cpu_baseline_blas_error"] = f"{type(exc).__name__}: {exc}"
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

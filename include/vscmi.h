@@ -62,17 +62,35 @@ int vsc_device_count(void);
  * The reference set stays resident in HBM across searches; add is incremental.
  *
  * Every score the library returns is the fp32 chain acc = fmaf(q[k], r[k], acc), k ascending.  For
- * inner-product indexes the thresholded searches and the k-NN first evaluate the score matrix in fp16
- * on the matrix cores and hand to that exact stage every pair whose fp16 score plus a rigorous error
- * bound reaches the threshold; the outputs are bit-identical to the all-fp32 route.
- * Environment, read when a handle is created: VSC_PREFILTER=0 disables the pre-filter, =2 forces it on
- * every batch / every k-NN regardless of size (tests); VSC_PREFILTER_DENSITY=<fraction> moves the hit
- * density below which a batch of the thresholded search is pre-filtered (default 0.02).  Tuning / debug
- * aids read per call: VSC_KNN_NCHUNK (runs per query tile of the exact k-NN), VSC_SIM_GRID (persistent grid
- * of the exact similarity kernel), VSC_POISON_ALLOC=1 (fresh device buffers filled with 0xFF); A/B switches:
- * VSC_F16_KERNEL=ring (handle creation: the 256x256 LDS-ring pre-filter instead of the panel-stationary one),
- * VSC_KNN_LEVELS=1 (pre-filtered k-NN without the threshold-refinement pass), VSC_KNN_SUBSET=<factor> (size of its
- * exact subset pass, default 300). */
+ * inner-product indexes the thresholded searches and the k-NN first evaluate the score matrix at reduced precision
+ * on the matrix cores -- int8 (v_mfma_i32_16x16x64_i8, dims <= 1024) where hits are sparse, fp16 otherwise -- and
+ * hand to that exact stage every pair whose low-precision score plus a rigorous error bound reaches the threshold;
+ * the outputs are bit-identical to the all-fp32 route.
+ *
+ * Environment.  Every switch below is read ONCE, when a handle is created, and stays with that handle:
+ *   VSC_PREFILTER=0           no pre-filter (every search on the exact fp32 MFMA kernel); =2 forces it onto every
+ *                             batch / every k-NN regardless of size (tests)
+ *   VSC_PREFILTER_DENSITY=f   expected hit density below which a batch of the thresholded search is pre-filtered
+ *                             (default 0.05)
+ *   VSC_F16_KERNEL=ring       the 256x256 LDS-ring fp16 pre-filter instead of the panel-stationary one (A/B)
+ *   VSC_I8=0                  no int8 image (fp16 pre-filter only); =2 forces the int8 kernel onto every
+ *                             pre-filtered batch (tests)
+ *   VSC_I8_DENSITY=f          expected hit density below which a pre-filtered batch runs on int8 (default 3e-4)
+ *   VSC_I8_MAX_REL=f          sqrt(dim) x mean(E_r / N'_r) of the references above which the index never starts
+ *                             on int8 (default 0.35: the 8-bit bound would pass too much of the matrix)
+ *   VSC_I8_EXCLUDE=0          keep coordinates on which all references agree inside the int8 images
+ *   VSC_I8_SORT=0             int8 launches see their rows in batch order (default: sorted by threshold / scale)
+ *   VSC_I8P_ORDER=0           panel-major work items with stealing (default 1: slice-major)
+ *   VSC_I8P_SLICE=n           col-steps of 512 reference rows per work item (default 16 slice-major)
+ *   VSC_I8_SCREEN=1           fp16 screen between the int8 pre-filter and the exact stage (measured neutral: off)
+ *   VSC_I8_KNN=0              k-NN threshold passes on the fp16 kernel
+ *   VSC_RESCORE_SORT=0        exact stage over the waves' candidate segments as they are (default: compacted and
+ *                             sorted by reference row)
+ *   VSC_KNN_LEVELS=1          pre-filtered k-NN with one refinement level; VSC_KNN_SUBSET=<factor> (default 300),
+ *   VSC_KNN_S0DIV=<n> (7), VSC_KNN_RATIO=<r> (by k), VSC_KNN_NCHUNK=<n>: sizes of its exact subset pass / levels
+ *   VSC_DEBUG_I8 / VSC_DEBUG_SCREEN: notes on stderr when a search falls back from int8 / per screen launch
+ * Process-wide (first use): VSC_SIM_GRID (persistent grid of the exact similarity kernel), VSC_POISON_ALLOC=1
+ * (fresh device buffers filled with 0xFF). */
 int vsc_index_create(int dim, int metric, int device, vsc_index_t** out);
 int vsc_index_destroy(vsc_index_t* idx);
 int vsc_index_add(vsc_index_t* idx, const float* x, int64_t n, int x_mem);
@@ -110,6 +128,19 @@ int vsc_index_range_search(vsc_index_t* idx, const float* q, int64_t nq, int q_m
 int vsc_index_global_topk(vsc_index_t* idx, const float* q, int64_t nq, int q_mem, int64_t K,
                           int32_t* out_i, int32_t* out_j, float* out_s, int64_t cap, int out_mem,
                           int64_t* n_out, float* final_radius);
+
+/* The same search for a caller that already knows a radius below the K-th best score (the query-sharded pipeline,
+ * vsc2022_amd/dist.py: every rank seeds its local search with a radius agreed over a row sample -- what FAISS gives
+ * the reference when an index is spread over GPUs, vsc/index.py:153): the rows run as steady 32768-row batches from
+ * `radius0` (a score for inner product, a distance for L2) instead of replaying the doubling schedule from -/+1e10.
+ * Returns every hit STRICTLY beyond max(radius0, the re-threshold radii) -- the re-threshold rule of
+ * range_search_max_results stays active (more than 2K kept: radius <- (K+1)-th best), so a seed that is too low costs
+ * time, not memory -- ordered and truncated like vsc_index_global_topk; *final_radius = the last radius: the list is
+ * complete beyond it.  Fewer than K hits come back when the seed was too high: the caller falls back to the unseeded
+ * search.  radius0 must be finite. */
+int vsc_index_global_topk_seeded(vsc_index_t* idx, const float* q, int64_t nq, int q_mem, int64_t K, float radius0,
+                                 int32_t* out_i, int32_t* out_j, float* out_s, int64_t cap, int out_mem,
+                                 int64_t* n_out, float* final_radius);
 
 /* Fused candidate generation: vsc_index_global_topk followed by vsc_pair_max without the hit list
  * leaving HBM -- the whole of CandidateGeneration.query with MaxScoreAggregation

@@ -241,18 +241,78 @@ def test_sharded_hits_terminates_when_one_shard_holds_the_whole_topk(tmp_path):
     assert np.float32(r0[1]) == np.float32(r1[1]) == r0[0][-1]
 
 
+# ---------------------------------------------------------------- seeded local searches (round 4: no schedule replay per rank)
+def _seeded_worker(rank, world, port, out_path):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        sys.path[:0] = [ROOT]
+        from vsc2022_amd import dist as vdist
+
+        rng = np.random.default_rng(70 + rank)
+        full = np.sort(rng.random(500 + 100 * rank).astype(np.float32))[::-1].copy()
+        full[40:44] = full[40]  # ties inside every list
+        out = {}
+        for name, K, seed in (("good", 300, 0.55), ("too_high", 300, 0.93), ("one_rank_full", 120, 0.05)):
+            calls = []
+
+            def local_search(k_local, seed=seed, K=K, calls=calls):
+                # first call: seeded -- every local score beyond the seed, cut at K; later calls: the plain budgeted search
+                if not calls:
+                    calls.append(("seeded", K))
+                    s = torch.from_numpy(full[full > np.float32(seed)][:K].copy())
+                    z = torch.zeros(len(s), dtype=torch.int32)
+                    return z, z, s, float(seed), True
+                calls.append(("plain", k_local))
+                s = torch.from_numpy(full[:k_local].copy())
+                z = torch.zeros(len(s), dtype=torch.int32)
+                return z, z, s, float("-inf")
+
+            hi, hj, hs, tau = vdist.sharded_hits(local_search, 10 ** 9, K)
+            out[name] = (hs.numpy(), tau, calls)
+        torch.save((full, out), f"{out_path}.{rank}")
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_hits_with_seeded_local_searches(tmp_path):
+    """world 3: a seed below the global cut gives the exact top-K in ONE seeded search per rank; a seed above it (fewer
+    than K hits over all ranks) sends every rank through the plain search; a rank whose seeded list is full (K hits) is
+    exact although its own cut equals its last element."""
+    out = str(tmp_path / "seeded")
+    world = 3
+    mp.spawn(_seeded_worker, args=(world, 29700 + os.getpid() % 200, out), nprocs=world, join=True)
+    got = [torch.load(f"{out}.{r}", weights_only=False) for r in range(world)]
+    lists = [g[0] for g in got]
+    for name, K in (("good", 300), ("too_high", 300), ("one_rank_full", 120)):
+        order = sorted(((-float(v), r, p) for r in range(world) for p, v in enumerate(lists[r])))[:K]
+        for r in range(world):
+            want = [lists[r][p] for _, rr, p in order if rr == r]
+            hs, tau, calls = got[r][1][name]
+            assert np.array_equal(hs, np.array(want, dtype=np.float32)), (name, r)
+            assert np.float32(tau) == np.float32(-order[-1][0])
+            if name == "good":
+                assert calls == [("seeded", K)], calls
+            if name == "too_high":
+                assert calls[0] == ("seeded", K) and calls[1][0] == "plain", calls
+    # 'one_rank_full': the seed 0.05 leaves > 120 scores on every rank: all lists are full, one search each
+    assert all(got[r][1]["one_rank_full"][2] == [("seeded", 120)] for r in range(world))
+
+
 # ---------------------------------------------------------------- reference-sharded index (configs[4])
 class _OracleIndex:
     """FlatIndex stand-in over the CPU oracle (there is no GPU here): what is under test is refshard.py."""
 
-    def __init__(self, rows):
+    def __init__(self, rows, metric_type=0):
         self.rows = np.ascontiguousarray(rows, dtype=np.float32)
         self.ntotal = len(self.rows)
+        self.metric_type = metric_type
 
     def search(self, x, k):
         import oracle as orc
 
-        return orc.knn(np.ascontiguousarray(x, dtype=np.float32), self.rows, k)
+        return orc.knn(np.ascontiguousarray(x, dtype=np.float32), self.rows, k, self.metric_type)
 
     def global_topk(self, x, K, device_out=False):
         import oracle as orc
@@ -287,6 +347,8 @@ def _refshard_worker(rank, world, port, out_path):
         idx = RefShardedIndex(_OracleIndex(r[lo:hi]), lo, len(r))
         D, I = idx.search(q, 9)
         res = {"D": D, "I": I}
+        # the same shards behind an L2 index: distances ascend, ties by id (vsc/index.py:171 with faiss.METRIC_L2)
+        res["D2"], res["I2"] = RefShardedIndex(_OracleIndex(r[lo:hi], 1), lo, len(r)).search(q, 7)
         for K in (50, 700, 5000):
             i, j, s, tau = idx.global_topk(q, K, k_local_start=K // 6 + 1)
             res[f"i{K}"], res[f"j{K}"], res[f"s{K}"] = i.numpy(), j.numpy(), s.numpy()
@@ -306,9 +368,11 @@ def test_ref_sharded_index_equals_single_index(tmp_path):
     mp.spawn(_refshard_worker, args=(world, 29400 + os.getpid() % 500, out), nprocs=world, join=True)
     q, r = _refshard_data()
     D, I = orc.knn(q, r, 9)
+    D2, I2 = orc.knn(q, r, 7, 1)
     for rank in range(world):
         got = np.load(f"{out}.{rank}.npz")
         assert np.array_equal(got["I"], I) and np.array_equal(got["D"].view(np.uint32), D.view(np.uint32))
+        assert np.array_equal(got["I2"], I2) and np.array_equal(got["D2"].view(np.uint32), D2.view(np.uint32))
         for K in (50, 700, 5000):
             # K small enough that the reference's schedule never re-thresholds on a tie: plain exact top-K
             S = (q @ r.T).astype(np.float32)

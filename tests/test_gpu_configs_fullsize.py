@@ -1,0 +1,179 @@
+"""BASELINE.json's configurations at their literal sizes on ONE MI355X:
+
+  configs[3]  full pipeline incl. score normalisation + TN localisation on 40 000 query videos (1 M query frames,
+              2 M reference + 2 M noise frames) -- the configuration the metric is quoted on -- with oracle spot checks;
+  configs[2]  SSCD ResNet-50 @1fps frame inference over 8 000 synthetic videos x 25 frames on `FastSSCD`: finite,
+              the same bits on a second run, 64 sampled videos against the fp32 eager per-video network;
+  bench.py    its default (configs[3]) line under `torch.distributed.run --nproc-per-node 1`: the nccl (= RCCL) branch
+              of the process-group set-up, the max-over-ranks timing and the candidate-table check execute.
+"""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.gpu
+
+
+def pair_scores(orc, a, b):
+    """fp32 fma-chain scores of row pairs (a[k], b[k]) through the oracle"""
+    return np.array([orc.scores(a[k : k + 1], b[k : k + 1])[0, 0] for k in range(len(a))], dtype=np.float32)
+
+
+def test_config4_full_pipeline_40k_query_videos(gpu, orc):
+    """vsc/baseline/sscd_baseline.py:185-231 at BASELINE configs[3]'s size on one GPU: score normalisation of 1 M query
+    rows against 2 M noise rows, search K = 48 M over 2 M references, 1 M candidates, 200 k pairs localised with bias
+    0.5.  Size-independent properties + sampled rows / hits recomputed by the CPU oracle bit for bit."""
+    import torch
+    from bench import plant_copies, synth_on_device
+    from vsc2022_amd.engine import DeviceMatcher, DeviceScoreNormalizer
+
+    dev = torch.device("cuda", 0)
+    n_qv, qf, n_rv, rf, dim = 40000, 25, 40000, 50, 512
+    nq, nr = n_qv * qf, n_rv * rf
+    refs = synth_on_device(torch, dev, 31, n_rv, rf, dim)
+    queries = synth_on_device(torch, dev, 32, n_qv, qf, dim)
+    gt = plant_copies(torch, dev, 33, queries, n_qv, qf, refs, n_rv, rf)
+    noise = synth_on_device(torch, dev, 77, nr, 1, dim, static_frac=0.0)  # (not 34: plant_copies draws its perturbations from seed + 1)
+    beta = 1.2
+    norm = DeviceScoreNormalizer(noise, beta=beta)
+    qn = norm.queries(queries)
+    assert qn.shape == (nq, dim) and qn.is_cuda
+    # ---- the 1-NN behind the bias column: sampled rows against ALL 2 M noise rows on the oracle
+    rng = np.random.default_rng(9)
+    rows = np.sort(rng.choice(nq, 8, replace=False))
+    keep = norm.sel.cpu().numpy()
+    noise_prep = norm._prepare(noise).cpu().numpy()
+    del noise
+    q_prep = orc.row_normalize(queries[torch.from_numpy(rows).to(dev)].cpu().numpy()[:, keep])
+    got = qn[torch.from_numpy(rows).to(dev)].cpu().numpy()
+    assert np.array_equal(got[:, : dim - 1].view(np.uint32), q_prep.view(np.uint32))
+    best, _ = orc.knn(q_prep, noise_prep, 1)
+    assert np.array_equal(got[:, dim - 1].view(np.uint32), (best[:, 0] * np.float32(-beta)).view(np.uint32))
+    del noise_prep
+    # ---- search on the normalised descriptors
+    rn = norm.refs(refs)
+    del refs, queries
+    m = DeviceMatcher(rn, np.arange(n_rv + 1, dtype=np.int64) * rf, 0)
+    m.set_queries(qn, np.arange(n_qv + 1, dtype=np.int64) * qf)
+    K = 1200 * n_qv
+    hi, hj, hs, radius = m.search(K)
+    assert hs.numel() == K
+    assert bool((hs[:-1] >= hs[1:]).all()) and bool((hs > radius).all())
+    key = hi.to(torch.int64) * nr + hj.to(torch.int64)
+    same = hs[:-1] == hs[1:]
+    assert bool((key[:-1][same] < key[1:][same]).all())            # ties: (row, ref) ascending
+    assert int(torch.unique(key).numel()) == K                      # no pair twice
+    pick = torch.from_numpy(rng.choice(K, 1000, replace=False)).to(dev)
+    a = qn[hi[pick].long()].cpu().numpy()
+    b = rn[hj[pick].long()].cpu().numpy()
+    assert np.array_equal(pair_scores(orc, a, b).view(np.uint32), hs[pick].cpu().numpy().view(np.uint32))
+    # completeness on the sampled rows against a 200 k-row slice of the references
+    sub = orc.scores(got, rn[:200000].cpu().numpy())
+    last = float(hs[-1].item())
+    row_hits = {}
+    for x, r_ in enumerate(rows):
+        sel = hi == int(r_)
+        row_hits[x] = set(hj[sel].cpu().tolist())
+    rr, cc = np.nonzero(sub > np.float32(last))
+    for x, y in zip(rr, cc):
+        assert int(y) in row_hits[int(x)], (int(rows[x]), int(y))
+    del hi, hj, hs, key, same
+    # ---- candidates + localisation (bias 0.5, MaxSim), and the same result on a second run
+    res = m.match(bias=0.5)
+    assert res.n_hits == K and res.n_candidates == 25 * n_qv and res.n_localized == 5 * n_qv
+    planted = set(gt)
+    cq, cr = res.cand_q.cpu().numpy(), res.cand_r.cpu().numpy()
+    cand = set(zip(cq.tolist(), cr.tolist()))
+    assert len(planted & cand) >= 0.99 * len(planted)
+    nbox = res.nbox.cpu().numpy()
+    loc = set(zip(cq[: res.n_localized][nbox > 0].tolist(), cr[: res.n_localized][nbox > 0].tolist()))
+    assert len(planted & loc) >= 0.95 * len(planted)
+    res2 = m.match(bias=0.5)
+    assert torch.equal(res.cand_q, res2.cand_q) and torch.equal(res.cand_r, res2.cand_r)
+    assert torch.equal(res.cand_score.view(torch.int32), res2.cand_score.view(torch.int32))
+    assert torch.equal(res.boxes, res2.boxes) and torch.equal(res.nbox, res2.nbox)
+
+
+def test_config3_fast_inference_8000_videos(gpu):
+    """BASELINE configs[2] at its literal size: 8 000 synthetic videos x 25 frames @ 320 x 320 through `FastSSCD`
+    (packed batches of 256).  Finite, bit-identical on a second run, and 64 sampled videos against the fp32 eager
+    per-video network (vsc/baseline/inference_impl.py:210-239) at the tolerance of
+    test_inference.py::test_fast_inference_configuration_against_fp32_eager: cosine >= 0.999 on every frame."""
+    import torch
+    from dataclasses import dataclass
+
+    from vsc2022_amd.vsc.baseline.inference import FastSSCD, SyntheticVideos, build_sscd_model, preprocess, run_inference, \
+        run_inference_packed, to_flat
+
+    @dataclass
+    class PatternVideos(SyntheticVideos):
+        first: int = 0
+
+        def video(self, idx, n_frames, device):
+            g = torch.Generator(device=device)
+            g.manual_seed(self.seed * 1000003 + self.first + idx)
+            base = torch.rand((1, 3, 6, 6), generator=g, device=device)
+            frames = base + 0.35 * torch.rand((n_frames, 3, 6, 6), generator=g, device=device)
+            frames = torch.nn.functional.interpolate(frames, size=(self.size, self.size), mode="bilinear")
+            frames = frames + 0.03 * torch.rand(frames.shape, generator=g, device=device)
+            return (frames / frames.amax(dim=(1, 2, 3), keepdim=True) * 255.0).to(torch.uint8)
+
+    dev = torch.device("cuda", 0)
+    n_videos = 8000
+    src = PatternVideos(n_videos=n_videos, frames=(25, 25), size=320, seed=11)
+    model = build_sscd_model(device=dev)
+    # (the calibrated random-init trunk of the accuracy gate in test_inference.py: data-driven BatchNorm statistics,
+    # small residual gains -- between the two degenerate regimes a random ResNet can sit in)
+    for blk in model.trunk:
+        blk.bn3.weight.fill_(0.25)
+    for mod in model.modules():
+        if isinstance(mod, torch.nn.BatchNorm2d):
+            mod.reset_running_stats()
+            mod.momentum = None
+    model.train()
+    with torch.no_grad():
+        for v in range(8):
+            model(preprocess(src.video(100000 + v, 25, dev)))
+    model.eval()
+    fast = FastSSCD(model).to(dev)
+    d1, off1, ids1 = to_flat(run_inference_packed(fast, src, dev, batch_size=256))
+    assert d1.shape == (n_videos * 25, 512) and torch.isfinite(d1).all()
+    assert len(ids1) == n_videos and off1[-1] == n_videos * 25
+    d2, off2, ids2 = to_flat(run_inference_packed(fast, src, dev, batch_size=256))
+    assert ids1 == ids2 and np.array_equal(off1, off2)
+    assert torch.equal(d1.view(torch.int32), d2.view(torch.int32)), "FastSSCD is not deterministic across runs"
+    # 64 videos spread over the set against the fp32 eager network, one video per batch
+    pick = np.linspace(0, n_videos - 1, 64).astype(int)
+    worst = 1.0
+    for v in pick:
+        one = PatternVideos(n_videos=1, frames=(25, 25), size=320, seed=11, first=int(v))
+        slow, _, _ = to_flat(run_inference(model, one, dev, batch_size=32, autocast_dtype=None))
+        got = d1[off1[v] : off1[v + 1]]
+        cos = torch.nn.functional.cosine_similarity(slow, got, dim=1)
+        worst = min(worst, float(cos.min().item()))
+    assert worst >= 0.999, f"min cosine over 64 sampled videos {worst:.6f}"
+
+
+def test_bench_default_line_under_torchrun_nproc1(gpu):
+    """`python -m torch.distributed.run --nproc-per-node 1 bench.py ...` (the driver's launcher form): WORLD_SIZE = 1
+    comes from the launcher; the line must be the metric's own configuration with score normalisation in the step."""
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr", "127.0.0.1",
+           "--master-port", str(29600 + os.getpid() % 300), os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "1",
+           "--warmup", "1", "--no-extra", "--no-cpu-baseline"]
+    out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith('{"metric"')]
+    assert len(lines) == 1, out.stdout[-2000:]
+    rep = json.loads(lines[0])
+    assert rep["n_gpus"] == 1 and rep["scaling"] == "strong" and rep["steps"] == 1
+    assert rep["process_group"]["backend"] == "nccl" and rep["process_group"]["ranks_answered"] == 1
+    assert rep["config"]["score_normalisation_in_step"] is True and "configs[3]" in rep["config"]["workload"]
+    assert rep["config"]["hits"] == 48000000 and rep["config"]["candidates"] == 1000000 and rep["config"]["pairs_localized"] == 200000
+    assert rep["value"] > 0 and 0.0 < rep["roofline"]["frac"] < 1.0

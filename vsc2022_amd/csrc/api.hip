@@ -156,6 +156,21 @@ struct vsc_index {
     bool i8_dirty = false;
     int64_t i8_rows = 0;  // rows [0, i8_rows) of the image are current
     unsigned long long stat_i8_fallbacks = 0;
+    // tuning / A-B switches of the pre-filtered routes, read from the environment when the handle is created
+    // (include/vscmi.h lists them)
+    bool i8_exclude = true;      // VSC_I8_EXCLUDE=0: keep agreeing coordinates in the images
+    int i8p_order = 1;           // VSC_I8P_ORDER: 1 slice-major work items (default), 0 panel-major with stealing
+    int i8p_slice = 0;           // VSC_I8P_SLICE: col-steps per work item (0: 16 slice-major / the plan's panel-major)
+    bool i8_sort_rows = true;    // VSC_I8_SORT=0: the rows of a launch keep their order
+    bool rescore_by_ref = true;  // VSC_RESCORE_SORT=0: re-score the waves' segments as they are
+    bool i8_screen = false;      // VSC_I8_SCREEN=1: fp16 screen between the int8 pre-filter and the exact stage
+    bool knn_i8 = true;          // VSC_I8_KNN=0: k-NN passes on the fp16 kernel
+    bool knn_two_level = true;   // VSC_KNN_LEVELS=1: one refinement level
+    double knn_subset_factor = 300.0;  // VSC_KNN_SUBSET
+    int knn_s0_div = 7;          // VSC_KNN_S0DIV
+    double knn_ratio = 0.0;      // VSC_KNN_RATIO (0: by k)
+    int knn_nchunk = 0;          // VSC_KNN_NCHUNK: reference chunks of the exact k-NN kernel (0: by size)
+    bool debug_i8 = false, debug_screen = false;  // VSC_DEBUG_I8 / VSC_DEBUG_SCREEN: stderr notes
     bool prefilter = false, prefilter_force = false;
     double prefilter_density = 0.05;  // expected hit density below which a batch goes through the pre-filter (r03: 0.02 -> 0.05 with the cheaper exact stage: -0.8 %)
     unsigned long long stat_candidates = 0, stat_hits = 0;  // last search (vsc_index_profile_read)
@@ -306,8 +321,8 @@ int vsc_index_create(int dim, int metric, int device, vsc_index_t** out) {
         const char* d = getenv("VSC_PREFILTER_DENSITY");
         if (d && atof(d) > 0.0) idx->prefilter_density = atof(d);
         // VSC_I8=0: no int8 image; VSC_I8=2: every pre-filtered batch goes through the int8 kernel (tests);
-        // VSC_I8_DENSITY: expected hit density below which a batch does (default 2e-4: the looser int8 bound
-        // brings ~4x the candidates, each ~0.44 ns of exact re-scoring, against 0.36 ps saved per pair)
+        // VSC_I8_DENSITY: expected hit density below which a batch does (default 3e-4: the looser int8 bound
+        // brings ~4x the candidates, each ~0.3 ns of exact re-scoring, against 0.36 ps saved per pair)
         idx->dpad8 = round_up(dim, 256);
         const char* i8 = getenv("VSC_I8");
         idx->i8_mode = (idx->prefilter && idx->dpad8 <= I8P_MAX_DPAD8 && !(i8 && i8[0] == '0')) ? 1 : 0;
@@ -316,6 +331,22 @@ int vsc_index_create(int dim, int metric, int device, vsc_index_t** out) {
         if (dd && atof(dd) > 0.0) idx->i8_density = atof(dd);
         const char* mr = getenv("VSC_I8_MAX_REL");
         if (mr && atof(mr) > 0.0) idx->i8_max_rel = atof(mr);
+        auto is = [](const char* name, char c) { const char* v = getenv(name); return v && v[0] == c; };
+        auto num = [](const char* name, double dflt) { const char* v = getenv(name); return v ? atof(v) : dflt; };
+        idx->i8_exclude = !is("VSC_I8_EXCLUDE", '0');
+        idx->i8p_order = (int)num("VSC_I8P_ORDER", 1.0) == 1 ? 1 : 0;
+        idx->i8p_slice = (int)num("VSC_I8P_SLICE", 0.0);
+        idx->i8_sort_rows = !is("VSC_I8_SORT", '0');
+        idx->rescore_by_ref = !is("VSC_RESCORE_SORT", '0');
+        idx->i8_screen = is("VSC_I8_SCREEN", '1');
+        idx->knn_i8 = !is("VSC_I8_KNN", '0');
+        idx->knn_two_level = !is("VSC_KNN_LEVELS", '1');
+        idx->knn_subset_factor = num("VSC_KNN_SUBSET", 300.0);
+        idx->knn_s0_div = num("VSC_KNN_S0DIV", 0.0) > 0.0 ? (int)num("VSC_KNN_S0DIV", 0.0) : 7;
+        idx->knn_ratio = num("VSC_KNN_RATIO", 0.0);
+        idx->knn_nchunk = (int)num("VSC_KNN_NCHUNK", 0.0);
+        idx->debug_i8 = getenv("VSC_DEBUG_I8") != nullptr;
+        idx->debug_screen = getenv("VSC_DEBUG_SCREEN") != nullptr;
     }
     idx->device = device;
     hipError_t e = hipStreamCreateWithFlags(&idx->stream, hipStreamNonBlocking);
@@ -425,7 +456,7 @@ static int i8_after_add(vsc_index* idx, int64_t first_new, int64_t n, int64_t ne
         }
     std::sort(cst.begin(), cst.end());
     ExcludedDims ex;
-    static const bool no_ex = getenv("VSC_I8_EXCLUDE") && getenv("VSC_I8_EXCLUDE")[0] == '0';
+    const bool no_ex = !idx->i8_exclude;
     for (size_t c = 0; c < cst.size() && ex.n < I8_MAX_EXCLUDED && !no_ex; ++c) {
         ex.idx[ex.n] = cst[c].second;
         ex.val[ex.n] = key2f(idx->cmin_key[(size_t)cst[c].second]);
@@ -581,6 +612,40 @@ static int ensure_hit_buffers(vsc_index* idx, int64_t cap, int64_t ccap = -1, bo
     return VSC_OK;
 }
 
+}  // extern "C"
+
+// The candidate list of one pre-filter launch (cand_list.h): `ccap` entries in per-wave segments + the chunked tail
+// behind them.  Fills the list fields that SimF16Args / SimF16PArgs / SimI8PArgs share and keeps the geometry for
+// the exact stage.
+struct CandList {
+    int grid = 0, seg_cap = 0, tail_shift = 6;
+    int64_t tail_base = 0;
+    long long tail_cap = 0;
+};
+template <class Args>
+static int cand_list_setup(vsc_index* idx, int64_t ccap, int grid, Args& f, CandList& cl) {
+    SelectCtl* ctl = idx->ws.ctl.as<SelectCtl>();
+    cl.grid = grid;
+    cl.seg_cap = (int)std::min<int64_t>(ccap / (grid * 8), 0x7fffffff);
+    cl.tail_base = (int64_t)cl.seg_cap * grid * 8;
+    cl.tail_cap = cand_entries(ccap) - cl.tail_base;
+    cl.tail_shift = tail_chunk_shift_for(cl.tail_cap, grid * 8);
+    VSC_TRY(idx->ws.tailfill.reserve((size_t)((cl.tail_cap >> cl.tail_shift) + 2) * sizeof(int)));
+    f.out_i = idx->ws.ci.as<int32_t>();
+    f.out_j = idx->ws.cj.as<int32_t>();
+    f.seg_cap = cl.seg_cap;
+    f.seg_count = idx->ws.segcnt.as<int>();
+    f.tail_base = cl.tail_base;
+    f.tail_cap = cl.tail_cap;
+    f.tail_shift = cl.tail_shift;
+    f.tail_fill = idx->ws.tailfill.as<int>();
+    f.tail_count = &ctl->n_tail;
+    f.overflow = &ctl->overflow;
+    return VSC_OK;
+}
+
+extern "C" {
+
 // fp16 pre-filter + exact re-scoring of query rows [i0, i1): appends to hit buffer A every (row, ref, score)
 // with score > *radius -- or, when `row_thr` (one threshold per query row, padded like the fp16 query
 // image) is given, with score >= row_thr[row].
@@ -602,12 +667,9 @@ static int enqueue_f16(vsc_index* idx, const float* qpacked, int64_t i0, int64_t
         const float c1 = (float)(ldexp(1.0, -10) + ldexp(1.0, -22) + (2.0 * D + D / 16.0 + 16.0) * ldexp(1.0, -23));
         const float c2 = (float)(ldexp(1.0, -25) * 1.001 * sqrt(D));
         const float c3 = (float)(D * ldexp(1.0, -50));
-        int32_t* const cand_i = idx->ws.ci.as<int32_t>();
-        int32_t* const cand_j = idx->ws.cj.as<int32_t>();
-        int grid = 0, seg_cap = 0, tail_shift = 6;
+        int grid = 0;
+        CandList cl;
         const int32_t* cand_perm = nullptr;  // set when the candidate list holds positions of a permuted int8 launch
-        int64_t tail_base = 0;
-        long long tail_cap = 0;
         hipEvent_t stop;
         int pcls = 1;
         if (use_i8 && idx->i8_mode) {
@@ -618,9 +680,8 @@ static int enqueue_f16(vsc_index* idx, const float* qpacked, int64_t i0, int64_t
                 // work order: slice-major items of 16 col-steps (4 MiB of the int8 image at 512-d: what an XCD's L2
                 // holds) measured +3 % on the bench (2431 -> 2507-2515 TOP/s; 8: +2 %, 32: +2 %, 4 and 64: -1 / 0 %) and
                 // -6 % on the 1-NN of score normalisation; VSC_I8P_ORDER=0: panel-major with stealing as in sim_f16p
-                static const int order_env = getenv("VSC_I8P_ORDER") ? atoi(getenv("VSC_I8P_ORDER")) : 1;
-                static const int slice_env = getenv("VSC_I8P_SLICE") ? atoi(getenv("VSC_I8P_SLICE")) : 0;
-                f.order = order_env == 1 ? 1 : 0;
+                const int slice_env = idx->i8p_slice;
+                f.order = idx->i8p_order;
                 if (f.order == 1) f.slice = std::max(1, std::min(f.nsteps, slice_env > 0 ? slice_env : 16));
                 else if (slice_env > 0) f.slice = std::max(1, std::min(f.nsteps, slice_env));
             }
@@ -640,7 +701,7 @@ static int enqueue_f16(vsc_index* idx, const float* qpacked, int64_t i0, int64_t
                 thr_src = idx->ws.rt8b.as<float>();
             }
             // VSC_I8_SORT=0: rows in their own order (A/B; the kernel then gates blocks of unrelated thresholds)
-            static const bool sort_rows = !(getenv("VSC_I8_SORT") && getenv("VSC_I8_SORT")[0] == '0');
+            const bool sort_rows = idx->i8_sort_rows;
             if (thr_src && !sort_rows) {
                 VSC_TRY(idx->ws.rt8.reserve((size_t)f.npanel * F16P_PANEL_ROWS * sizeof(float)));
                 rt_pos = idx->ws.rt8.as<float>();
@@ -677,20 +738,7 @@ static int enqueue_f16(vsc_index* idx, const float* qpacked, int64_t i0, int64_t
             f.radius = &ctl->radius;
             f.row_thr = rt_pos;
             cand_perm = perm;
-            f.out_i = cand_i;
-            f.out_j = cand_j;
-            seg_cap = (int)std::min<int64_t>(ccap / (grid * 8), 0x7fffffff);
-            tail_base = (int64_t)seg_cap * grid * 8;
-            tail_cap = cand_entries(ccap) - tail_base;
-            f.seg_cap = seg_cap;
-            f.seg_count = idx->ws.segcnt.as<int>();
-            f.tail_base = tail_base;
-            f.tail_cap = tail_cap;
-            f.tail_shift = tail_shift = tail_chunk_shift_for(tail_cap, grid * 8);
-            VSC_TRY(idx->ws.tailfill.reserve((size_t)((tail_cap >> tail_shift) + 2) * sizeof(int)));
-            f.tail_fill = idx->ws.tailfill.as<int>();
-            f.tail_count = &ctl->n_tail;
-            f.overflow = &ctl->overflow;
+            VSC_TRY(cand_list_setup(idx, ccap, grid, f, cl));
             VSC_TRY(launch_sim_i8p(f, grid, idx->stream));
             pcls = 5;
         } else if (idx->frag) {
@@ -710,20 +758,7 @@ static int enqueue_f16(vsc_index* idx, const float* qpacked, int64_t i0, int64_t
             f.c1 = c1; f.c2 = c2; f.c3 = c3;
             f.radius = &ctl->radius;
             f.row_thr = row_thr ? row_thr + i0 : nullptr;
-            f.out_i = cand_i;
-            f.out_j = cand_j;
-            seg_cap = (int)std::min<int64_t>(ccap / (grid * 8), 0x7fffffff);
-            tail_base = (int64_t)seg_cap * grid * 8;
-            tail_cap = cand_entries(ccap) - tail_base;
-            f.seg_cap = seg_cap;
-            f.seg_count = idx->ws.segcnt.as<int>();
-            f.tail_base = tail_base;
-            f.tail_cap = tail_cap;
-            f.tail_shift = tail_shift = tail_chunk_shift_for(tail_cap, grid * 8);
-            VSC_TRY(idx->ws.tailfill.reserve((size_t)((tail_cap >> tail_shift) + 2) * sizeof(int)));
-            f.tail_fill = idx->ws.tailfill.as<int>();
-            f.tail_count = &ctl->n_tail;
-            f.overflow = &ctl->overflow;
+            VSC_TRY(cand_list_setup(idx, ccap, grid, f, cl));
             VSC_TRY(prof_begin(idx, &stop, 1));
             VSC_TRY(launch_sim_f16p(f, grid, idx->stream));
         } else {
@@ -742,21 +777,8 @@ static int enqueue_f16(vsc_index* idx, const float* qpacked, int64_t i0, int64_t
             f.c1 = c1; f.c2 = c2; f.c3 = c3;
             f.radius = &ctl->radius;
             f.row_thr = row_thr ? row_thr + i0 : nullptr;
-            f.out_i = cand_i;
-            f.out_j = cand_j;
             grid = sim_f16_grid(f.tq, f.tr);
-            seg_cap = (int)std::min<int64_t>(ccap / (grid * 8), 0x7fffffff);
-            tail_base = (int64_t)seg_cap * grid * 8;
-            tail_cap = cand_entries(ccap) - tail_base;
-            f.seg_cap = seg_cap;
-            f.seg_count = idx->ws.segcnt.as<int>();
-            f.tail_base = tail_base;
-            f.tail_cap = tail_cap;
-            f.tail_shift = tail_shift = tail_chunk_shift_for(tail_cap, grid * 8);
-            VSC_TRY(idx->ws.tailfill.reserve((size_t)((tail_cap >> tail_shift) + 2) * sizeof(int)));
-            f.tail_fill = idx->ws.tailfill.as<int>();
-            f.tail_count = &ctl->n_tail;
-            f.overflow = &ctl->overflow;
+            VSC_TRY(cand_list_setup(idx, ccap, grid, f, cl));
             VSC_TRY(prof_begin(idx, &stop, 1));
             VSC_TRY(launch_sim_f16(f, idx->stream));
         }
@@ -766,15 +788,15 @@ static int enqueue_f16(vsc_index* idx, const float* qpacked, int64_t i0, int64_t
         r.Q = qpacked;
         r.R = idx->ref.as<float>();
         r.dpad = idx->dpad;
-        r.cand_i = cand_i;
-        r.cand_j = cand_j;
-        r.n_seg = grid * 8;
-        r.seg_cap = seg_cap;
+        r.cand_i = idx->ws.ci.as<int32_t>();
+        r.cand_j = idx->ws.cj.as<int32_t>();
+        r.n_seg = cl.grid * 8;
+        r.seg_cap = cl.seg_cap;
         r.seg_count = idx->ws.segcnt.as<int>();
-        r.tail_base = tail_base;
-        r.tail_cap = tail_cap;
+        r.tail_base = cl.tail_base;
+        r.tail_cap = cl.tail_cap;
         r.tail_count = &ctl->n_tail;
-        r.tail_shift = tail_shift;
+        r.tail_shift = cl.tail_shift;
         r.tail_fill = idx->ws.tailfill.as<int>();
         r.perm = cand_perm;
         r.perm_i0 = (int)i0;
@@ -790,19 +812,25 @@ static int enqueue_f16(vsc_index* idx, const float* qpacked, int64_t i0, int64_t
         VSC_TRY(prof_begin(idx, &stop, 2));
         // The candidates are compacted out of the waves' segments, sorted by reference row and re-scored as one dense
         // list (sim_f16.hip, "candidates ordered by reference row"): 74 -> 54 ms per bench step, k-NN k = 20 140 ->
-        // 100 ms.  It needs the candidate count on the host: one stream sync per launch.  VSC_RESCORE_SORT=0: the
-        // segments as they are.
-        static const bool by_ref = !(getenv("VSC_RESCORE_SORT") && getenv("VSC_RESCORE_SORT")[0] == '0');
+        // 100 ms.  It needs the candidate count on the host (buffer sizes, grid of the sort): one stream sync per
+        // launch, ~20 us against launches of 3-30 ms.  VSC_RESCORE_SORT=0: the segments as they are.
+        const bool by_ref = idx->rescore_by_ref;
         if (by_ref) {
-            const size_t cap_e = (size_t)cand_entries(ccap);  // (an overflowing launch may store more than ccap)
-            for (auto& b : idx->ws.cs) VSC_TRY(b.reserve(cap_e * sizeof(uint32_t)));
-            VSC_TRY(idx->ws.csn.reserve(2 * sizeof(unsigned long long)));
-            const int n_chunks_max = (int)std::min<long long>((tail_cap >> tail_shift) + 1, 1 << 20);
+            // count first (one tiny kernel + the stream sync the sort needs anyway), then size the four dense lists of
+            // the sort from what the launch really left behind -- not from the list's capacity (96 bytes
+            // per unit of capacity, 26 GB for a default range search whose launches hold a few percent of that)
+            VSC_TRY(idx->ws.csn.reserve(3 * sizeof(unsigned long long)));
+            const int n_chunks_max = (int)std::min<long long>((cl.tail_cap >> cl.tail_shift) + 1, 1 << 20);
+            VSC_TRY(launch_cand_count(r, n_chunks_max, idx->ws.csn.as<unsigned long long>() + 2, idx->stream));
+            unsigned long long n_c = 0;
+            VSC_HIP(hipMemcpyAsync(&n_c, idx->ws.csn.as<unsigned long long>() + 2, sizeof(n_c), hipMemcpyDeviceToHost, idx->stream));
+            VSC_HIP(hipStreamSynchronize(idx->stream));
+            // (grown in steps of a quarter so that launches of slowly varying size do not reallocate every time)
+            const size_t cap_e = (size_t)(n_c + n_c / 4 + 4096);
+            for (auto& b : idx->ws.cs)
+                if (b.bytes < (size_t)(n_c + 1) * sizeof(uint32_t)) VSC_TRY(b.reserve(cap_e * sizeof(uint32_t)));
             VSC_TRY(launch_cand_compact(r, n_chunks_max, idx->ws.cs[0].as<uint32_t>(), idx->ws.cs[2].as<uint32_t>(),
                                         idx->ws.csn.as<unsigned long long>(), idx->stream));
-            unsigned long long n_c = 0;
-            VSC_HIP(hipMemcpyAsync(&n_c, idx->ws.csn.p, sizeof(n_c), hipMemcpyDeviceToHost, idx->stream));
-            VSC_HIP(hipStreamSynchronize(idx->stream));
             const uint32_t *sj = nullptr, *si = nullptr;
             VSC_TRY(sort_candidates_by_ref(idx->ws.cs[0].as<uint32_t>(), idx->ws.cs[1].as<uint32_t>(), idx->ws.cs[2].as<uint32_t>(),
                                            idx->ws.cs[3].as<uint32_t>(), (int64_t)n_c, nrefs, idx->ws.cstmp, &sj, &si, idx->stream));
@@ -812,9 +840,8 @@ static int enqueue_f16(vsc_index* idx, const float* qpacked, int64_t i0, int64_t
             // 59.8 ms -- both stages gather one query row per pair from the Infinity Cache at ~6 TB/s, which is the
             // bound (profiles/r03_prefilter_attribution.md).  Kept because it pays once the survivor share drops
             // (descriptors with outlier coordinates widen the int8 bound, not the fp16 one).
-            static const bool screen = getenv("VSC_I8_SCREEN") && getenv("VSC_I8_SCREEN")[0] == '1';
+            const bool screen = idx->i8_screen;
             if (pcls == 5 && screen && n_c > 0) {
-                VSC_TRY(idx->ws.csn.reserve(2 * sizeof(unsigned long long)));
                 ScreenArgs sa;
                 sa.Qh = idx->ws.qh.as<_Float16>();
                 sa.qn = idx->ws.qn.as<float>();
@@ -835,7 +862,7 @@ static int enqueue_f16(vsc_index* idx, const float* qpacked, int64_t i0, int64_t
                 sa.overflow = &ctl->overflow;
                 VSC_TRY(launch_f16_screen(sa, idx->stream));
                 VSC_TRY(launch_rescore_dense(r, sa.out_j, sa.out_i, (long long)n_c, idx->stream, sa.n_out));
-                if (getenv("VSC_DEBUG_SCREEN")) {
+                if (idx->debug_screen) {
                     unsigned long long n_s = 0;
                     VSC_HIP(hipMemcpyAsync(&n_s, sa.n_out, sizeof(n_s), hipMemcpyDeviceToHost, idx->stream));
                     VSC_HIP(hipStreamSynchronize(idx->stream));
@@ -908,9 +935,16 @@ static int init_ctl(vsc_index* idx, float radius_score_space) {
     return VSC_OK;
 }
 
-int vsc_index_global_topk(vsc_index_t* idx, const float* q, int64_t nq, int q_mem, int64_t K,
-                          int32_t* out_i, int32_t* out_j, float* out_s, int64_t cap_out, int out_mem,
-                          int64_t* n_out, float* final_radius) {
+}  // extern "C"
+
+// The body of vsc_index_global_topk.  seeded = false: the reference's schedule (batches of 32, 64, ... rows doubling
+// while < 20000, radius from -1e10).  seeded = true (vsc_index_global_topk_seeded): the caller already knows a radius
+// below the K-th best score -- every batch is a steady 32768-row batch from the first row on, pre-filtered from the
+// first row on; the re-threshold rule stays (kept > 2K: radius <- (K+1)-th best), so the buffers stay bounded when the
+// seed was low.
+static int global_topk_impl(vsc_index_t* idx, const float* q, int64_t nq, int q_mem, int64_t K, bool seeded,
+                            float radius0, int32_t* out_i, int32_t* out_j, float* out_s, int64_t cap_out, int out_mem,
+                            int64_t* n_out, float* final_radius) {
     if (!idx || nq < 0 || K < 0 || !n_out || (nq > 0 && !q)) {
         set_error("vsc_index_global_topk: invalid argument");
         return VSC_ERR_INVALID;
@@ -933,22 +967,24 @@ int vsc_index_global_topk(vsc_index_t* idx, const float* q, int64_t nq, int q_me
         bool used_i8 = false;
         VSC_TRY(ensure_hit_buffers(idx, cap));
         // initial radius -1e10 (IP) / +1e10 (L2) -> -1e10 in score space either way (vsc/index.py:146)
-        VSC_TRY(init_ctl(idx, -1e10f));
+        VSC_TRY(init_ctl(idx, seeded ? (ip ? radius0 : -radius0) : -1e10f));
         SelectCtl* ctl = idx->ws.ctl.as<SelectCtl>();
         // exponential_query_iterator: 32, 64, ... doubling while bs < 20000
-        int64_t bs = 32, i0 = 0;
+        int64_t bs = seeded ? 32768 : 32, i0 = 0;
         while (i0 < nq) {
             const int64_t i1 = std::min(nq, i0 + bs);
+            // (seeded: the radius is already near its final value -- the expected density is that of the whole search)
+            const double seen = seeded ? (double)nq : (double)i0;
             // After i0 rows the radius sits near the K-th best of i0 * ntotal scores, so about
             // K / (i0 * ntotal) of this batch's pairs are hits.  While that density is high the
             // exact kernel is cheaper than pre-filtering and re-scoring nearly everything
             // (exact: ~7.5 ps per pair; re-scoring: ~0.5 ns per candidate; measured optimum near 2 % with the segment-wise exact stage, 5 % with the sorted one).
             const bool f16 = idx->prefilter_force ||
-                             (idx->prefilter && i0 > 0 && (double)K < idx->prefilter_density * (double)i0 * (double)idx->ntotal);
+                             (idx->prefilter && seen > 0 && (double)K < idx->prefilter_density * seen * (double)idx->ntotal);
             // ... and once it is low enough that the int8 kernel's 4-5x candidates cost less than the fp16 kernel's
             // second half (the bound of 8-bit rows is ~16x looser), the batch runs on int8
             const bool i8 = f16 && allow_i8 &&
-                            (idx->i8_mode == 2 || (i0 > 0 && (double)K < idx->i8_density * (double)i0 * (double)idx->ntotal));
+                            (idx->i8_mode == 2 || (seen > 0 && (double)K < idx->i8_density * seen * (double)idx->ntotal));
             used_i8 |= i8;
             VSC_TRY(enqueue_batch(idx, qp, i0, i1, cap, f16, i8));
             hipEvent_t stop;
@@ -958,7 +994,7 @@ int vsc_index_global_topk(vsc_index_t* idx, const float* q, int64_t nq, int q_me
                                         idx->ws.hB[1].as<int32_t>(), idx->ws.hB[2].as<float>(),
                                         (unsigned long long)K, idx->stream));
             VSC_TRY(prof_end(idx, stop, 0.0, 3));
-            if (bs < 20000) bs *= 2;
+            if (!seeded && bs < 20000) bs *= 2;
             i0 = i1;
         }
         VSC_HIP(hipMemcpyAsync(&h, ctl, sizeof(h), hipMemcpyDeviceToHost, idx->stream));
@@ -971,7 +1007,7 @@ int vsc_index_global_topk(vsc_index_t* idx, const float* q, int64_t nq, int q_me
             // these rows -- same buffers, fp16 pre-filter throughout
             allow_i8 = false;
             idx->stat_i8_fallbacks += 1;
-            if (getenv("VSC_DEBUG_I8"))
+            if (idx->debug_i8)
                 fprintf(stderr, "[vscmi] int8 batches overflowed the candidate list (cap %lld, candidates so far %llu, tail %llu, "
                         "kept %llu): fp16 pre-filter for this search\n", (long long)cap, h.n_cand_total, h.n_tail, h.n);
             continue;
@@ -1020,6 +1056,24 @@ int vsc_index_global_topk(vsc_index_t* idx, const float* q, int64_t nq, int q_me
     VSC_TRY(prof_collect(idx));
     *n_out = mm;
     return VSC_OK;
+}
+
+extern "C" {
+
+int vsc_index_global_topk(vsc_index_t* idx, const float* q, int64_t nq, int q_mem, int64_t K,
+                          int32_t* out_i, int32_t* out_j, float* out_s, int64_t cap_out, int out_mem,
+                          int64_t* n_out, float* final_radius) {
+    return global_topk_impl(idx, q, nq, q_mem, K, false, 0.0f, out_i, out_j, out_s, cap_out, out_mem, n_out, final_radius);
+}
+
+int vsc_index_global_topk_seeded(vsc_index_t* idx, const float* q, int64_t nq, int q_mem, int64_t K, float radius0,
+                                 int32_t* out_i, int32_t* out_j, float* out_s, int64_t cap_out, int out_mem,
+                                 int64_t* n_out, float* final_radius) {
+    if (!(radius0 == radius0) || std::fabs(radius0) > 1e9f) {
+        set_error("vsc_index_global_topk_seeded: the seed radius must be a finite score (got %g)", (double)radius0);
+        return VSC_ERR_INVALID;
+    }
+    return global_topk_impl(idx, q, nq, q_mem, K, true, radius0, out_i, out_j, out_s, cap_out, out_mem, n_out, final_radius);
 }
 
 int vsc_index_candidates(vsc_index_t* idx, const float* q, int64_t nq, int q_mem, int64_t K,
@@ -1151,7 +1205,7 @@ static int knn_exact_ip(vsc_index* idx, const float* qp, int64_t nq, int64_t nr,
     // split until ~1024 workgroups exist (2000 x 1 M: 39 TFLOP/s with 64 runs, 24 with 32).
     int nchunk = tq >= 256 ? 1 : (int)std::min<int64_t>(tr, (1024 + tq - 1) / tq);
     nchunk = std::min(nchunk, 64);
-    if (const char* e = getenv("VSC_KNN_NCHUNK")) nchunk = std::max(1, std::min(std::min(atoi(e), tr), 64));
+    if (idx->knn_nchunk > 0) nchunk = std::max(1, std::min(std::min(idx->knn_nchunk, tr), 64));
     const int64_t nq_pad = (int64_t)tq * 128;
     VSC_TRY(idx->ws.parts.reserve((size_t)nq_pad * nchunk * k * 4));
     VSC_TRY(idx->ws.partj.reserve((size_t)nq_pad * nchunk * k * 4));
@@ -1217,11 +1271,11 @@ static int knn_threshold_pass(vsc_index* idx, const float* qp, int64_t nq, int64
 static int knn_prefiltered(vsc_index* idx, const float* qp, int64_t nq, int k, float* ds, int64_t* dj) {
     const int64_t nr = idx->ntotal;
     // the thresholded passes run on the int8 kernel when the index keeps an int8 image (VSC_I8_KNN=0: fp16)
-    static const bool knn_i8_env = !(getenv("VSC_I8_KNN") && getenv("VSC_I8_KNN")[0] == '0');
+    const bool knn_i8_env = idx->knn_i8;
     bool knn_i8 = idx->i8_mode == 2 || (i8_usable(idx) && knn_i8_env);
-    static const double subset_factor = getenv("VSC_KNN_SUBSET") ? atof(getenv("VSC_KNN_SUBSET")) : 300.0;
-    static const bool two_level = !(getenv("VSC_KNN_LEVELS") && getenv("VSC_KNN_LEVELS")[0] == '1');
-    static const int s0_div = getenv("VSC_KNN_S0DIV") && atoi(getenv("VSC_KNN_S0DIV")) > 0 ? atoi(getenv("VSC_KNN_S0DIV")) : 7;
+    const double subset_factor = idx->knn_subset_factor;
+    const bool two_level = idx->knn_two_level;
+    const int s0_div = idx->knn_s0_div;
     // one level: S0 = sqrt(300 k nr) balances the exact pass (~2 dim S0 / 1e14 s per row) against the per-hit cost of
     // the final pass (k nr / S0 hits per row, ~1 ns each).  Two levels: S0 = 16 k (k^2 nr^2 / 3e5)^(1/3) ... in
     // practice S0 ~ S_one / 7 and S1 = 16 S0 sit on a flat optimum (measured at 200 k x 2 M, k = 1 and 20)
@@ -1244,7 +1298,7 @@ static int knn_prefiltered(vsc_index* idx, const float* qp, int64_t nq, int k, f
         // pass.  Every level costs one pre-filter pass over its prefix + k * ratio hits per row (x the filter's
         // inflation in candidates); the int8 bound passes 4-5 candidates per hit, so its optimum is several levels
         // of ratio ~5 where the fp16 filter (1.1 per hit) wanted one level of 16.
-        static const double ratio_env = getenv("VSC_KNN_RATIO") ? atof(getenv("VSC_KNN_RATIO")) : 0.0;
+        const double ratio_env = idx->knn_ratio;
         // measured at 200 k x 2 M (profiles/r03_knn_levels.md): k = 1: 244 / 249 / 271 ms at ratio 16 / 8 / 5;
         // k = 20: 500 / 514 / 448 / 448 ms at 16 / 8 / 5 / 4
         const double ratio = idx->prefilter_force ? 3.0

@@ -223,10 +223,10 @@ extern "C" int vsc_conv_bias_act_bf16(const void* x, const void* w, const float*
                                       void* hip_stream) {
     using namespace vscmi;
     if (!x || !w || !bias || !out || B < 0 || H <= 0 || W <= 0 || C <= 0 || N <= 0 || (C & 63) || (N & 63) || (taps != 1 && taps != 9) ||
-        stride < 1 || stride > 2 || (taps == 1 && stride != 1) || B * H * W * (C / 8) >= (1ll << 31) || H > (1 << 16) || W > (1 << 16) || C > (1 << 16) || N > (1 << 16) ||
+        stride < 1 || stride > 2 || (taps == 1 && stride != 1) || B * H * W * (C / 8) >= (1ll << 31) || H > 32767 || W > 65535 || C > (1 << 16) || N > (1 << 16) ||
         (((uintptr_t)x | (uintptr_t)w | (uintptr_t)bias | (uintptr_t)res | (uintptr_t)out) & 15)) {
         set_error("vsc_conv_bias_act_bf16: invalid argument (C and N multiples of 64, taps 1 or 9, stride 1 or 2 (1 for taps = 1), "
-                  "pointers 16-byte aligned)");
+                  "pointers 16-byte aligned, H <= 32767 and W <= 65535: a pixel is packed as (h << 16) | w in a signed int)");
         return VSC_ERR_INVALID;
     }
     cg::Args a;

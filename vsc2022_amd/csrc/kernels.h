@@ -136,6 +136,7 @@ int launch_sim_thresh(const SimThreshArgs&, hipStream_t);
 int launch_sim_f16(const SimF16Args&, hipStream_t);
 int sim_f16_grid(int tq, int tr);
 int launch_rescore(const RescoreArgs&, hipStream_t);
+int launch_cand_count(const RescoreArgs&, int, unsigned long long*, hipStream_t);
 int launch_cand_compact(const RescoreArgs&, int, uint32_t*, uint32_t*, unsigned long long*, hipStream_t);
 int launch_rescore_dense(const RescoreArgs&, const uint32_t*, const uint32_t*, long long, hipStream_t,
                          const unsigned long long* n_dev = nullptr);

@@ -744,6 +744,37 @@ __global__ __launch_bounds__(256) void rescore_dense_kernel(RescoreArgs a, const
     if (blockIdx.x == 0 && threadIdx.x == 0 && !n_dev) atomicAdd(a.n_cand_total, (unsigned long long)n);
 }
 
+// How many candidates a launch left in its segments and tail chunks (one workgroup): the host sizes the dense lists
+// of the sort from this number instead of from the list's capacity (round 4: 4 x 16 bytes per unit of CAPACITY went to
+// buffers that a launch fills to a few percent).  An overflowed launch counts 0 (nothing of it is re-scored).
+__global__ __launch_bounds__(1024) void cand_count_kernel(RescoreArgs a, int n_chunks_max, unsigned long long* n_out) {
+    __shared__ unsigned long long red[16];
+    unsigned long long s = 0;
+    if (!*a.overflow) {
+        for (int b = threadIdx.x; b < a.n_seg; b += 1024) s += (unsigned long long)max(0, min(a.seg_count[b], a.seg_cap));
+        const unsigned long long nt = *a.tail_count;
+        if ((long long)nt <= a.tail_cap) {
+            const long long used = (long long)((nt + (1ull << a.tail_shift) - 1) >> a.tail_shift);
+            for (long long c = threadIdx.x; c < used && c < n_chunks_max; c += 1024) s += (unsigned long long)max(0, a.tail_fill[c]);
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long t = 0;
+        for (int w = 0; w < 16; ++w) t += red[w];
+        *n_out = t;
+    }
+}
+
+int launch_cand_count(const RescoreArgs& a, int n_chunks_max, unsigned long long* n_out, hipStream_t stream) {
+    hipLaunchKernelGGL(cand_count_kernel, dim3(1), dim3(1024), 0, stream, a, n_chunks_max, n_out);
+    VSC_HIP(hipGetLastError());
+    return VSC_OK;
+}
+
 int launch_cand_compact(const RescoreArgs& a, int n_chunks_max, uint32_t* key_j, uint32_t* val_i, unsigned long long* n_out,
                         hipStream_t stream) {
     VSC_HIP(hipMemsetAsync(n_out, 0, sizeof(unsigned long long), stream));

@@ -229,6 +229,13 @@ def sharded_hits(local_search, local_matrix_size: int, k_global: int, group=None
     its K best can be among the global K best).  Every rank leaves the loop on the same, all-reduced
     flag.  Returns (i, j, s, tau) = this rank's share of the global top-K (ties="all": including every
     hit tied with tau, see distributed_prefix_select).
+
+    local_search may return a fifth element, True for a SEEDED search (engine.DeviceMatcher.seed_radius: the rank
+    searched with the full budget k_global from a radius agreed over a row sample instead of replaying the
+    reference's doubling schedule; k_local is ignored).  Its list holds every local hit beyond the returned radius,
+    cut at k_global: exact when it is full (k_global hits: nothing beyond a rank's K best can be among the global K
+    best) or when the global cut lies strictly beyond that radius; otherwise -- the seed was too high -- the rank
+    retries, and local_search is expected to answer the retry with the unseeded search.
     """
     rank, world = _world(group)
     # A rank's share of the global top-K is K/world up to sampling noise when the shards are alike; the
@@ -240,18 +247,24 @@ def sharded_hits(local_search, local_matrix_size: int, k_global: int, group=None
     cached = None
     while True:
         if cached is None:
-            hi, hj, hs, radius = local_search(k_local)
+            res = local_search(k_local)
+            hi, hj, hs, radius = res[:4]
+            seeded = len(res) > 4 and bool(res[4])
             n = int(hs.numel())
+            full = False
             if n >= local_matrix_size:
                 complete_above = float("-inf")      # the whole local matrix was kept
+            elif seeded:
+                complete_above = float(radius)      # every local hit beyond the radius is listed (cut at k_global)
+                full = n >= k_global
             elif n >= k_local:
                 complete_above = float(hs[-1].item())  # truncated at k_local: ties with the last may be missing
             else:
                 complete_above = float(radius)      # hits <= radius were dropped by the schedule
-            cached = (hi, hj, hs, complete_above)
-        hi, hj, hs, complete_above = cached
+            cached = (hi, hj, hs, complete_above, seeded, full)
+        hi, hj, hs, complete_above, seeded, full = cached
         n_take, tau, exact = merge_hits(hs, k_global, complete_above, group, ties)
-        exact = exact or k_local >= k_global
+        exact = exact or full or (k_local >= k_global and not seeded)
         all_exact = all_reduce_max_int(0 if exact else 1, hs.device if device is None else device, group) == 0
         if all_exact:
             return hi[:n_take], hj[:n_take], hs[:n_take], tau

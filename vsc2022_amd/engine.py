@@ -171,20 +171,60 @@ class DeviceMatcher:
             self._tn = None
 
     # ---- stages (all tensors stay in HBM)
-    def search(self, K: int):
-        """vsc/index.py:142-165 over the resident queries: (i, j, s) sorted hits + final radius."""
-        cap = int(max(1, min(K, self.q_feats.shape[0] * max(self.index.ntotal, 1))))
-        oi = self._buf("hit_i", cap, torch.int32)
-        oj = self._buf("hit_j", cap, torch.int32)
-        os_ = self._buf("hit_s", cap, torch.float32)
+    def search(self, K: int, seed_radius: Optional[float] = None, rows: Optional[torch.Tensor] = None):
+        """vsc/index.py:142-165 over the resident queries: (i, j, s) sorted hits + final radius.
+
+        seed_radius: a radius known to lie below the K-th best score (sharded pipeline): the rows run as steady
+        batches from there (`vsc_index_global_topk_seeded`) instead of replaying the doubling schedule.
+        rows: search these query rows instead (an [n, dim] tensor in HBM; row numbers are relative to it)."""
+        q = self.q_feats if rows is None else rows.to(self.tdev, torch.float32).contiguous()
+        nq = int(q.shape[0])
+        cap = int(max(1, min(K, nq * max(self.index.ntotal, 1))))
+        tag = "hit" if rows is None else "shit"
+        oi = self._buf(tag + "_i", cap, torch.int32)
+        oj = self._buf(tag + "_j", cap, torch.int32)
+        os_ = self._buf(tag + "_s", cap, torch.float32)
         n_out, radius = ctypes.c_int64(0), ctypes.c_float(0.0)
         torch.cuda.synchronize(self.tdev)
-        _lib.check(_lib.lib().vsc_index_global_topk(
-            self.index.handle, _dev_ptr(self.q_feats), int(self.q_feats.shape[0]), _lib.MEM_DEVICE, int(K),
-            _dev_ptr(oi), _dev_ptr(oj), _dev_ptr(os_), cap, _lib.MEM_DEVICE, ctypes.byref(n_out),
-            ctypes.byref(radius)))
+        if seed_radius is None:
+            _lib.check(_lib.lib().vsc_index_global_topk(
+                self.index.handle, _dev_ptr(q), nq, _lib.MEM_DEVICE, int(K),
+                _dev_ptr(oi), _dev_ptr(oj), _dev_ptr(os_), cap, _lib.MEM_DEVICE, ctypes.byref(n_out),
+                ctypes.byref(radius)))
+        else:
+            _lib.check(_lib.lib().vsc_index_global_topk_seeded(
+                self.index.handle, _dev_ptr(q), nq, _lib.MEM_DEVICE, int(K), float(seed_radius),
+                _dev_ptr(oi), _dev_ptr(oj), _dev_ptr(os_), cap, _lib.MEM_DEVICE, ctypes.byref(n_out),
+                ctypes.byref(radius)))
         m = n_out.value
         return oi[:m], oj[:m], os_[:m], radius.value
+
+    def seed_radius(self, K: int, group=None) -> Optional[float]:
+        """A radius just below the K-th best score of the GLOBAL score matrix, estimated over a strided sample of every
+        rank's query rows (same stride everywhere): each rank searches its sample with the reference's schedule, the
+        1.25 * K * (sample share)-th best score over all ranks' sample hits is found with the exact distributed
+        selection (two histogram all-reduces + one all-gather of tie counts).  None when the query set is too small for
+        a sample to pay (then the ranks replay the schedule as before).  An estimate, never trusted: the caller checks
+        the seeded result with the same exactness test as any other local search and falls back when it fails."""
+        nq_loc = int(self.q_feats.shape[0])
+        tot_rows = vdist.all_reduce_sum_int(nq_loc, self.tdev, group)
+        target = int(os.environ.get("VSC_SHARD_SEED_ROWS", "4096"))  # sample rows over all ranks
+        stride = tot_rows // max(target, 1)
+        if stride < 4 or self.index.ntotal == 0:
+            return None
+        pick = torch.arange(0, nq_loc, stride, device=self.tdev)
+        s_loc = int(pick.numel())
+        s_tot = vdist.all_reduce_sum_int(s_loc, self.tdev, group)
+        k_tot = int(np.ceil(1.25 * K * s_tot / tot_rows))
+        if s_loc:
+            k_s = int(min(s_loc * self.index.ntotal, np.ceil(2.0 * K * s_loc / tot_rows) + 1024))
+            _, _, sc, _ = self.search(k_s, rows=self.q_feats.index_select(0, pick))
+        else:
+            sc = torch.zeros(0, dtype=torch.float32, device=self.tdev)
+        _, tau = vdist.distributed_prefix_select(sc, k_tot, group)
+        if not np.isfinite(tau):
+            return None
+        return float(np.nextafter(np.float32(tau), np.float32(-np.inf)))
 
     def pair_max(self, hi, hj, hs):
         """vsc/index.py:121-140 + vsc/candidates.py:24-40 on device hits."""
@@ -245,8 +285,17 @@ class DeviceMatcher:
                                pq[:n_cand], pr[:n_cand], ps[:n_cand],
                                torch.arange(n_loc, device=self.tdev), nbox, boxes, bmax, radius)
         radius_box = [float("nan")]
+        # The sharded result is the exact global top-K (vsc2022_amd/dist.py), not the reference's tie-dropping schedule,
+        # so a rank need not replay the 32, 64, ... doubling batches on its own rows: a radius agreed over a row sample
+        # seeds every rank's FIRST local search; a retry (seed too high, skewed shard) takes the unseeded search.
+        seed = [self.seed_radius(K, group) if os.environ.get("VSC_SHARD_SEED", "1") != "0" else None]
 
         def local_search(k_local):
+            if seed[0] is not None:
+                i, j, sc, rad = self.search(K, seed_radius=seed[0])  # (full budget: see dist.sharded_hits)
+                seed[0] = None
+                radius_box[0] = rad
+                return i, j, sc, rad, True
             i, j, sc, rad = self.search(k_local)
             radius_box[0] = rad
             return i, j, sc, rad

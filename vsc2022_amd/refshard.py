@@ -64,9 +64,9 @@ class RefShardedIndex:
         n = int(x.shape[0])
         n_loc = int(self.local.ntotal)
         on_gpu = self.device.type == "cuda"
-        if getattr(self.local, "metric_type", 0) == 1:
-            raise NotImplementedError("the reference-sharded merge orders by larger-is-better scores (inner product)")
-        # missing slots carry the single index's sentinel (-FLT_MAX and id -1, include/vscmi.h), not -inf
+        # L2: distances ascend -- merge their negation (larger is better, ties by id ascending either way) and negate back
+        l2 = getattr(self.local, "metric_type", 0) == 1
+        # missing slots carry the single index's sentinel (-/+FLT_MAX and id -1, include/vscmi.h), not -/+inf
         D = torch.full((n, k), -float(np.finfo(np.float32).max), dtype=torch.float32, device=self.device)
         I = torch.full((n, k), -1, dtype=torch.int64, device=self.device)
         kk = min(k, n_loc)
@@ -75,9 +75,11 @@ class RefShardedIndex:
                 d, i = self.local.search(x, kk, device_out=True)  # stays in HBM until the all-gather
             else:
                 d, i = (torch.from_numpy(np.ascontiguousarray(a)) for a in self.local.search(x, kk))
-            D[:, :kk] = d
+            D[:, :kk] = -d if l2 else d
             I[:, :kk] = torch.where(i >= 0, i + self.row0, torch.full_like(i, -1))
         gD, gI = vdist.ref_sharded_knn(D, I, k, self.group)
+        if l2:
+            gD = -gD
         return gD.cpu().numpy(), gI.cpu().numpy()
 
     # ---- global top-K of the whole score matrix

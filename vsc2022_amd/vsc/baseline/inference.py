@@ -308,6 +308,12 @@ class FastSSCD(nn.Module):
             p.requires_grad_(False)
 
     def forward(self, x):
+        # the hand-written kernels launch on torch's current stream OF THE TENSOR'S DEVICE and never switch devices
+        # themselves: make that device current for the whole pass (a caller may sit on another one)
+        with torch.cuda.device(x.device):
+            return self._forward(x)
+
+    def _forward(self, x):
         x = self.stem_conv(x.to(torch.bfloat16).contiguous(memory_format=torch.channels_last))
         if _FUSED_POOL and x.permute(0, 2, 3, 1).is_contiguous():
             x = _pool_bias_relu(x, self.stem_bias)                                        # bias + relu + max-pool, one pass
