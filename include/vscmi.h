@@ -81,7 +81,7 @@ int vsc_device_count(void);
  *   VSC_I8_EXCLUDE=0          keep coordinates on which all references agree inside the int8 images
  *   VSC_I8_SORT=0             int8 launches see their rows in batch order (default: sorted by threshold / scale)
  *   VSC_I8P_ORDER=0           panel-major work items with stealing (default 1: slice-major)
- *   VSC_I8P_SLICE=n           col-steps of 512 reference rows per work item (default 16 slice-major)
+ *   VSC_I8P_SLICE=n           col-steps of 512 reference rows per work item (default 32 slice-major)
  *   VSC_I8_SCREEN=1           fp16 screen between the int8 pre-filter and the exact stage (measured neutral: off)
  *   VSC_I8_KNN=0              k-NN threshold passes on the fp16 kernel
  *   VSC_RESCORE_SORT=0        exact stage over the waves' candidate segments as they are (default: compacted and

@@ -155,6 +155,10 @@ struct vsc_index {
     ExcludedDims i8_ex;
     bool i8_dirty = false;
     int64_t i8_rows = 0;  // rows [0, i8_rows) of the image are current
+    // rows [i8_seen, ntotal) have been added but not yet folded into the per-coordinate min / max nor quantised: `add`
+    // only packs rows, the first search afterwards catches up in one go (a dim_minmax pass, two copies to
+    // the host and two stream syncs PER ADD made many small adds -- one per video -- slow)
+    int64_t i8_seen = 0;
     unsigned long long stat_i8_fallbacks = 0;
     // tuning / A-B switches of the pre-filtered routes, read from the environment when the handle is created
     // (include/vscmi.h lists them)
@@ -544,16 +548,20 @@ int vsc_index_add(vsc_index_t* idx, const float* x, int64_t n, int x_mem) {
     }
     VSC_TRY(pack_into(x, n, idx->dim, x_mem, dst, need_rows - idx->ntotal, idx->dpad, idx->ws, idx->stream, h));
     VSC_HIP(hipStreamSynchronize(idx->stream));
-    const int64_t first_new = idx->ntotal;
-    idx->ntotal += n;
-    if (idx->i8_mode) VSC_TRY(i8_after_add(idx, first_new, n, need_rows));
+    idx->ntotal += n;  // (the int8 image catches up in i8_prepare, before the next search)
     return VSC_OK;
 }
 
 // Call before a search that may use the int8 kernel: brings the image up to date when the set of excluded
 // coordinates changed since it was written.
 static int i8_prepare(vsc_index* idx) {
-    if (!idx->i8_mode || !idx->i8_dirty) return VSC_OK;
+    if (!idx->i8_mode) return VSC_OK;
+    if (idx->i8_seen < idx->ntotal) {
+        const int64_t first_new = idx->i8_seen;
+        idx->i8_seen = idx->ntotal;
+        VSC_TRY(i8_after_add(idx, first_new, idx->ntotal - first_new, round_up64(idx->ntotal, ROW_PAD_REF)));
+    }
+    if (!idx->i8_dirty) return VSC_OK;
     idx->i8_loose_sum = idx->i8_loose_cnt = 0.0;
     VSC_TRY(i8_quantise(idx, 0, round_up64(idx->ntotal, ROW_PAD_REF), idx->ntotal));
     idx->i8_dirty = false;
@@ -677,12 +685,14 @@ static int enqueue_f16(vsc_index* idx, const float* qpacked, int64_t i0, int64_t
             SimI8PArgs f;
             sim_f16p_plan(nqb, nrefs, &f.npanel, &f.nsteps, &f.slice, &grid);
             {
-                // work order: slice-major items of 16 col-steps (4 MiB of the int8 image at 512-d: what an XCD's L2
-                // holds) measured +3 % on the bench (2431 -> 2507-2515 TOP/s; 8: +2 %, 32: +2 %, 4 and 64: -1 / 0 %) and
-                // -6 % on the 1-NN of score normalisation; VSC_I8P_ORDER=0: panel-major with stealing as in sim_f16p
+                // work order: slice-major items.  r03 (32x32x32 kernel): items of 16 col-steps (4 MiB of the int8 image at
+                // 512-d: what an XCD's L2 holds) +3 % on the bench over panel-major (2431 -> 2507-2515 TOP/s).  r04
+                // (16x16x64 kernel, configs[3]): 8 / 16 / 32 / 64 col-steps 2456 / 2390 / 2363 / 2368 ms per query set
+                // -- the faster K loop makes the hand-over (panel load + two barriers) the larger share: 32.
+                // VSC_I8P_ORDER=0: panel-major with stealing as in sim_f16p
                 const int slice_env = idx->i8p_slice;
                 f.order = idx->i8p_order;
-                if (f.order == 1) f.slice = std::max(1, std::min(f.nsteps, slice_env > 0 ? slice_env : 16));
+                if (f.order == 1) f.slice = std::max(1, std::min(f.nsteps, slice_env > 0 ? slice_env : 32));
                 else if (slice_env > 0) f.slice = std::max(1, std::min(f.nsteps, slice_env));
             }
             VSC_TRY(idx->ws.slices.reserve(((size_t)f.npanel + 1) * sizeof(int)));

@@ -129,27 +129,45 @@ int launch_pack_half_frag(const float* src, int64_t n, int dim, _Float16* image,
     return VSC_OK;
 }
 
-// One wave per row.  The squared norm is the ascending-k fp32 fma chain (the oracle's order), so a
-// single lane walks the row for the norm; the division is done by all lanes.  Rows are short
-// (<= a few KB) and the kernel is bandwidth-trivial next to the search.
+// The squared norm is the ascending-k fp32 fma chain (the oracle's order): one chain per row, sequential by
+// definition.  One LANE per row: a wave owns 64 rows and walks them 64 columns at a time -- the chunk is read with
+// coalesced 256-byte row segments into a padded LDS tile, then every lane runs the next 64 links of ITS row's chain
+// out of the tile (column stride 65 words: conflict-free).  Second sweep (the rows are L2-hot): divide and write,
+// coalesced again.  Round 3's kernel gave a whole wave to a row and let lane 0 walk it alone: 14-28 ms per 1 M rows of
+// 511 floats (the score normalisation of configs[3]'s query set), against ~1.5 ms of traffic.
 __global__ __launch_bounds__(256) void row_normalize_kernel(const float* __restrict__ x, int64_t n,
                                                             int dim, float* __restrict__ out) {
-    const int lane = threadIdx.x & 63;
-    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= n) return;
-    const float* r = x + row * dim;
+    __shared__ float tile[4][64][65];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t row0 = ((int64_t)blockIdx.x * 4 + wave) * 64;
+    if (row0 >= n) return;
+    const int rows = (int)min((int64_t)64, n - row0);
+    float (*t)[65] = tile[wave];
     float acc = 0.0f;
-    if (lane == 0)
-        for (int k = 0; k < dim; ++k) acc = __fmaf_rn(r[k], r[k], acc);
-    acc = __shfl(acc, 0);
+    for (int c0 = 0; c0 < dim; c0 += 64) {
+        const int k = c0 + lane;
+        for (int r = 0; r < rows; ++r) t[r][lane] = k < dim ? x[(row0 + r) * dim + k] : 0.0f;
+        __builtin_amdgcn_wave_barrier();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        const int kn = min(64, dim - c0);
+        if (lane < rows)
+            for (int kk = 0; kk < kn; ++kk) acc = __fmaf_rn(t[lane][kk], t[lane][kk], acc);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+    }
     float nrm = sqrtf(acc);  // correctly rounded (__fsqrt_rn maps to the approximate native sqrt)
     if (nrm == 0.0f) nrm = 1.0f;
-    for (int k = lane; k < dim; k += 64) out[row * dim + k] = r[k] / nrm;
+    for (int r = 0; r < rows; ++r) {
+        const float d = __shfl(nrm, r);
+        const float* src = x + (row0 + r) * dim;
+        float* dst = out + (row0 + r) * dim;
+        for (int k = lane; k < dim; k += 64) dst[k] = src[k] / d;
+    }
 }
 
 int launch_row_normalize(const float* x, int64_t n, int dim, float* out, hipStream_t stream) {
     if (n <= 0) return VSC_OK;
-    hipLaunchKernelGGL(row_normalize_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, stream, x, n,
+    hipLaunchKernelGGL(row_normalize_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, x, n,
                        dim, out);
     VSC_HIP(hipGetLastError());
     return VSC_OK;

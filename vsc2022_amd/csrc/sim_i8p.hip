@@ -40,6 +40,10 @@ typedef int i32x4 __attribute__((ext_vector_type(4)));
 
 namespace i8p {
 
+#ifndef VSC_I8P_ABLATE  // timing experiments only (scripts/experiments): 1 = no candidate emission, 2 = no block maxima
+#define VSC_I8P_ABLATE 0  // and no emission either -- both give WRONG results
+#endif
+
 constexpr int PR = F16P_PANEL_ROWS;  // 128
 constexpr int CSW = F16P_COL_STEP;   // 512
 #ifndef VSC_I8P_PF
@@ -187,9 +191,14 @@ __device__ __forceinline__ void emit_candidates(const SimI8PArgs& a, const int (
         }
 #pragma unroll
         for (int m = 0; m < MB; ++m) {
+            // a block is tested against the tile's common threshold first: a block's own threshold is never below it
+            // (rt16[m] >= the panel's smallest row threshold, and column_threshold is monotone in t), so the
+            // arithmetic of the block's threshold is spent only on blocks that can hold a candidate (PMC, round 4: with
+            // it on every block of a passing column block the kernel issued 316 VALU per tile against the skeleton's 67)
+            const int bmx = max(max(max(acc[m][n][0], acc[m][n][1]), acc[m][n][2]), acc[m][n][3]);
+            if (!__any(bmx > tc[n])) continue;
             const int tb = ROWTHR ? column_threshold<true>(rt16[m], eps_c, inv_c) : tc[n];
-            const int bmx = max(max(acc[m][n][0], acc[m][n][1]), max(acc[m][n][2], acc[m][n][3]));
-            if (!__any(bmx > tb)) continue;
+            if (ROWTHR && !__any(bmx > tb)) continue;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const bool hit = acc[m][n][r] > tb;
@@ -242,9 +251,14 @@ __device__ __forceinline__ void emit_candidates_seg(const SimI8PArgs& a, const i
         }
 #pragma unroll
         for (int m = 0; m < MB; ++m) {
+            // a block is tested against the tile's common threshold first: a block's own threshold is never below it
+            // (rt16[m] >= the panel's smallest row threshold, and column_threshold is monotone in t), so the
+            // arithmetic of the block's threshold is spent only on blocks that can hold a candidate (PMC, round 4: with
+            // it on every block of a passing column block the kernel issued 316 VALU per tile against the skeleton's 67)
+            const int bmx = max(max(max(acc[m][n][0], acc[m][n][1]), acc[m][n][2]), acc[m][n][3]);
+            if (!__any(bmx > tc[n])) continue;
             const int tb = ROWTHR ? column_threshold<true>(rt16[m], eps_c, inv_c) : tc[n];
-            const int bmx = max(max(acc[m][n][0], acc[m][n][1]), max(acc[m][n][2], acc[m][n][3]));
-            if (!__any(bmx > tb)) continue;
+            if (ROWTHR && !__any(bmx > tb)) continue;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const bool cand = acc[m][n][r] > tb;
@@ -272,6 +286,9 @@ __global__ __launch_bounds__(512) void sim_i8p_kernel(SimI8PArgs a) {
     __shared__ float rt_sh[ROWTHR ? PR : 1];
     __shared__ int item_sh[2];
     __shared__ TailExt tail_sh[8];
+#if VSC_I8P_ABLATE
+    __shared__ volatile int ablate_sink;
+#endif
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     constexpr int NK4 = NKC * 4;
@@ -425,18 +442,43 @@ __global__ __launch_bounds__(512) void sim_i8p_kernel(SimI8PArgs a) {
             // ... and the thresholds of the four columns this lane holds accumulators of
             int tc[CB], cm[CB];
             bool any_col = false;
+#if VSC_I8P_ABLATE == 2
 #pragma unroll
             for (int n = 0; n < CB; ++n) {
-                tc[n] = bperm(n * 16 + (lane & 15), t_own);
-                // the lane's 32 accumulators of this column block (8 row blocks x 4 registers): 16 v_max3
-                int x = max(max(acc[0][n][0], acc[0][n][1]), acc[0][n][2]);
-#pragma unroll
-                for (int k = 3; k < 31; k += 2) x = max(max(x, acc[k >> 2][n][k & 3]), acc[(k + 1) >> 2][n][(k + 1) & 3]);
-                x = max(x, acc[7][n][3]);
-                cm[n] = x;
-                any_col |= x > tc[n];
+                // no maxima: one accumulator of every block stands in for the block (keeps the MFMAs alive)
+                tc[n] = t_own;
+                int y = acc[0][n][0];
+                for (int m = 1; m < MB; ++m) y |= acc[m][n][m & 3];
+                cm[n] = y;
+                any_col |= y == 0x12345678;
             }
-            if (__any(any_col)) {
+#else
+#pragma unroll
+            for (int n = 0; n < CB; ++n) tc[n] = bperm(n * 16 + (lane & 15), t_own);
+            // the lane's 32 accumulators of each column block (8 row blocks x 4 registers): 16 v_max3 per block, the
+            // four blocks' chains advanced together (a chain of dependent v_max3 issues every ~8 cycles, four
+            // independent ones keep the VALU fed).  Measured (round 4, -DVSC_I8P_ABLATE): these maxima + the threshold
+            // distribution cost 9 % of the kernel, the emission of this workload's candidates 1 %; starting the second
+            // wave of every SIMD 2000-4000 cycles late so that the two waves' epilogues do not coincide: +-0
+            {
+                int x[CB];
+#pragma unroll
+                for (int n = 0; n < CB; ++n) x[n] = max(max(acc[0][n][0], acc[0][n][1]), acc[0][n][2]);
+#pragma unroll
+                for (int k = 3; k < 31; k += 2)
+#pragma unroll
+                    for (int n = 0; n < CB; ++n) x[n] = max(max(x[n], acc[k >> 2][n][k & 3]), acc[(k + 1) >> 2][n][(k + 1) & 3]);
+#pragma unroll
+                for (int n = 0; n < CB; ++n) {
+                    cm[n] = max(x[n], acc[7][n][3]);
+                    any_col |= cm[n] > tc[n];
+                }
+            }
+#endif
+#if VSC_I8P_ABLATE
+            if (__any(any_col) && lane == 0) ablate_sink = col0;  // (keeps the accumulators alive)
+#endif
+            if (VSC_I8P_ABLATE == 0 && __any(any_col)) {
                 const bool interior = panel * PR + PR <= a.nq && col0 + 64 <= a.nr;
                 if (interior && count + 8192 <= a.seg_cap) {
                     emit_candidates_seg<ROWTHR>(a, tc, cm, rt16, eps_own, inv_own, panel * PR, col0, acc, rs_ci, rs_cj, count);
@@ -449,6 +491,9 @@ __global__ __launch_bounds__(512) void sim_i8p_kernel(SimI8PArgs a) {
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the stream ran a few steps past its end)
     tail_close(a.tail_base, a.tail_shift, a.tail_fill, lane, &tail_sh[wave]);
+#if VSC_I8P_ABLATE
+    if (ablate_sink == 0x7fffffff) count = -1;
+#endif
     if (lane == 0) a.seg_count[seg] = count;
 }
 
