@@ -37,8 +37,12 @@ def _result_arrays(res):
                 bscore=res.box_score.cpu().numpy(), n=np.array([res.n_hits, res.n_candidates, res.n_localized, res.n_matches]))
 
 
-def _worker(rank, world, port, out_dir, seed):
+def _worker(rank, world, port, out_dir, seed, seed_rows):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), LOCAL_RANK="0")
+    if seed_rows:
+        # a sample of `seed_rows` rows over all ranks seeds every rank's local search (engine.DeviceMatcher.seed_radius);
+        # by default these query sets are too small for the sample to be taken
+        os.environ["VSC_SHARD_SEED_ROWS"] = str(seed_rows)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         sys.path.insert(0, ROOT)
@@ -58,8 +62,8 @@ def _worker(rank, world, port, out_dir, seed):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("seed,world", [(5, 2), (6, 3), (7, 2)])
-def test_sharded_engine_equals_single_process(gpu, tmp_path, seed, world):
+@pytest.mark.parametrize("seed,world,seed_rows", [(5, 2, 0), (6, 3, 0), (7, 2, 0), (5, 2, 120), (6, 3, 40), (7, 2, 300), (7, 3, 12)])
+def test_sharded_engine_equals_single_process(gpu, tmp_path, seed, world, seed_rows):
     from vsc2022_amd.engine import DeviceMatcher
 
     q, r = _data(seed)
@@ -71,7 +75,7 @@ def test_sharded_engine_equals_single_process(gpu, tmp_path, seed, world):
     del m
     torch.cuda.empty_cache()
     port = 29650 + os.getpid() % 500
-    mp.spawn(_worker, args=(world, port, str(tmp_path), seed), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, port, str(tmp_path), seed, seed_rows), nprocs=world, join=True)
     parts = [np.load(tmp_path / f"rank{k}.npz") for k in range(world)]
     for p in parts:  # every rank holds the same global candidate table = the single-process one
         assert np.array_equal(p["cq"], single["cq"]) and np.array_equal(p["cr"], single["cr"])
