@@ -499,12 +499,16 @@ int vsc_index_add(vsc_index_t* idx, const float* x, int64_t n, int x_mem) {
         DevBuf nb, nh, nn, n8, n8m;
         VSC_TRY(nb.reserve((size_t)cap * idx->dpad * 4));
         if (idx->prefilter) {
-            VSC_TRY(nh.reserve((size_t)cap * idx->dpadh * 2));
-            VSC_TRY(nn.reserve((size_t)cap * 4));
+            // (+ one col-step of rows: a launch over the reference range [b, e) walks whole col-steps FROM b, and b is
+            // only tile-aligned when the tests force the k-NN's levels on small indexes -- the per-row tables are read
+            // with plain loads up to b + round_up(e - b, 512) <= cap + 511; the images go through bounds-checked
+            // buffer descriptors)
+            VSC_TRY(nh.reserve((size_t)(cap + F16P_COL_STEP) * idx->dpadh * 2));
+            VSC_TRY(nn.reserve((size_t)(cap + F16P_COL_STEP) * 4));
         }
         if (idx->i8_mode) {
-            VSC_TRY(n8.reserve((size_t)cap * idx->dpad8));
-            VSC_TRY(n8m.reserve((size_t)cap * sizeof(float4)));
+            VSC_TRY(n8.reserve((size_t)(cap + F16P_COL_STEP) * idx->dpad8));
+            VSC_TRY(n8m.reserve((size_t)(cap + F16P_COL_STEP) * sizeof(float4)));
         }
         if (idx->ntotal > 0) {
             VSC_HIP(hipMemcpyAsync(nb.p, idx->ref.p, (size_t)idx->ntotal * idx->dpad * 4,
@@ -658,10 +662,18 @@ extern "C" {
 // with score > *radius -- or, when `row_thr` (one threshold per query row, padded like the fp16 query
 // image) is given, with score >= row_thr[row].
 static int enqueue_f16(vsc_index* idx, const float* qpacked, int64_t i0, int64_t i1, int64_t cap,
-                       const float* row_thr, int64_t ccap = -1, int64_t nr_limit = -1, bool use_i8 = false) {
+                       const float* row_thr, int64_t ccap = -1, int64_t nr_limit = -1, bool use_i8 = false,
+                       int64_t nr_begin = 0) {
     if (ccap < 0) ccap = cap;  // capacity of the candidate list (cap: of the hit list)
-    // nr_limit: search only the first nr_limit reference rows (threshold refinement of the k-NN)
-    const int64_t nrefs = nr_limit >= 0 ? std::min<int64_t>(nr_limit, idx->ntotal) : idx->ntotal;
+    // [nr_begin, nr_limit): search only these reference rows (the levels of the k-NN); nr_begin a multiple of 64
+    // (whole wave tiles of the fragment-major images).  The kernels see the images from row nr_begin on and emit
+    // refs relative to it; the exact stage adds the offset back (RescoreArgs::j0).
+    const int64_t nr_end = nr_limit >= 0 ? std::min<int64_t>(nr_limit, idx->ntotal) : idx->ntotal;
+    if (nr_begin < 0 || nr_begin % 64 != 0 || nr_begin > nr_end) {
+        set_error("enqueue_f16: reference range [%lld, %lld) does not start on a 64-row tile", (long long)nr_begin, (long long)nr_end);
+        return VSC_ERR_INVALID;
+    }
+    const int64_t nrefs = nr_end - nr_begin;  // rows the kernels see
     SelectCtl* ctl = idx->ws.ctl.as<SelectCtl>();
     const int nqb = (int)(i1 - i0);
     {
@@ -736,8 +748,8 @@ static int enqueue_f16(vsc_index* idx, const float* qpacked, int64_t i0, int64_t
                                               idx->ws.pstat.as<float4>(), perm, thr_src, rt_pos, idx->i8_ex, idx->stream));
             f.Q = idx->ws.q8.p;
             f.pstat = idx->ws.pstat.as<float4>();
-            f.Rf = idx->ref8.p;
-            f.rmeta = idx->ref8m.as<float4>();
+            f.Rf = static_cast<const char*>(idx->ref8.p) + nr_begin * idx->dpad8;  // (whole 64-row tiles: dpad8 x 64 B each)
+            f.rmeta = idx->ref8m.as<float4>() + nr_begin;
             f.dpad8 = idx->dpad8;
             f.nq = nqb;
             f.i0 = (int)i0;
@@ -757,9 +769,9 @@ static int enqueue_f16(vsc_index* idx, const float* qpacked, int64_t i0, int64_t
             sim_f16p_plan(nqb, nrefs, &f.npanel, &f.nsteps, &f.slice, &grid);
             VSC_TRY(idx->ws.slices.reserve((size_t)f.npanel * sizeof(int)));
             f.Q = idx->ws.qh.as<_Float16>() + i0 * idx->dpadh;
-            f.Rf = idx->refh.p;
+            f.Rf = static_cast<const char*>(idx->refh.p) + nr_begin * idx->dpadh * 2;
             f.qn = idx->ws.qn.as<float>() + i0;
-            f.rn = idx->refn.as<float>();
+            f.rn = idx->refn.as<float>() + nr_begin;
             f.dpadh = idx->dpadh;
             f.nq = nqb;
             f.i0 = (int)i0;
@@ -775,9 +787,9 @@ static int enqueue_f16(vsc_index* idx, const float* qpacked, int64_t i0, int64_t
             // dims > 512: 256x256 LDS-ring kernel (sim_f16.hip) on the natural image
             SimF16Args f;
             f.Q = idx->ws.qh.as<_Float16>() + i0 * idx->dpadh;
-            f.R = idx->refh.as<_Float16>();
+            f.R = idx->refh.as<_Float16>() + nr_begin * idx->dpadh;
             f.qn = idx->ws.qn.as<float>() + i0;
-            f.rn = idx->refn.as<float>();
+            f.rn = idx->refn.as<float>() + nr_begin;
             f.dpadh = idx->dpadh;
             f.nq = nqb;
             f.i0 = (int)i0;
@@ -819,6 +831,7 @@ static int enqueue_f16(vsc_index* idx, const float* qpacked, int64_t i0, int64_t
         r.cap = cap;
         r.overflow = &ctl->overflow;
         r.row_thr = row_thr;
+        r.j0 = (int)nr_begin;
         VSC_TRY(prof_begin(idx, &stop, 2));
         // The candidates are compacted out of the waves' segments, sorted by reference row and re-scored as one dense
         // list (sim_f16.hip, "candidates ordered by reference row"): 74 -> 54 ms per bench step, k-NN k = 20 140 ->
@@ -843,7 +856,7 @@ static int enqueue_f16(vsc_index* idx, const float* qpacked, int64_t i0, int64_t
                                         idx->ws.csn.as<unsigned long long>(), idx->stream));
             const uint32_t *sj = nullptr, *si = nullptr;
             VSC_TRY(sort_candidates_by_ref(idx->ws.cs[0].as<uint32_t>(), idx->ws.cs[1].as<uint32_t>(), idx->ws.cs[2].as<uint32_t>(),
-                                           idx->ws.cs[3].as<uint32_t>(), (int64_t)n_c, nrefs, idx->ws.cstmp, &sj, &si, idx->stream));
+                                           idx->ws.cs[3].as<uint32_t>(), (int64_t)n_c, nr_end, idx->ws.cstmp, &sj, &si, idx->stream));
             // VSC_I8_SCREEN=1: int8 launches pass an fp16 screen first (sim_f16.hip: f16_screen_kernel).  Measured
             // neutral and therefore OFF by default: 29 % of the int8 candidates survive it (bench, 128 M -> 37 M per
             // step), the screen moves half the bytes per pair (23.8 ms) and the exact stage then costs 35.6 instead of
@@ -1230,36 +1243,36 @@ static int knn_exact_ip(vsc_index* idx, const float* qp, int64_t nq, int64_t nr,
     return VSC_OK;
 }
 
-// Pre-filtered exact k-NN (inner product).  1. exact k-NN against a SUBSET of the references (the first
-// 1/16): the k-th best score T_i found there is a lower bound of the row's final k-th best.  2. the fp16
-// pre-filter over ALL references passes every pair whose fp16 score + error bound reaches T_i; the exact
-// stage keeps those with exact score >= T_i -- a superset of the final top-k of every row (the subset's own
-// top-k included).  3. (row asc, score desc, ref asc) order, cut at k.  Same result as knn_exact_ip, at the
-// cost of one fp32 pass over 1/16 of the references plus one fp16 pass over all of them.
-// Returns VSC_ERR_OVERFLOW when the hit estimate was too small (the caller then runs the exact kernel).
-// One thresholded pass of the pre-filtered k-NN: fp16 pre-filter + exact stage of all query rows against the first
-// `nrefs` references with the per-row thresholds in ws.rowthr, then (row asc, score desc, ref asc) order cut at k
-// -> ds / dj.  `per_row` = expected hits per query row.  VSC_ERR_OVERFLOW when the estimate was too small.
-static int knn_threshold_pass(vsc_index* idx, const float* qp, int64_t nq, int64_t nrefs, int k, double per_row, float* ds,
-                              int64_t* dj, bool use_i8 = false) {
+// One thresholded pass of the pre-filtered k-NN over the reference rows [r_begin, r_end): pre-filter + exact stage of
+// all query rows with the per-row thresholds in ws.rowthr; the k-NN lists of the rows [0, r_begin) that ds / dj hold
+// (r_begin > 0) re-enter the hit list first, so that the (row asc, score desc, ref asc) sort + cut at k that follows
+// yields the k-NN over [0, r_end) -> ds / dj.  `per_row` = expected hits of the range per query row.
+// VSC_ERR_OVERFLOW when the estimate was too small (ds / dj untouched: the overflow is seen before they are rewritten).
+static int knn_threshold_pass(vsc_index* idx, const float* qp, int64_t nq, int64_t r_begin, int64_t r_end, int k,
+                              double per_row, float* ds, int64_t* dj, bool use_i8 = false) {
     const int64_t step = 32768;
-    int64_t cap = (int64_t)((double)nq * per_row) + (1 << 20);
-    cap = std::min<int64_t>(cap, nq * nrefs + 1024);
+    const int64_t nrange = r_end - r_begin;
+    int64_t cap = (int64_t)((double)nq * per_row) + (r_begin > 0 ? nq * k : 0) + (1 << 20);
+    cap = std::min<int64_t>(cap, nq * (nrange + k) + 1024);
     if (idx->hit_cap_user > 0) cap = idx->hit_cap_user;
     // the candidate list is consumed slab by slab, only the hits accumulate over the whole query set
     const int64_t slab_rows = std::min(nq, step);
     // (the int8 bound is looser: ~4-5x the candidates per hit)
     int64_t ccap = std::min<int64_t>((int64_t)((double)slab_rows * per_row * (use_i8 ? 6.0 : 1.0)) + (1 << 20),
-                                     slab_rows * nrefs + 1024);
+                                     slab_rows * nrange + 1024);
     if (!use_i8) ccap = std::min(ccap, std::max<int64_t>(cap, 1024));
     VSC_TRY(ensure_hit_buffers(idx, cap, ccap, false));
     VSC_TRY(init_ctl(idx, 0.0f));
+    SelectCtl* ctl = idx->ws.ctl.as<SelectCtl>();
+    if (r_begin > 0)
+        VSC_TRY(launch_knn_seed_hits(ds, dj, nq, k, idx->ws.hA[0].as<int32_t>(), idx->ws.hA[1].as<int32_t>(),
+                                     idx->ws.hA[2].as<float>(), &ctl->n, idx->stream));
     for (int64_t i0 = 0; i0 < nq; i0 += step)
-        VSC_TRY(enqueue_f16(idx, qp, i0, std::min(nq, i0 + step), cap, idx->ws.rowthr.as<float>(), ccap, nrefs, use_i8));
+        VSC_TRY(enqueue_f16(idx, qp, i0, std::min(nq, i0 + step), cap, idx->ws.rowthr.as<float>(), ccap, r_end, use_i8, r_begin));
     SelectCtl h;
     VSC_HIP(hipMemcpyAsync(&h, idx->ws.ctl.p, sizeof(h), hipMemcpyDeviceToHost, idx->stream));
     VSC_HIP(hipStreamSynchronize(idx->stream));
-    idx->stat_candidates = h.n_cand_total;
+    idx->stat_candidates += h.n_cand_total;  // (over the ranges of one k-NN: knn_prefiltered resets it)
     if (h.overflow) return VSC_ERR_OVERFLOW;
     VSC_TRY(knn_from_hits(idx->ws.hA[0].as<int32_t>(), idx->ws.hA[1].as<int32_t>(), idx->ws.hA[2].as<float>(),
                           (int64_t)h.n, nq, k, idx->ws.w0, idx->ws.w1, idx->ws.w2, idx->ws.w3, idx->ws.tmp, ds, dj,
@@ -1269,13 +1282,14 @@ static int knn_threshold_pass(vsc_index* idx, const float* qp, int64_t nq, int64
 
 // Pre-filtered exact k-NN (inner product).  Any lower bound T_i of a row's final k-th best score is a valid
 // threshold: the k-th best score against a SUBSET of the references is one.
-//   1. exact fp32 k-NN (sim_knn_kernel) against the first S0 references -> T_i(0);
-//   2. (large problems) the fp16 pre-filter + exact stage over the first S1 >> S0 references with T_i(0), cut at k
-//      -> the much tighter T_i(1): the exact kernel runs at 1/10 of the pre-filter's rate, so a small S0 and one
-//      cheap refinement pass beat a large S0;
-//   3. the pre-filter + exact stage over ALL references with the last T_i: every pair whose fp16 score + error bound
-//      reaches T_i goes to the exact stage, which keeps exact score >= T_i -- a superset of the final top-k of every
-//      row (the subset's own top-k included) --, then (row asc, score desc, ref asc) order, cut at k.
+//   1. exact fp32 k-NN (sim_knn_kernel) against the first S0 references -> lists + thresholds T_i(0);
+//   2. the remaining references in RANGES [S_l, S_l+1) that grow by `ratio` (round 4; round 3 re-searched whole
+//      prefixes): the pre-filter (int8, else fp16) + exact stage over a range with the thresholds of everything before
+//      it -- every pair whose low-precision score + error bound reaches T_i goes to the exact stage, which keeps exact
+//      score >= T_i --, merged with the lists so far by one sort + cut at k -> the lists over [0, S_l+1) and the
+//      tighter T_i(l+1).  Every reference row is visited once; a range brings ~k (ratio - 1) hits per query row (x the
+//      filter's inflation in candidates) whatever its size, so the hits a search re-scores fall from k nr / S_last
+//      (round 3's final pass: 30 per row at k = 1, 139 at k = 20) to ~k (ratio - 1) per level.
 // Same result as knn_exact_ip bit for bit.  Returns VSC_ERR_OVERFLOW when a hit estimate was too small (the caller
 // then runs the exact kernel).
 static int knn_prefiltered(vsc_index* idx, const float* qp, int64_t nq, int k, float* ds, int64_t* dj) {
@@ -1284,59 +1298,51 @@ static int knn_prefiltered(vsc_index* idx, const float* qp, int64_t nq, int k, f
     const bool knn_i8_env = idx->knn_i8;
     bool knn_i8 = idx->i8_mode == 2 || (i8_usable(idx) && knn_i8_env);
     const double subset_factor = idx->knn_subset_factor;
-    const bool two_level = idx->knn_two_level;
+    const bool levels = idx->knn_two_level;
     const int s0_div = idx->knn_s0_div;
-    // one level: S0 = sqrt(300 k nr) balances the exact pass (~2 dim S0 / 1e14 s per row) against the per-hit cost of
-    // the final pass (k nr / S0 hits per row, ~1 ns each).  Two levels: S0 = 16 k (k^2 nr^2 / 3e5)^(1/3) ... in
-    // practice S0 ~ S_one / 7 and S1 = 16 S0 sit on a flat optimum (measured at 200 k x 2 M, k = 1 and 20)
+    // without levels: S0 = sqrt(300 k nr) balances the exact pass (~2 dim S0 / 1e14 s per row) against the per-hit cost of
+    // the one pass over the rest (k nr / S0 hits per row, ~1 ns each).  With levels the exact kernel -- a tenth of the
+    // pre-filter's rate -- only has to get the thresholds started: S0 = that / 7 (at least 4096 rows).
+    // (range boundaries sit on col-steps; on whole 64-row wave tiles when VSC_PREFILTER=2, the tests' switch, forces the
+    // levels on small problems)
+    const int64_t unit = idx->prefilter_force ? 64 : F16P_COL_STEP;
     const int64_t S_one = std::min<int64_t>(
-        nr, round_up64(std::max<int64_t>((int64_t)std::sqrt(subset_factor * k * (double)nr), 4096), ROW_PAD));
-    // (VSC_PREFILTER=2, the tests' switch, also forces the refinement on small problems)
+        nr, round_up64(std::max<int64_t>((int64_t)std::sqrt(subset_factor * k * (double)nr), 4096), unit));
     const int64_t S0_small = std::min<int64_t>(
-        nr, round_up64(std::max<int64_t>(S_one / s0_div, idx->prefilter_force ? (int64_t)k : 4096), ROW_PAD));
-    const bool refine = two_level && (idx->prefilter_force ? nr >= 2 * S0_small
-                                                           : (nr >= 8 * S_one && (double)nq * (double)nr >= 4e10));
+        nr, round_up64(std::max<int64_t>(S_one / s0_div, idx->prefilter_force ? (int64_t)k : 4096), unit));
+    const bool refine = levels && (idx->prefilter_force ? nr >= 2 * S0_small
+                                                        : (nr >= 8 * S_one && (double)nq * (double)nr >= 4e10));
     const int64_t S0 = refine ? S0_small : S_one;
     if (S0 < k) return VSC_ERR_OVERFLOW;
+    idx->stat_candidates = 0;
     VSC_TRY(knn_exact_ip(idx, qp, nq, S0, k, ds, dj));
     const int64_t rows_h = round_up64(nq, ROW_PAD_H) + ROW_PAD_H;
     VSC_TRY(idx->ws.rowthr.reserve((size_t)rows_h * 4));
     VSC_TRY(launch_knn_row_thr(ds, nq, k, idx->ws.rowthr.as<float>(), rows_h, idx->stream));
+    // ranges: [S0, r S0), [r S0, r^2 S0), ... -- the last one runs to nr (and swallows a remainder shorter than half a
+    // range).  Every range costs its share of ONE pass over the references plus k (ratio - 1) hits per row (x the
+    // filter's inflation) and the launches' own overhead (~0.3 ms per 32768-row slab: quantisation, sorts, one sync).
+    // VSC_KNN_RATIO; measured at 200 k x 2 M (profiles/r04_knn_levels.md).
+    const double ratio_env = idx->knn_ratio;
+    const double ratio = !refine ? 1e30 : idx->prefilter_force ? 3.0 : (ratio_env > 1.0 ? ratio_env : 4.0);
     int64_t S_last = S0;
-    if (refine) {
-        // refinement levels: the prefix grows by `ratio` per level until less than a factor 2 is left for the final
-        // pass.  Every level costs one pre-filter pass over its prefix + k * ratio hits per row (x the filter's
-        // inflation in candidates); the int8 bound passes 4-5 candidates per hit, so its optimum is several levels
-        // of ratio ~5 where the fp16 filter (1.1 per hit) wanted one level of 16.
-        const double ratio_env = idx->knn_ratio;
-        // measured at 200 k x 2 M (profiles/r03_knn_levels.md): k = 1: 244 / 249 / 271 ms at ratio 16 / 8 / 5;
-        // k = 20: 500 / 514 / 448 / 448 ms at 16 / 8 / 5 / 4
-        const double ratio = idx->prefilter_force ? 3.0
-                             : (ratio_env > 1.0 ? ratio_env : (knn_i8 ? std::min(16.0, std::max(4.0, 80.0 / (double)k)) : 16.0));
-        for (int level = 0; level < 8; ++level) {
-            const int64_t S1 = std::min<int64_t>(nr, round_up64((int64_t)(ratio * (double)S_last), F16P_COL_STEP));
-            if (S1 <= S_last || 2 * S1 > nr) break;
-            // expected hits per row: k * S1 / S_last (plus the filter's inflation); generous factor
-            const double per_row = (double)k * ((double)S1 / (double)S_last) * 4.0;
-            int rc = knn_threshold_pass(idx, qp, nq, S1, k, per_row, ds, dj, knn_i8);
-            if (rc == VSC_ERR_OVERFLOW && knn_i8 && idx->i8_mode != 2) {
-                // (ds / dj still hold the previous level's lists: the overflow is detected before they are rewritten)
-                knn_i8 = false;
-                idx->stat_i8_fallbacks += 1;
-                rc = knn_threshold_pass(idx, qp, nq, S1, k, per_row, ds, dj, false);
-            }
-            if (rc == VSC_ERR_OVERFLOW) break;  // keep the previous thresholds (ws.rowthr was not touched)
-            if (rc != VSC_OK) return rc;
-            VSC_TRY(launch_knn_row_thr(ds, nq, k, idx->ws.rowthr.as<float>(), rows_h, idx->stream));
-            S_last = S1;
+    while (S_last < nr) {
+        int64_t S1 = ratio >= 1e29 ? nr : std::min<int64_t>(nr, round_up64((int64_t)(ratio * (double)S_last), unit));
+        if (nr - S1 < (S1 - S_last) / 2) S1 = nr;
+        // expected hits of the range per row: k (S1 - S_last) / S_last; generous factor
+        const double per_row = (double)k * ((double)(S1 - S_last) / (double)S_last) * 4.0 + 16.0;
+        int rc = knn_threshold_pass(idx, qp, nq, S_last, S1, k, per_row, ds, dj, knn_i8);
+        if (rc == VSC_ERR_OVERFLOW && knn_i8 && idx->i8_mode != 2) {
+            // (ds / dj still hold the lists over [0, S_last): the overflow is detected before they are rewritten)
+            knn_i8 = false;
+            idx->stat_i8_fallbacks += 1;
+            rc = knn_threshold_pass(idx, qp, nq, S_last, S1, k, per_row, ds, dj, false);
         }
+        if (rc != VSC_OK) return rc;
+        S_last = S1;
+        if (S_last < nr) VSC_TRY(launch_knn_row_thr(ds, nq, k, idx->ws.rowthr.as<float>(), rows_h, idx->stream));
     }
-    int rc = knn_threshold_pass(idx, qp, nq, nr, k, (double)k * ((double)nr / (double)S_last) * 4.0, ds, dj, knn_i8);
-    if (rc == VSC_ERR_OVERFLOW && knn_i8 && idx->i8_mode != 2) {
-        idx->stat_i8_fallbacks += 1;
-        rc = knn_threshold_pass(idx, qp, nq, nr, k, (double)k * ((double)nr / (double)S_last) * 4.0, ds, dj, false);
-    }
-    return rc;
+    return VSC_OK;
 }
 
 int vsc_index_knn(vsc_index_t* idx, const float* q, int64_t nq, int q_mem, int k, float* out_s,

@@ -86,6 +86,9 @@ struct RescoreArgs {
     const float* radius; int32_t* out_i; int32_t* out_j; float* out_s;
     unsigned long long* counter; long long cap; int* overflow;
     const float* row_thr;  // k-NN mode: keep score >= row_thr[global row] (nullptr: score > *radius)
+    // the launch searched the reference rows [j0, j0 + nr): the kernels' images were handed over from row j0 on, the
+    // candidate list holds refs RELATIVE to it (cand_compact / the segment-wise exact stage add j0 back)
+    int j0 = 0;
 };
 // fp16 screen of the int8 route's candidates (sim_f16.hip): the pair list sorted by reference row in, the pairs whose
 // fp16 score + error bound still reaches the threshold out
@@ -161,6 +164,7 @@ int launch_knn_merge(const KnnMergeArgs&, hipStream_t);
 int knn_from_hits(const int32_t*, const int32_t*, const float*, int64_t, int64_t, int, DevBuf&, DevBuf&, DevBuf&,
                   DevBuf&, DevBuf&, float*, int64_t*, hipStream_t);
 int launch_knn_row_thr(const float*, int64_t, int, float*, int64_t, hipStream_t);
+int launch_knn_seed_hits(const float*, const int64_t*, int64_t, int, int32_t*, int32_t*, float*, unsigned long long*, hipStream_t);
 int launch_score_matrix(const ScoreMatArgs&, hipStream_t);
 int launch_matrix_thresh(const MatThreshArgs&, hipStream_t);
 int launch_matrix_knn(const MatKnnArgs&, hipStream_t);

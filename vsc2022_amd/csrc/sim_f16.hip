@@ -526,7 +526,7 @@ __device__ __forceinline__ void rescore_list(const RescoreArgs& a, float radius,
         // (the tail is a sequence of chunks, each filled up to its own level: cand_list.h)
         const bool valid = c < n && (fill == nullptr || (int)(c & ((1ll << shift) - 1)) < fill[c >> shift]);
         int i = valid ? ci[c] : 0;
-        const int j = valid ? cj[c] : 0;
+        const int j = valid ? cj[c] + a.j0 : 0;
         if (a.perm && valid) i = a.perm_i0 + a.perm[i - a.perm_i0];  // position inside a permuted int8 launch -> row
         const f32x4* q = reinterpret_cast<const f32x4*>(a.Q + (int64_t)i * a.dpad) + 2 * g;
         const f32x4* r = reinterpret_cast<const f32x4*>(a.R + (int64_t)j * a.dpad) + 2 * g;
@@ -635,7 +635,7 @@ __global__ __launch_bounds__(256) void cand_compact_kernel(RescoreArgs a, uint32
     for (int x = threadIdx.x; x < n; x += 256) {
         int i = ci[x];
         if (a.perm) i = a.perm_i0 + a.perm[i - a.perm_i0];  // position inside a permuted int8 launch -> row
-        key_j[base + x] = (uint32_t)cj[x];
+        key_j[base + x] = (uint32_t)(cj[x] + a.j0);
         val_i[base + x] = (uint32_t)i;
     }
 }
@@ -738,6 +738,7 @@ __global__ __launch_bounds__(256) void rescore_dense_kernel(RescoreArgs a, const
     int pend = 0;
     const float radius = a.row_thr ? 0.0f : *a.radius;
     a.perm = nullptr;  // (rows already)
+    a.j0 = 0;          // (absolute reference rows already: cand_compact added the launch's offset)
     rescore_list(a, radius, reinterpret_cast<const int32_t*>(si), reinterpret_cast<const int32_t*>(sj), n,
                  (long long)blockIdx.x * 256 + threadIdx.x, (long long)gridDim.x * 256, buf, pend);
     flush_hits(a, buf, pend);

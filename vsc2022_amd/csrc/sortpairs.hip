@@ -294,6 +294,36 @@ int knn_from_hits(const int32_t* hi, const int32_t* hj, const float* hs, int64_t
     return VSC_OK;
 }
 
+// The k-NN lists of the reference rows searched so far re-enter the hit list as (row, ref, score) triples, so that the
+// next range of references is merged with them by the same sort + cut (knn_from_hits); empty slots (ref -1) are skipped.
+__global__ __launch_bounds__(256) void knn_seed_hits_kernel(const float* __restrict__ knn_s, const int64_t* __restrict__ knn_j,
+                                                            int64_t n, int k, int32_t* __restrict__ hi, int32_t* __restrict__ hj,
+                                                            float* __restrict__ hs, unsigned long long* __restrict__ counter) {
+    const int64_t x = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const bool have = x < n && knn_j[x] >= 0;
+    const unsigned long long m = __ballot(have);
+    if (m == 0ull) return;
+    const int lane = threadIdx.x & 63;
+    unsigned long long base = 0;
+    if (lane == __ffsll((long long)m) - 1) base = atomicAdd(counter, (unsigned long long)__popcll(m));
+    base = __shfl(base, __ffsll((long long)m) - 1);
+    if (have) {
+        const unsigned long long p = base + __popcll(m & ((1ull << lane) - 1));
+        hi[p] = (int32_t)(x / k);
+        hj[p] = (int32_t)knn_j[x];
+        hs[p] = knn_s[x];
+    }
+}
+
+int launch_knn_seed_hits(const float* knn_s, const int64_t* knn_j, int64_t nq, int k, int32_t* hi, int32_t* hj, float* hs,
+                         unsigned long long* counter, hipStream_t stream) {
+    const int64_t n = nq * k;
+    if (n <= 0) return VSC_OK;
+    hipLaunchKernelGGL(knn_seed_hits_kernel, dim3(grid_for(n)), dim3(256), 0, stream, knn_s, knn_j, n, k, hi, hj, hs, counter);
+    VSC_HIP(hipGetLastError());
+    return VSC_OK;
+}
+
 // row_thr[i] = k-th best score of row i (out of a k-NN result), +inf for the padding rows
 __global__ __launch_bounds__(256) void knn_row_thr_kernel(const float* knn_s, int64_t nq, int k, float* row_thr,
                                                           int64_t rows) {
