@@ -80,6 +80,8 @@ int vsc_device_count(void);
  *                             on int8 (default 0.35: the 8-bit bound would pass too much of the matrix)
  *   VSC_I8_EXCLUDE=0          keep coordinates on which all references agree inside the int8 images
  *   VSC_I8_SORT=0             int8 launches see their rows in batch order (default: sorted by threshold / scale)
+ *   VSC_I8_GROUP=n            radius searches with per-row thresholds (excluded coordinates): inside groups of 2^n
+ *                             rows of the threshold order the rows are ordered by scale (default 9; 0: off)
  *   VSC_I8P_ORDER=0           panel-major work items with stealing (default 1: slice-major)
  *   VSC_I8P_SLICE=n           col-steps of 512 reference rows per work item (default 32 slice-major)
  *   VSC_I8_SCREEN=1           fp16 screen between the int8 pre-filter and the exact stage (measured neutral: off)

@@ -68,12 +68,13 @@ struct Workspace {
     DevBuf q8, pstat;       // int8 image + per-panel {1/s, E, N, s} of ONE launch's query rows (sim_i8p.hip)
     DevBuf cs[4], cstmp, csn;  // candidates of a launch compacted + sorted by reference row (keys, values, ping-pong)
     DevBuf tailfill;        // fill levels of the chunks of the candidate list's shared tail (cand_list.h)
+    DevBuf rt8c;            // the rows' largest |x| (second sort key of launches with per-row thresholds)
     DevBuf rt8, rt8b;       // ... and its row thresholds in position order (rows sorted by threshold inside a launch);
                             // rt8b: thresholds lowered by the excluded coordinates' contribution, in row order
     void release() {
         stage.release(); qbuf.release();
         qh.release(); qn.release(); ci.release(); cj.release(); segcnt.release(); rowthr.release(); slices.release();
-        q8.release(); pstat.release(); rt8.release(); rt8b.release(); tailfill.release();
+        q8.release(); pstat.release(); rt8.release(); rt8b.release(); rt8c.release(); tailfill.release();
         for (auto& b : cs) b.release();
         cstmp.release(); csn.release();
         for (auto& b : hA) b.release();
@@ -166,12 +167,14 @@ struct vsc_index {
     int i8p_order = 1;           // VSC_I8P_ORDER: 1 slice-major work items (default), 0 panel-major with stealing
     int i8p_slice = 0;           // VSC_I8P_SLICE: col-steps per work item (0: 16 slice-major / the plan's panel-major)
     bool i8_sort_rows = true;    // VSC_I8_SORT=0: the rows of a launch keep their order
+    int i8_group_shift = 9;      // VSC_I8_GROUP=<log2 rows>: radius searches with per-row thresholds order groups of 2^n rows by scale (0: off)
     bool rescore_by_ref = true;  // VSC_RESCORE_SORT=0: re-score the waves' segments as they are
     bool i8_screen = false;      // VSC_I8_SCREEN=1: fp16 screen between the int8 pre-filter and the exact stage
     bool knn_i8 = true;          // VSC_I8_KNN=0: k-NN passes on the fp16 kernel
     bool knn_two_level = true;   // VSC_KNN_LEVELS=1: one refinement level
     double knn_subset_factor = 300.0;  // VSC_KNN_SUBSET
     int knn_s0_div = 7;          // VSC_KNN_S0DIV
+    int knn_s0_min = 4096;       // VSC_KNN_S0MIN: smallest exact subset
     double knn_ratio = 0.0;      // VSC_KNN_RATIO (0: by k)
     int knn_nchunk = 0;          // VSC_KNN_NCHUNK: reference chunks of the exact k-NN kernel (0: by size)
     bool debug_i8 = false, debug_screen = false;  // VSC_DEBUG_I8 / VSC_DEBUG_SCREEN: stderr notes
@@ -341,6 +344,7 @@ int vsc_index_create(int dim, int metric, int device, vsc_index_t** out) {
         idx->i8p_order = (int)num("VSC_I8P_ORDER", 1.0) == 1 ? 1 : 0;
         idx->i8p_slice = (int)num("VSC_I8P_SLICE", 0.0);
         idx->i8_sort_rows = !is("VSC_I8_SORT", '0');
+        idx->i8_group_shift = getenv("VSC_I8_GROUP") ? std::max(0, std::min(16, (int)num("VSC_I8_GROUP", 9.0))) : 9;
         idx->rescore_by_ref = !is("VSC_RESCORE_SORT", '0');
         idx->i8_screen = is("VSC_I8_SCREEN", '1');
         idx->knn_i8 = !is("VSC_I8_KNN", '0');
@@ -348,6 +352,7 @@ int vsc_index_create(int dim, int metric, int device, vsc_index_t** out) {
         idx->knn_subset_factor = num("VSC_KNN_SUBSET", 300.0);
         idx->knn_s0_div = num("VSC_KNN_S0DIV", 0.0) > 0.0 ? (int)num("VSC_KNN_S0DIV", 0.0) : 7;
         idx->knn_ratio = num("VSC_KNN_RATIO", 0.0);
+        idx->knn_s0_min = num("VSC_KNN_S0MIN", 0.0) >= 64.0 ? (int)num("VSC_KNN_S0MIN", 0.0) : 4096;
         idx->knn_nchunk = (int)num("VSC_KNN_NCHUNK", 0.0);
         idx->debug_i8 = getenv("VSC_DEBUG_I8") != nullptr;
         idx->debug_screen = getenv("VSC_DEBUG_SCREEN") != nullptr;
@@ -732,6 +737,19 @@ static int enqueue_f16(vsc_index* idx, const float* qpacked, int64_t i0, int64_t
                 // gates 32-row blocks by their smallest threshold)
                 VSC_TRY(idx->ws.rt8.reserve((size_t)f.npanel * F16P_PANEL_ROWS * sizeof(float)));
                 rt_pos = idx->ws.rt8.as<float>();
+                if (idx->i8_group_shift > 0 && !row_thr && nqb >= (4 << idx->i8_group_shift)) {
+                    // ... and, inside groups of 512 positions of that order, by the rows' largest element (sortpairs.hip).
+                    // Only for the radius search over excluded coordinates (thresholds = radius - the rows' bias: a
+                    // narrow spread): configs[3] 1162 -> 1086 M candidates, exact stage 367 -> 341 ms (groups of 256 /
+                    // 512 / 1024 / 2048 / 4096: 1110 / 1086 / 1090 / 1125 / 1205 M).  The k-NN's thresholds -- each
+                    // row's best score so far -- spread far more: there the same grouping cost 2 % (892 -> 907 ms).
+                    VSC_TRY(idx->ws.rt8c.reserve((size_t)nqb * sizeof(float)));
+                    VSC_TRY(launch_row_absmax(qpacked + i0 * idx->dpad, idx->dpad, nqb, idx->i8_ex, idx->ws.rt8c.as<float>(),
+                                              idx->stream));
+                    VSC_TRY(sort_rows_by_threshold_then_scale(thr_src, idx->ws.rt8c.as<float>(), nqb, idx->i8_group_shift,
+                                                              idx->ws.w0, idx->ws.w1, idx->ws.w2, idx->ws.w3, idx->ws.tmp,
+                                                              &perm, idx->stream));
+                } else
                 VSC_TRY(sort_rows_by_threshold(thr_src, nqb, idx->ws.w0, idx->ws.w1, idx->ws.w2, idx->ws.w3, idx->ws.tmp,
                                                &perm, idx->stream));
             }
@@ -1309,7 +1327,7 @@ static int knn_prefiltered(vsc_index* idx, const float* qp, int64_t nq, int k, f
     const int64_t S_one = std::min<int64_t>(
         nr, round_up64(std::max<int64_t>((int64_t)std::sqrt(subset_factor * k * (double)nr), 4096), unit));
     const int64_t S0_small = std::min<int64_t>(
-        nr, round_up64(std::max<int64_t>(S_one / s0_div, idx->prefilter_force ? (int64_t)k : 4096), unit));
+        nr, round_up64(std::max<int64_t>(S_one / s0_div, idx->prefilter_force ? (int64_t)k : (int64_t)idx->knn_s0_min), unit));
     const bool refine = levels && (idx->prefilter_force ? nr >= 2 * S0_small
                                                         : (nr >= 8 * S_one && (double)nq * (double)nr >= 4e10));
     const int64_t S0 = refine ? S0_small : S_one;

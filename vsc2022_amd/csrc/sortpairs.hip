@@ -114,6 +114,35 @@ int sort_rows_by_threshold(const float* thr, int64_t n, DevBuf& w0, DevBuf& w1, 
     return VSC_OK;
 }
 
+// ... and, inside groups of `group` consecutive positions of that order, by the rows' scale (their largest |x|): the
+// panels of the int8 kernel share ONE quantisation scale per 128 rows, so a panel of rows that would have picked
+// nearly that scale themselves keeps the panel's error bound E_q near a single row's (the radius search sorts all its
+// rows that way); with per-row thresholds the order by threshold comes first -- a block is gated by its smallest
+// threshold -- but inside a group of 512 rows of a 32768-row launch the thresholds differ by a few percent of their
+// spread, less than what the tighter scale buys (round 4: -6.5 % candidates on configs[3]'s search; api.hip).
+__global__ __launch_bounds__(256) void group_scale_keys_kernel(const int32_t* __restrict__ perm, const float* __restrict__ scale,
+                                                               int n, int group_shift, uint32_t* __restrict__ keys) {
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= n) return;
+    // 12 bits of group number | the top 20 bits of the order-preserving key of a non-negative float
+    keys[p] = ((uint32_t)(p >> group_shift) << 20) | (f2key(scale[perm[p]]) >> 12);
+}
+
+int sort_rows_by_threshold_then_scale(const float* thr, const float* scale, int64_t n, int group_shift, DevBuf& w0, DevBuf& w1,
+                                      DevBuf& w2, DevBuf& w3, DevBuf& tmp, const int32_t** perm, hipStream_t stream) {
+    VSC_TRY(sort_rows_by_threshold(thr, n, w0, w1, w2, w3, tmp, perm, stream));
+    if (n <= 0 || (n >> group_shift) >= 4096) return VSC_OK;  // (12 bits of group number)
+    uint32_t *ka = w0.as<uint32_t>(), *kb = w1.as<uint32_t>();
+    int32_t* va = const_cast<int32_t*>(*perm);
+    int32_t* vb = va == w2.as<int32_t>() ? w3.as<int32_t>() : w2.as<int32_t>();
+    hipLaunchKernelGGL(group_scale_keys_kernel, dim3(grid_for(n)), dim3(256), 0, stream, va, scale, (int)n, group_shift, ka);
+    VSC_HIP(hipGetLastError());
+    const int w = radix_sort_pairs<uint32_t, int32_t>(ka, kb, va, vb, n, 0, 32, false, tmp.p, stream);
+    if (w < 0) { set_error("radix sort launch failed"); return VSC_ERR_HIP; }
+    *perm = w ? vb : va;
+    return VSC_OK;
+}
+
 // candidates (reference row, query row) of one launch ordered by reference row: keys need only the bits of nrefs
 int sort_candidates_by_ref(uint32_t* ka, uint32_t* kb, uint32_t* va, uint32_t* vb, int64_t n, int64_t nrefs, DevBuf& tmp,
                            const uint32_t** sorted_j, const uint32_t** sorted_i, hipStream_t stream) {
