@@ -84,6 +84,20 @@ __device__ __forceinline__ void wave_first_max(float& v, int& o) {
 }
 
 
+#ifdef VSC_TN_PROFILE  // experiment builds only: shader cycles per phase, summed over all pairs (scripts/experiments)
+__device__ unsigned long long tn_prof[8];
+#define TN_T0() unsigned long long t_prof = __builtin_readcyclecounter()
+#define TN_T(k)                                                                          \
+    do {                                                                                 \
+        const unsigned long long t_now = __builtin_readcyclecounter();                   \
+        if (threadIdx.x == 0) atomicAdd(&tn_prof[k], t_now - t_prof);                    \
+        t_prof = t_now;                                                                  \
+    } while (0)
+#else
+#define TN_T0() do {} while (0)
+#define TN_T(k) do {} while (0)
+#endif
+
 template <class IDX, bool GSTATE>
 __global__ __launch_bounds__(64) void tn_pair_kernel(TnPairArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem_lds[];
@@ -144,12 +158,18 @@ __global__ __launch_bounds__(64) void tn_pair_kernel(TnPairArgs a) {
     off = (off + 15) & ~(size_t)15;
     int* boxes = reinterpret_cast<int*>(smem + off);
     off += (size_t)VSC_TN_MAX_BOXES * 16;
+    // which lanes of a (query row, node pair) pass of the DP hold a valid edge: the graph does not change between the
+    // longest-path extractions (only edge weights are zeroed), so the first extraction records one ballot per pass and
+    // the other max_path reuse it instead of re-deriving every edge from five LDS reads (tn_edge_ok)
+    unsigned long long* okmask = reinterpret_cast<unsigned long long*>(smem + off);
+    off += (size_t)a.max_lq * ((top_cap + 1) / 2) * 8;
     off = (off + 63) & ~(size_t)63;
     float* sims;
     if (a.sims_in) sims = const_cast<float*>(a.sims_in) + a.sims_off[pidx];
     else if ((int64_t)lq * lr <= a.lds_tile_floats) sims = reinterpret_cast<float*>(smem + off);
     else sims = a.slab + (int64_t)blockIdx.x * a.slab_floats;
 
+    TN_T0();
     // ---- 1. similarity tile on the matrix cores: 32x32 output blocks, K ascending ----
     if (!a.sims_in) {
         const int hi = lane >> 5, l31 = lane & 31;
@@ -200,6 +220,7 @@ __global__ __launch_bounds__(64) void tn_pair_kernel(TnPairArgs a) {
     for (int x = lane; x < zero_words; x += 64) zero[x] = 0;
     __threadfence_block();
     __syncthreads();
+    TN_T(0);
 
     // ---- 2. per-row top-k by (sim desc, ref asc) ----
     // Two equivalent methods.  Lane per ROW (top_k <= 8, enough rows to fill lanes): every lane walks its row once,
@@ -303,6 +324,7 @@ __global__ __launch_bounds__(64) void tn_pair_kernel(TnPairArgs a) {
     }
     __syncthreads();
 
+    TN_T(1);
     // ---- 4. longest-path extractions ----
     const int P = (ms - 1) * top;  // regular predecessor slots of a node, insertion order
     int nbox = 0;
@@ -327,16 +349,23 @@ __global__ __launch_bounds__(64) void tn_pair_kernel(TnPairArgs a) {
                     const bool mine = b < top && v != g.sink;
                     float c = 0.0f;
                     int oo = -1;
-                    if (mine && o < P) {
-                        const int d = ms - 1 - o / top, aa = o % top;
-                        const int qi = qj - d;
-                        if (qi >= 0 && tn_edge_ok(g, qi, aa, d, b)) {
-                            const int bit = tn_edge_bit(g, qi, aa, d, b);
-                            const bool z = (zero[bit >> 5] >> (bit & 31)) & 1u;
-                            const float w = z ? 0.0f : tsim[qj * top + b];
-                            c = dist[1 + qi * top + aa] + w;
-                            oo = o;
-                        }
+                    const int d = ms - 1 - o / top, aa = o % top;
+                    const int qi = qj - d;
+                    const int mslot = qj * ((top + 1) / 2) + (b0 >> 1);
+                    bool ok;
+                    if (it == 0) {
+                        ok = mine && o < P && qi >= 0 && tn_edge_ok(g, qi, aa, d, b);
+                        const unsigned long long m = __ballot(ok);
+                        if (lane == 0) okmask[mslot] = m;
+                    } else {
+                        ok = (okmask[mslot] >> lane) & 1ull;
+                    }
+                    if (ok) {
+                        const int bit = tn_edge_bit(g, qi, aa, d, b);
+                        const bool z = (zero[bit >> 5] >> (bit & 31)) & 1u;
+                        const float w = z ? 0.0f : tsim[qj * top + b];
+                        c = dist[1 + qi * top + aa] + w;
+                        oo = o;
                     }
 #pragma unroll
                     for (int off = 16; off >= 1; off >>= 1) {  // (value, slot) first-max inside the half wave
@@ -360,6 +389,7 @@ __global__ __launch_bounds__(64) void tn_pair_kernel(TnPairArgs a) {
                 // only the sink (last node of the last row) is left for the whole-wave path
                 b_first = (qj == lq - 1) ? top - 1 : top;
             }
+            if (qj == lq - 1) TN_T(2);
             for (int b = b_first; b < top; ++b) {
                 const int v = 1 + qj * top + b;
                 const bool is_sink = (v == g.sink);
@@ -426,6 +456,7 @@ __global__ __launch_bounds__(64) void tn_pair_kernel(TnPairArgs a) {
             __syncthreads();
         }
 
+        TN_T(3);
         // end node: first node in topological order with maximal dist
         float mx = -FLT_MAX;
         int mxn = -1;
@@ -509,6 +540,7 @@ __global__ __launch_bounds__(64) void tn_pair_kernel(TnPairArgs a) {
             vend = order[bestpos];
         }
 
+        TN_T(4);
         // back-track, zero the path's edge weights, score and box (lane 0; paths are short)
         int accepted = 0, stop = 0;
         int bq0 = 0, br0 = 0, bq1 = 0, br1 = 0;
@@ -597,6 +629,7 @@ __global__ __launch_bounds__(64) void tn_pair_kernel(TnPairArgs a) {
         stop = __shfl(stop, 0);
         accepted = __shfl(accepted, 0);
         __syncthreads();
+        TN_T(5);
         if (stop) break;
         if (accepted) {
             bq0 = __shfl(bq0, 0); br0 = __shfl(br0, 0); bq1 = __shfl(bq1, 0); br1 = __shfl(br1, 0);
@@ -621,9 +654,21 @@ __global__ __launch_bounds__(64) void tn_pair_kernel(TnPairArgs a) {
             }
             ++nbox;
         }
+        TN_T(6);
     }
     if (lane == 0) *o_nbox = nbox;
 }
+
+#ifdef VSC_TN_PROFILE
+extern "C" int vsc_tn_prof_read(unsigned long long* out8, int reset) {
+    if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(tn_prof), sizeof(tn_prof)) != hipSuccess) return -1;
+    if (reset) {
+        unsigned long long z[8] = {};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(tn_prof), z, sizeof(z)) != hipSuccess) return -1;
+    }
+    return 0;
+}
+#endif
 
 size_t tn_state_bytes_host(int max_lq, int top_cap, int ms, int idx_bytes) {
     const size_t n_nodes = 1 + (size_t)max_lq * top_cap;
@@ -640,6 +685,7 @@ size_t tn_state_bytes_host(int max_lq, int top_cap, int ms, int idx_bytes) {
     b += n_nodes * ib * 3;
     b = (b + 15) & ~(size_t)15;
     b += (size_t)VSC_TN_MAX_BOXES * 16;
+    b += (size_t)max_lq * ((top_cap + 1) / 2) * 8;  // okmask
     b = (b + 63) & ~(size_t)63;
     return b;
 }
