@@ -234,7 +234,8 @@ int vsc_index_profile_read(vsc_index_t* idx, double* sim_ms, int64_t* sim_launch
  * reports), 1 = fp16 pre-filter GEMM (work = algorithmic flops 2*nq*nr*dim), 2 = exact re-scoring of
  * the pre-filter's candidates (work unused), 3 = re-threshold kernels of the search schedule (radix select +
  * compaction; work unused), 4 = final ordering of the kept hits (work = bytes of the hit triples read),
- * 5 = int8 pre-filter GEMM of the sparse batches incl. the quantisation of its query rows (work = 2*nq*nr*dim). */
+ * 5 = int8 pre-filter kernel of the sparse batches (work = 2*nq*nr*dim), 6 = the preamble of its launches (row
+ * thresholds / scales, the sort of the launch's rows, quantisation of the query panels; work unused). */
 int vsc_index_profile_read_class(vsc_index_t* idx, int cls, double* ms, int64_t* launches, double* work,
                                  int reset);
 /* Process-wide accounting of the entry points that own no index handle, same method (HIP events on the

@@ -549,3 +549,26 @@ def test_fast_inference_configuration_against_fp32_eager(gpu, config):
     fn = fast / fast.norm(dim=1, keepdim=True)
     _, top1 = index.search(fn, 1)
     assert np.array_equal(top1[:, 0], np.arange(len(fn))), f"{int((top1[:, 0] != np.arange(len(fn))).sum())} frames retrieve another frame"
+
+
+def test_checked_fast_falls_back_on_a_bad_first_batch():
+    """`--fast` is gated on REAL data: the first batch also runs on the fp32 network; a fast network that disagrees
+    (any frame below the stated cosine) is dropped for the rest of the run."""
+    from vsc2022_amd.vsc.baseline.inference_cli import CheckedFast
+
+    torch.manual_seed(0)
+    eager = torch.nn.Linear(16, 8)
+    good = torch.nn.Linear(16, 8)
+    good.load_state_dict(eager.state_dict())
+    with torch.no_grad():
+        good.weight.add_(1e-5 * torch.randn_like(good.weight))
+    bad = torch.nn.Linear(16, 8)
+    x = torch.randn(12, 16)
+    ok = CheckedFast(good, eager, 0.999)
+    y = ok(x)
+    assert ok.use_fast and ok.first_batch_cosine >= 0.999 and torch.equal(y, good(x))
+    assert torch.equal(ok(x), good(x))                       # later batches: the fast network, no second check
+    gate = CheckedFast(bad, eager, 0.999)
+    y = gate(x)
+    assert not gate.use_fast and gate.first_batch_cosine < 0.999
+    assert torch.equal(y, eager(x)) and torch.equal(gate(x), eager(x))

@@ -180,7 +180,7 @@ class DeviceMatcher:
         q = self.q_feats if rows is None else rows.to(self.tdev, torch.float32).contiguous()
         nq = int(q.shape[0])
         cap = int(max(1, min(K, nq * max(self.index.ntotal, 1))))
-        tag = "hit" if rows is None else "shit"
+        tag = "hit" if rows is None else "seed_hit"
         oi = self._buf(tag + "_i", cap, torch.int32)
         oj = self._buf(tag + "_j", cap, torch.int32)
         os_ = self._buf(tag + "_s", cap, torch.float32)

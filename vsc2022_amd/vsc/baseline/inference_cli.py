@@ -208,6 +208,34 @@ def get_device(args, rank: int, world_size: int) -> torch.device:
     return torch.device("cuda", dev)
 
 
+class CheckedFast(torch.nn.Module):
+    """`FastSSCD` behind a gate on REAL data: the bf16 configuration is accuracy-tested on a calibrated
+    random-init trunk (tests/test_inference.py), which says nothing about a particular checkpoint.  On the first batch
+    of frames the fp32 eager network runs as well; if any frame's descriptors agree worse than `min_cosine` the fast
+    network is dropped for the rest of the run (with a warning) and the eager one answers."""
+
+    def __init__(self, fast: torch.nn.Module, eager: torch.nn.Module, min_cosine: float = 0.999):
+        super().__init__()
+        self.fast, self.eager, self.min_cosine = fast, eager, float(min_cosine)
+        self.checked, self.use_fast, self.first_batch_cosine = False, True, None
+
+    def forward(self, x):
+        if not self.use_fast:
+            return self.eager(x)
+        y = self.fast(x)
+        if not self.checked:
+            self.checked = True
+            ref = self.eager(x)
+            cos = torch.nn.functional.cosine_similarity(ref.float(), y.float(), dim=1)
+            self.first_batch_cosine = float(cos.min().item()) if cos.numel() else 1.0
+            if not (self.first_batch_cosine >= self.min_cosine):
+                logger.warning(f"--fast: descriptors of the first batch agree with the fp32 network only to cosine "
+                               f"{self.first_batch_cosine:.5f} (< {self.min_cosine}); continuing on the fp32 network")
+                self.use_fast = False
+                return ref
+        return y
+
+
 def load_model(args, device):
     if args.torchscript_path:
         model = torch.jit.load(args.torchscript_path, map_location=device)
@@ -225,7 +253,7 @@ def load_model(args, device):
         if eager is None:
             raise Exception("--fast: the model is not a ResNet-50 trunk + GeM + Linear (or does not reproduce on a "
                             "random batch after conversion); run without --fast")
-        model = FastSSCD(eager).to(device).eval()
+        model = CheckedFast(FastSSCD(eager).to(device).eval(), eager, getattr(args, "fast_min_cosine", 0.999)).eval()
     return model
 
 
@@ -262,6 +290,9 @@ def build_parser() -> argparse.ArgumentParser:
     g.add_argument("--store_fp16", action="store_true")
     g.add_argument("--fast", action="store_true",
                    help="(extension) run a ResNet-50 SSCD model through FastSSCD: bf16 trunk, fused kernels; cuda only")
+    g.add_argument("--fast_min_cosine", type=float, default=0.999,
+                   help="(extension) --fast: the first batch is also run on the fp32 network; below this per-frame "
+                        "cosine the run continues on the fp32 network")
     d = p.add_argument_group("Dataset")
     d.add_argument("--dataset_path", required=True)
     d.add_argument("--fps", default=1, type=float)

@@ -250,8 +250,9 @@ class FlatIndex:
                                                      ctypes.byref(fl), 1 if reset else 0))
         out = {"sim_ms": ms.value, "sim_launches": n.value, "sim_flops": fl.value}
         # per kernel class: fp16 pre-filter GEMM and exact re-scoring of its candidates
-        # (5: the int8 pre-filter of the sparse batches, csrc/sim_i8p.hip)
-        for cls, name in ((1, "f16"), (2, "rescore"), (3, "select"), (4, "sort"), (5, "i8")):
+        # (5: the int8 pre-filter kernel of the sparse batches, csrc/sim_i8p.hip; 6: its launches' preamble -- row
+        # sorts and the quantisation of the query panels)
+        for cls, name in ((1, "f16"), (2, "rescore"), (3, "select"), (4, "sort"), (5, "i8"), (6, "i8_prep")):
             _lib.check(_lib.lib().vsc_index_profile_read_class(self._h, cls, ctypes.byref(ms), ctypes.byref(n),
                                                                ctypes.byref(fl), 1 if reset else 0))
             out.update({f"{name}_ms": ms.value, f"{name}_launches": n.value, f"{name}_flops": fl.value})
