@@ -735,7 +735,7 @@ static int enqueue_f16(vsc_index* idx, const float* qpacked, int64_t i0, int64_t
                 rt_pos = idx->ws.rt8.as<float>();
             } else if (thr_src) {
                 // thresholds that differ from row to row: the launch sees its rows sorted by threshold (the kernel
-                // gates 32-row blocks by their smallest threshold)
+                // gates a tile by its panel's smallest threshold and a 16-row block by the block's)
                 VSC_TRY(idx->ws.rt8.reserve((size_t)f.npanel * F16P_PANEL_ROWS * sizeof(float)));
                 rt_pos = idx->ws.rt8.as<float>();
                 if (idx->i8_group_shift > 0 && !row_thr && nqb >= (4 << idx->i8_group_shift)) {

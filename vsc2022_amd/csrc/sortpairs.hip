@@ -81,7 +81,8 @@ int sort_hits_topk(const int32_t* hi, const int32_t* hj, const float* hs, int64_
 
 // ----------------------------------------------------------------------------- rows of a launch by threshold
 //
-// The int8 pre-filter tests a 32-row block against the SMALLEST of its row thresholds before it looks at single
+// The int8 pre-filter tests a tile against the SMALLEST row threshold of its 128-row panel, and a 16-row block of a
+// passing column block against the smallest of its own (round 3: 32-row blocks), before it looks at single
 // accumulators; with an 8-bit error bound that gate only filters when the rows of a block have similar thresholds.
 // Inside one launch the row order is free (candidates carry their row index), so the rows are handed to the kernel
 // sorted by threshold: perm[position] = row.  All 32 key bits: the kernel tests a whole block against its smallest
