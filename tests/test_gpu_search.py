@@ -179,3 +179,42 @@ def test_row_normalize(gpu, orc):
     assert np.all(out[13] == 0)
     nz = np.delete(np.arange(777), 13)
     assert np.allclose(np.linalg.norm(out[nz].astype(np.float64), axis=1), 1.0, atol=1e-6)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("metric", ["ip", "l2"])
+def test_seeded_global_topk_matches_the_exact_topk(gpu, orc, metric):
+    """`vsc_index_global_topk_seeded` (the local search of the query-sharded pipeline): from a radius below the K-th
+    best score the steady-batch search returns the exact top-K -- what the reference's schedule returns too when no hit
+    ties with a re-threshold radius --; from a radius above it, every hit strictly beyond that radius and nothing else;
+    a non-finite seed is refused."""
+    from vsc2022_amd import _lib
+    from vsc2022_amd.vsc.index import FlatIndex
+
+    rng = np.random.default_rng(77)
+    nq, nr, d, K = 3000, 40000, 96, 50000
+    q = rng.standard_normal((nq, d)).astype(np.float32)
+    r = rng.standard_normal((nr, d)).astype(np.float32)
+    q /= np.linalg.norm(q, axis=1, keepdims=True)
+    r /= np.linalg.norm(r, axis=1, keepdims=True)
+    l2 = metric == "l2"
+    idx = FlatIndex(d, _lib.METRIC_L2 if l2 else _lib.METRIC_INNER_PRODUCT)
+    idx.add(r)
+    oi, oj, os_ = orc.global_threshold_search(q, r, K, 1 if l2 else 0)
+    kth = float(os_[-1])
+    # a seed comfortably on the easy side of the K-th best (scores: larger is better; L2 distances: smaller)
+    seed = kth + 0.02 if l2 else kth - 0.02
+    i, j, s, rad = idx.global_topk(q, K, seed_radius=seed)
+    assert np.array_equal(i, oi) and np.array_equal(j, oj) and np.array_equal(s.view(np.uint32), os_.view(np.uint32))
+    assert (rad >= seed) if not l2 else (rad <= seed)
+    # a seed on the wrong side: only the hits strictly beyond it, in order
+    cut = int(K * 0.6)
+    seed_hi = float(os_[cut])
+    i2, j2, s2, rad2 = idx.global_topk(q, K, seed_radius=seed_hi)
+    beyond = (os_ < np.float32(seed_hi)) if l2 else (os_ > np.float32(seed_hi))
+    n_exp = int(np.count_nonzero(beyond))
+    assert 0 < len(s2) == n_exp < K
+    assert np.array_equal(i2, oi[:n_exp]) and np.array_equal(j2, oj[:n_exp])
+    assert np.array_equal(s2.view(np.uint32), os_[:n_exp].view(np.uint32))
+    with pytest.raises(ValueError):
+        idx.global_topk(q, K, seed_radius=float("nan"))

@@ -205,17 +205,31 @@ class FlatIndex:
                                                 ctypes.byref(need)))
         return lims.astype(np.uint64), D, I
 
-    def global_topk(self, x, K: int, device_out: bool = False):
+    def global_topk(self, x, K: int, device_out: bool = False, seed_radius=None):
         """The adaptive global-threshold search of vsc/index.py:142-165 in one call.
 
         Returns (i int32, j int32, s float32, radius): at most K hits ordered by
         (score desc, row asc, ref asc).  With device_out the arrays are torch tensors in HBM.
+
+        seed_radius (extension, `vsc_index_global_topk_seeded`): a radius the caller knows to lie below the K-th best
+        score -- the rows then run as steady batches from it instead of replaying the reference's doubling schedule
+        from -/+1e10.  Every hit strictly beyond the returned radius is listed (cut at K); fewer than K hits come back
+        when the seed was too high.  The query-sharded pipeline seeds its ranks' searches this way (engine.py).
         """
         p, mem, n, keep = self._rows(x)
         K = int(K)
         n_out = ctypes.c_int64(0)
         radius = ctypes.c_float(0.0)
         cap = max(min(K, n * max(self.ntotal, 1)), 1)
+
+        def call(pi, pj, ps, out_mem):
+            if seed_radius is None:
+                _lib.check(_lib.lib().vsc_index_global_topk(self._h, p, n, mem, K, pi, pj, ps, cap, out_mem,
+                                                            ctypes.byref(n_out), ctypes.byref(radius)))
+            else:
+                _lib.check(_lib.lib().vsc_index_global_topk_seeded(self._h, p, n, mem, K, float(seed_radius), pi, pj, ps, cap,
+                                                                   out_mem, ctypes.byref(n_out), ctypes.byref(radius)))
+
         if device_out:
             import torch
 
@@ -224,17 +238,13 @@ class FlatIndex:
             oj = torch.empty(cap, dtype=torch.int32, device=dev)
             os_ = torch.empty(cap, dtype=torch.float32, device=dev)
             torch.cuda.synchronize(dev)
-            _lib.check(_lib.lib().vsc_index_global_topk(
-                self._h, p, n, mem, K, oi.data_ptr(), oj.data_ptr(), os_.data_ptr(), cap,
-                _lib.MEM_DEVICE, ctypes.byref(n_out), ctypes.byref(radius)))
+            call(oi.data_ptr(), oj.data_ptr(), os_.data_ptr(), _lib.MEM_DEVICE)
             m = n_out.value
             return oi[:m], oj[:m], os_[:m], radius.value
         oi = np.empty(cap, dtype=np.int32)
         oj = np.empty(cap, dtype=np.int32)
         os_ = np.empty(cap, dtype=np.float32)
-        _lib.check(_lib.lib().vsc_index_global_topk(
-            self._h, p, n, mem, K, oi.ctypes.data, oj.ctypes.data, os_.ctypes.data, cap, _lib.MEM_HOST,
-            ctypes.byref(n_out), ctypes.byref(radius)))
+        call(oi.ctypes.data, oj.ctypes.data, os_.ctypes.data, _lib.MEM_HOST)
         m = n_out.value
         return oi[:m], oj[:m], os_[:m], radius.value
 
