@@ -339,9 +339,153 @@ __global__ __launch_bounds__(NWAVE * 64) void k16(Args a) {
     if (lane == 0) a.seg_count[seg] = count;
 }
 
+// ------------------------------------------------------------------ 16x16x64 with the reference stream through a WAVE-PRIVATE LDS
+// ring (LDS-DMA in, ds_read_b128 out; no cross-wave synchronisation): does the L2 -> LDS path cost less than L2 -> VGPR?
+template <int PRW, int NWAVE, int RSPLIT, int WM, int WN, int PF, int EPI = 0, int STUB = 0>
+__global__ __launch_bounds__(NWAVE * 64) void k16l(Args a) {
+    static_assert(PRW == RSPLIT * WM * 32, "panel rows");
+    constexpr int NT = NWAVE * 64, CG = NWAVE / RSPLIT, CSW = CG * WN * 32, T64 = WN / 2;
+    constexpr int MB = WM * 2, CB = WN * 2, NK4 = NKS / 2;  // 16-row / 16-col blocks, 64-k steps
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    __shared__ int item_sh[2];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int rgrp = wave / CG, cgrp = wave % CG;
+    const int lane16 = lane * 16;
+    // A operand of block mb at 64-k step k4: row = mb * 16 + (lane & 15), 16-byte piece 4 (k4 & 3) + (lane >> 4) of chunk k4 >> 2
+    int abase[4];
+    {
+        const int kp = lane >> 4, r15 = lane & 15;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) abase[u] = (rgrp * WM * 32 + r15) * 256 + ((((4 * u) | kp) ^ r15) << 4);
+    }
+    const int seg = blockIdx.x * NWAVE + wave;
+    const int64_t seg_base = (int64_t)seg * a.seg_cap;
+    int count = 0;
+    const int nslice = (a.nsteps + a.slice - 1) / a.slice;
+    int cur_panel = -1;
+    for (;;) {
+        __syncthreads();
+        if (wave == 0) {
+            int t = 0;
+            if (lane == 0) t = atomicAdd(a.next_item, 1);
+            t = __shfl(t, 0);
+            int p = -1, s = 0;
+            if (t < nslice * a.npanel) { s = t / a.npanel; p = t - s * a.npanel; }
+            if (lane == 0) { item_sh[0] = p; item_sh[1] = s; }
+        }
+        __syncthreads();
+        const int panel = item_sh[0], sl = item_sh[1];
+        if (panel < 0) break;
+        const int cs0 = sl * a.slice, cs1 = min(a.nsteps, cs0 + a.slice);
+        if (panel != cur_panel) {
+            __syncthreads();
+            const __amdgpu_buffer_rsrc_t qrs = __builtin_amdgcn_make_buffer_rsrc(
+                (void*)uniform_ptr(a.Q + (int64_t)panel * PRW * ROWB), 0, PRW * ROWB, 0x00020000);
+#pragma unroll
+            for (int n = 0; n < PRW * ROWB / 16 / NT; ++n) {
+                const int p = n * NT + tid;
+                const int kc = p / (PRW * 16), row = (p >> 4) % PRW, slot = p & 15;
+                const int c = kc * 16 + (slot ^ (row & 15));
+                dma16(qrs, row * ROWB + c * 16, smem + (n * NT + wave * 64) * 16);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            cur_panel = panel;
+        }
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+            (void*)uniform_ptr(a.Rf + (int64_t)cs0 * CG * T64 * TILEB), 0, (cs1 - cs0) * CG * T64 * TILEB, 0x00020000);
+        int so_tile = cgrp * T64 * TILEB;
+        // a 64-k step of a 64-column image tile = 4 KiB = the B operands of its 4 column blocks
+        // wave-private ring behind the panel: PF slots of CB KiB
+        char* const rbase = smem + PRW * ROWB + wave * (PF * CB * 1024);
+        __syncthreads();  // (nobody still reads the previous item's ring slots ... they are private: cheap safety only)
+#pragma unroll
+        for (int dd = 0; dd < PF - 1; ++dd)
+#pragma unroll
+            for (int n = 0; n < CB; ++n)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(rbase + dd * CB * 1024 + n * 1024), 16,
+                                                         lane16 + (n & 3) * 1024, so_tile + (n >> 2) * TILEB + dd * 4096, 0, 0);
+        i32x4 bcur[CB];
+        i32x4 afr[MB];
+#pragma unroll
+        for (int m = 0; m < MB; ++m) afr[m] = *reinterpret_cast<const i32x4*>(smem + abase[0] + m * 4096);
+        i32x4 acc[MB][CB] = {};
+        for (int cs = cs0; cs < cs1; ++cs) {
+            const int col0 = cs * CSW + cgrp * WN * 32;
+            const i32x4 zero = {};
+            const int so_next = so_tile + CG * T64 * TILEB;
+#pragma unroll
+            for (int k4 = 0; k4 < NK4; ++k4) {
+                const int t = k4 + PF - 1;
+                const int so = (t < NK4) ? so_tile + t * 4096 : so_next + (t - NK4) * 4096;
+                const int kn = (k4 + 1) % NK4;
+                const char* anext = smem + (kn >> 2) * (PRW * 256) + abase[kn & 3];
+                // the PF - 1 younger steps' DMA pieces may still be in flight; this step's have landed
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(CB * (PF - 2)) : "memory");
+#pragma unroll
+                for (int n = 0; n < CB; ++n) bcur[n] = *reinterpret_cast<const i32x4*>(rbase + (k4 % PF) * CB * 1024 + n * 1024 + lane16);
+#pragma unroll
+                for (int m = 0; m < MB; ++m) {
+#pragma unroll
+                    for (int n = 0; n < CB; ++n)
+                        acc[m][n] = __builtin_amdgcn_mfma_i32_16x16x64_i8(afr[m], bcur[n], (k4 == 0 && !EPI) ? zero : acc[m][n], 0, 0, 0);
+                    afr[m] = *reinterpret_cast<const i32x4*>(anext + m * 4096);
+                    // (the slot of step k4 - 1 is free: its operands went into registers a step ago)
+                    if (m < CB)
+                        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(rbase + ((k4 + PF - 1) % PF) * CB * 1024 + m * 1024),
+                                                                 16, lane16 + (m & 3) * 1024, so + (m >> 2) * TILEB, 0, 0);
+                }
+
+            }
+            so_tile = so_next;
+            if (EPI && cs + 1 < cs1) continue;
+            // per column block: one max over the wave tile's rows (the radius threshold is per column)
+            int cm[CB];
+            int any = 0x80000000;
+#pragma unroll
+            for (int n = 0; n < CB; ++n) {
+                int x = 0x80000000;
+#pragma unroll
+                for (int m = 0; m < MB; ++m) {
+                    x = max(max(x, acc[m][n][0]), acc[m][n][1]);
+                    x = max(max(x, acc[m][n][2]), acc[m][n][3]);
+                }
+                cm[n] = x;
+                any = max(any, x);
+            }
+            if (__any(any > a.thr)) {
+                const int row_base = panel * PRW + rgrp * WM * 32 + 4 * (lane >> 4);
+#pragma unroll
+                for (int n = 0; n < CB; ++n) {
+                    if (!__any(cm[n] > a.thr)) continue;
+#pragma unroll
+                    for (int m = 0; m < MB; ++m)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const bool c = acc[m][n][r] > a.thr;
+                            const unsigned long long ok = __ballot(c);
+                            if (ok == 0ull) continue;
+                            const int total = __popcll(ok);
+                            if (count + total <= a.seg_cap) {
+                                if (c) {
+                                    const int64_t pos = seg_base + count + __popcll(ok & ((1ull << lane) - 1));
+                                    a.out_i[pos] = row_base + m * 16 + r;
+                                    a.out_j[pos] = col0 + n * 16 + (lane & 15);
+                                }
+                                count += total;
+                            }
+                        }
+                }
+            }
+        }
+    }
+    if (lane == 0) a.seg_count[seg] = count;
+}
+
 template <typename K>
-void run(const char* name, K kern, Args a, int prw, int nwave, int csw, int slice_cols, int reps) {
-    const int lds = prw * ROWB;
+void run(const char* name, K kern, Args a, int prw, int nwave, int csw, int slice_cols, int reps, int lds_extra = 0) {
+    const int lds = prw * ROWB + lds_extra;
     CK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     a.npanel = (a.nq + prw - 1) / prw;
     a.nsteps = (a.nr + csw - 1) / csw;
@@ -475,6 +619,14 @@ int main(int argc, char** argv) {
                 snprintf(nm, sizeof nm, "V1 16x16x64 slice %d cols, epilogue per item only", sc);
                 run(nm, k16<128, 8, 1, 4, 2, 2, 1>, a, 128, 8, 512, sc, R);
             }
+    }
+    if (mode == 3) {
+        a.thr = (int)(9.f * sig);
+        const int R = 4;
+        for (int rep = 0; rep < 2; ++rep) {
+            run("V1 16x16x64 B: L2 -> VGPR (ring of 2)", k16<128, 8, 1, 4, 2, 2>, a, 128, 8, 512, 32768, R);
+            run("V8 16x16x64 B: L2 -> private LDS ring (2 slots) -> VGPR", k16l<128, 8, 1, 4, 2, 2>, a, 128, 8, 512, 32768, R, 8 * 2 * 4096);
+        }
     }
     if (mode == 2) {
         a.thr = (int)(9.f * sig);
