@@ -278,6 +278,18 @@ __global__ __launch_bounds__(NWAVE * 64) void k16(Args a) {
                 const int so = (t < NK4) ? so_tile + t * 4096 : so_next + (t - NK4) * 4096;
                 const int kn = (k4 + 1) % NK4;
                 const char* anext = smem + (kn >> 2) * (PRW * 256) + abase[kn & 3];
+                if (STUB & 4) {
+                    // n-major: consecutive MFMAs share the B operand; A operands reloaded behind their last use (n = CB - 1)
+#pragma unroll
+                    for (int n = 0; n < CB; ++n)
+#pragma unroll
+                        for (int m = 0; m < MB; ++m) {
+                            acc[m][n] = __builtin_amdgcn_mfma_i32_16x16x64_i8(afr[m], ring[k4 % PF][n], (k4 == 0 && !EPI) ? zero : acc[m][n], 0, 0, 0);
+                            if (n == CB - 1) afr[m] = *reinterpret_cast<const i32x4*>(anext + m * 4096);
+                            if (n == 0 && m < CB) ring[(k4 + PF - 1) % PF][m] = bload(rs, lane16 + (m & 3) * 1024, so + (m >> 2) * TILEB);
+                        }
+                    continue;
+                }
 #pragma unroll
                 for (int m = 0; m < MB; ++m) {
 #pragma unroll
@@ -626,6 +638,7 @@ int main(int argc, char** argv) {
         for (int rep = 0; rep < 2; ++rep) {
             run("V1 16x16x64 B: L2 -> VGPR (ring of 2)", k16<128, 8, 1, 4, 2, 2>, a, 128, 8, 512, 32768, R);
             run("V8 16x16x64 B: L2 -> private LDS ring (2 slots) -> VGPR", k16l<128, 8, 1, 4, 2, 2>, a, 128, 8, 512, 32768, R, 8 * 2 * 4096);
+            run("V9 16x16x64 n-major MFMA order (consecutive MFMAs share B)", k16<128, 8, 1, 4, 2, 2, 0, 4>, a, 128, 8, 512, 32768, R);
         }
     }
     if (mode == 2) {
