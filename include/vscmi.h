@@ -84,6 +84,8 @@ int vsc_device_count(void);
  *                             rows of the threshold order the rows are ordered by scale (default 9; 0: off)
  *   VSC_I8P_ORDER=0           panel-major work items with stealing (default 1: slice-major)
  *   VSC_I8P_SLICE=n           col-steps of 512 reference rows per work item (default 32 slice-major)
+ *   VSC_I8P_PAIR=0 / 2        never / always (dims <= 512) use work items of two 128-row panels (256 x 32 wave tiles;
+ *                             default 1: where a launch is large enough)
  *   VSC_I8_SCREEN=1           fp16 screen between the int8 pre-filter and the exact stage (measured neutral: off)
  *   VSC_I8_KNN=0              k-NN threshold passes on the fp16 kernel
  *   VSC_RESCORE_SORT=0        exact stage over the waves' candidate segments as they are (default: compacted and

@@ -203,11 +203,13 @@ __global__ __launch_bounds__(NWAVE * 64) void k32(Args a) {
 }
 
 // ------------------------------------------------------------------ MI = 1: 16x16x64 (WM, WN still in units of 32)
-template <int PRW, int NWAVE, int RSPLIT, int WM, int WN, int PF, int EPI = 0, int STUB = 0>
+template <int PRW, int NWAVE, int RSPLIT, int WM, int WN, int PF, int EPI = 0, int STUB = 0, int AWIN = 0>
 __global__ __launch_bounds__(NWAVE * 64) void k16(Args a) {
     static_assert(PRW == RSPLIT * WM * 32, "panel rows");
-    constexpr int NT = NWAVE * 64, CG = NWAVE / RSPLIT, CSW = CG * WN * 32, T64 = WN / 2;
+    constexpr int NT = NWAVE * 64, CG = NWAVE / RSPLIT, CSW = CG * WN * 32, TPS = CG * WN / 2;  // 64-column image tiles per col-step
+    static_assert((CG * WN) % 2 == 0, "whole image tiles per col-step");
     constexpr int MB = WM * 2, CB = WN * 2, NK4 = NKS / 2;  // 16-row / 16-col blocks, 64-k steps
+    constexpr int AW = AWIN ? AWIN : MB;                     // rolling window of A operands (the product keeps 4)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     __shared__ int item_sh[2];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -256,28 +258,30 @@ __global__ __launch_bounds__(NWAVE * 64) void k16(Args a) {
             cur_panel = panel;
         }
         const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
-            (void*)uniform_ptr(a.Rf + (int64_t)cs0 * CG * T64 * TILEB), 0, (cs1 - cs0) * CG * T64 * TILEB, 0x00020000);
-        int so_tile = cgrp * T64 * TILEB;
+            (void*)uniform_ptr(a.Rf + (int64_t)cs0 * TPS * TILEB), 0, (cs1 - cs0) * TPS * TILEB, 0x00020000);
+        int so_tile = (cgrp * WN / 2) * TILEB;
+        const int boff = WN == 1 ? (cgrp & 1) * 2 : 0;  // WN = 1: two waves share a 64-column tile (V10)
         // a 64-k step of a 64-column image tile = 4 KiB = the B operands of its 4 column blocks
         i32x4 ring[PF][CB];
 #pragma unroll
         for (int dd = 0; dd < PF - 1; ++dd)
 #pragma unroll
-            for (int n = 0; n < CB; ++n) ring[dd][n] = bload(rs, lane16 + (n & 3) * 1024, so_tile + (n >> 2) * TILEB + dd * 4096);
-        i32x4 afr[MB];
+            for (int n = 0; n < CB; ++n) ring[dd][n] = bload(rs, lane16 + ((boff + n) & 3) * 1024, so_tile + (n >> 2) * TILEB + dd * 4096);
+        i32x4 afr[AW];
 #pragma unroll
-        for (int m = 0; m < MB; ++m) afr[m] = *reinterpret_cast<const i32x4*>(smem + abase[0] + m * 4096);
+        for (int m = 0; m < AW; ++m) afr[m] = *reinterpret_cast<const i32x4*>(smem + abase[0] + m * 4096);
         i32x4 acc[MB][CB] = {};
         for (int cs = cs0; cs < cs1; ++cs) {
             const int col0 = cs * CSW + cgrp * WN * 32;
             const i32x4 zero = {};
-            const int so_next = so_tile + CG * T64 * TILEB;
+            const int so_next = so_tile + TPS * TILEB;
 #pragma unroll
             for (int k4 = 0; k4 < NK4; ++k4) {
                 const int t = k4 + PF - 1;
                 const int so = (t < NK4) ? so_tile + t * 4096 : so_next + (t - NK4) * 4096;
                 const int kn = (k4 + 1) % NK4;
                 const char* anext = smem + (kn >> 2) * (PRW * 256) + abase[kn & 3];
+                const char* acur = smem + (k4 >> 2) * (PRW * 256) + abase[k4 & 3];
                 if (STUB & 4) {
                     // n-major: consecutive MFMAs share the B operand; A operands reloaded behind their last use (n = CB - 1)
 #pragma unroll
@@ -286,7 +290,7 @@ __global__ __launch_bounds__(NWAVE * 64) void k16(Args a) {
                         for (int m = 0; m < MB; ++m) {
                             acc[m][n] = __builtin_amdgcn_mfma_i32_16x16x64_i8(afr[m], ring[k4 % PF][n], (k4 == 0 && !EPI) ? zero : acc[m][n], 0, 0, 0);
                             if (n == CB - 1) afr[m] = *reinterpret_cast<const i32x4*>(anext + m * 4096);
-                            if (n == 0 && m < CB) ring[(k4 + PF - 1) % PF][m] = bload(rs, lane16 + (m & 3) * 1024, so + (m >> 2) * TILEB);
+                            if (n == 0 && m < CB) ring[(k4 + PF - 1) % PF][m] = bload(rs, lane16 + ((boff + m) & 3) * 1024, so + (m >> 2) * TILEB);
                         }
                     continue;
                 }
@@ -294,9 +298,10 @@ __global__ __launch_bounds__(NWAVE * 64) void k16(Args a) {
                 for (int m = 0; m < MB; ++m) {
 #pragma unroll
                     for (int n = 0; n < CB; ++n)
-                        acc[m][n] = __builtin_amdgcn_mfma_i32_16x16x64_i8(afr[m], ring[k4 % PF][n], (k4 == 0 && !EPI) ? zero : acc[m][n], 0, 0, 0);
-                    if (!(STUB & 2)) afr[m] = *reinterpret_cast<const i32x4*>(anext + m * 4096);
-                    if (m < CB && !(STUB & 1)) ring[(k4 + PF - 1) % PF][m] = bload(rs, lane16 + (m & 3) * 1024, so + (m >> 2) * TILEB);
+                        acc[m][n] = __builtin_amdgcn_mfma_i32_16x16x64_i8(afr[m % AW], ring[k4 % PF][n], (k4 == 0 && !EPI) ? zero : acc[m][n], 0, 0, 0);
+                    if (!(STUB & 2))
+                        afr[m % AW] = *reinterpret_cast<const i32x4*>(m + AW < MB ? acur + (m + AW) * 4096 : anext + (m + AW - MB) * 4096);
+                    if (m < CB && !(STUB & 1)) ring[(k4 + PF - 1) % PF][m] = bload(rs, lane16 + ((boff + m) & 3) * 1024, so + (m >> 2) * TILEB);
                     if (m < CB && (STUB & 1)) ring[(k4 + PF - 1) % PF][m] = ring[k4 % PF][m];
                 }
 #pragma unroll
@@ -630,6 +635,19 @@ int main(int argc, char** argv) {
                 run(nm, k16<128, 8, 1, 4, 2, 2>, a, 128, 8, 512, sc, R);
                 snprintf(nm, sizeof nm, "V1 16x16x64 slice %d cols, epilogue per item only", sc);
                 run(nm, k16<128, 8, 1, 4, 2, 2, 1>, a, 128, 8, 512, sc, R);
+            }
+    }
+    if (mode == 4) {
+        // V10: 256-row panel (128 KiB), 8 waves x (256 rows x 32 columns): reference bytes per MFMA halved, panel reads doubled
+        const int R = 4;
+        for (int rep = 0; rep < 2; ++rep)
+            for (int dens = 0; dens < 2; ++dens) {
+                a.thr = (int)((dens == 0 ? 9.f : 3.5f) * sig);
+                run("V1  16x16x64 P128 8w  128x64  PF2", k16<128, 8, 1, 4, 2, 2>, a, 128, 8, 512, slice_cols, R);
+                run("V1  same, rolling window of 4 A operands", k16<128, 8, 1, 4, 2, 2, 0, 0, 4>, a, 128, 8, 512, slice_cols, R);
+                run("V10 16x16x64 P256 8w  256x32  PF2 AW4", k16<256, 8, 1, 8, 1, 2, 0, 0, 4>, a, 256, 8, 256, slice_cols, R);
+                run("V10 16x16x64 P256 8w  256x32  PF2 AW8", k16<256, 8, 1, 8, 1, 2, 0, 0, 8>, a, 256, 8, 256, slice_cols, R);
+                run("V10 16x16x64 P256 8w  256x32  PF2 AW4 slice 32768", k16<256, 8, 1, 8, 1, 2, 0, 0, 4>, a, 256, 8, 256, 32768, R);
             }
     }
     if (mode == 3) {

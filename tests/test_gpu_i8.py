@@ -322,3 +322,47 @@ def test_int8_route_with_the_fp16_screen():
                         "not forced_ and not fp32_path_at_scale and not chosen_by and not fp16_screen and not ring_kernel"],
                        cwd=ROOT, env=e, capture_output=True, text=True, timeout=1800)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("nq,nr,d,K,k", [(1000, 6000, 512, 4000, 5), (129, 3000, 256, 700, 1), (300, 2500, 100, 900, 20),
+                                          (640, 4000, 768, 1500, 3)])
+def test_paired_work_items_give_the_same_candidates_and_results(gpu, orc, nq, nr, d, K, k):
+    """csrc/sim_i8p.hip HALVES = 2 (work items of two 128-row panels, wave tiles of 256 rows x 32 columns): each half keeps
+    its own scale, bound and thresholds, so the CANDIDATE SET is the one of the 128-row shape -- same count, same exact
+    results (odd panel counts: the last item's second half is all rows past the batch; 768-d: the shape does not fit the
+    LDS and the switch must change nothing)."""
+    rng = np.random.default_rng(nq + d)
+    q, r = unit(rng, nq, d), unit(rng, nr, d)
+    outs = []
+    for pair in ("0", "2"):
+        with env(VSC_PREFILTER="2", VSC_I8="2", VSC_I8P_PAIR=pair):
+            from vsc2022_amd.vsc.index import FlatIndex
+
+            idx = FlatIndex(d)
+        idx.profile(True)
+        idx.add(r)
+        top = idx.global_topk(q, K)
+        st_top = idx.profile_read(reset=True)
+        knn = idx.search(q, k)
+        st_knn = idx.profile_read(reset=True)
+        assert st_top["i8_launches"] > 0
+        outs.append((top, knn, st_top["candidates"], st_knn["candidates"]))
+    assert_same(outs[0][0][:3], outs[1][0][:3])
+    assert outs[0][0][3] == outs[1][0][3]
+    assert np.array_equal(bits(outs[0][1][0]), bits(outs[1][1][0])) and np.array_equal(outs[0][1][1], outs[1][1][1])
+    assert outs[0][2] == outs[1][2] and outs[0][3] == outs[1][3], (outs[0][2:], outs[1][2:])
+    assert_same(outs[1][0][:3], orc.global_threshold_search(q, r, K, 0))
+
+
+@pytest.mark.gpu
+def test_parity_suites_with_paired_int8_work_items():
+    """The int8 / search / pre-filter suites again with the paired shape on EVERY int8 launch (VSC_I8P_PAIR=2; by default
+    only launches with >= 512 items use it, i.e. none of the small cases of those files)."""
+    e = dict(os.environ, VSC_PREFILTER="2", VSC_I8="2", VSC_I8P_PAIR="2")
+    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", "tests/test_gpu_search.py",
+                        "tests/test_gpu_i8.py", "tests/test_gpu_prefilter.py", "tests/test_gpu_edge_cases.py", "-k",
+                        "not forced_prefilter and not fp32_path_at_scale and not chosen_by and not fp16_screen "
+                        "and not parity_suites and not paired_work_items and not ring_kernel"],
+                       cwd=ROOT, env=e, capture_output=True, text=True, timeout=1800)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]

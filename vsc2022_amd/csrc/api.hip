@@ -165,6 +165,7 @@ struct vsc_index {
     // (include/vscmi.h lists them)
     bool i8_exclude = true;      // VSC_I8_EXCLUDE=0: keep agreeing coordinates in the images
     int i8p_order = 1;           // VSC_I8P_ORDER: 1 slice-major work items (default), 0 panel-major with stealing
+    int i8p_pair = 1;            // VSC_I8P_PAIR: 1 work items of two panels where the launch is large enough (default), 0 never, 2 wherever legal
     int i8p_slice = 0;           // VSC_I8P_SLICE: col-steps per work item (0: 16 slice-major / the plan's panel-major)
     bool i8_sort_rows = true;    // VSC_I8_SORT=0: the rows of a launch keep their order
     int i8_group_shift = 9;      // VSC_I8_GROUP=<log2 rows>: radius searches with per-row thresholds order groups of 2^n rows by scale (0: off)
@@ -343,6 +344,7 @@ int vsc_index_create(int dim, int metric, int device, vsc_index_t** out) {
         idx->i8_exclude = !is("VSC_I8_EXCLUDE", '0');
         idx->i8p_order = (int)num("VSC_I8P_ORDER", 1.0) == 1 ? 1 : 0;
         idx->i8p_slice = (int)num("VSC_I8P_SLICE", 0.0);
+        idx->i8p_pair = std::max(0, std::min(2, (int)num("VSC_I8P_PAIR", 1.0)));
         idx->i8_sort_rows = !is("VSC_I8_SORT", '0');
         idx->i8_group_shift = getenv("VSC_I8_GROUP") ? std::max(0, std::min(16, (int)num("VSC_I8_GROUP", 9.0))) : 9;
         idx->rescore_by_ref = !is("VSC_RESCORE_SORT", '0');
@@ -712,9 +714,13 @@ static int enqueue_f16(vsc_index* idx, const float* qpacked, int64_t i0, int64_t
                 if (f.order == 1) f.slice = std::max(1, std::min(f.nsteps, slice_env > 0 ? slice_env : 32));
                 else if (slice_env > 0) f.slice = std::max(1, std::min(f.nsteps, slice_env));
             }
+            // work items of two panels (wave tiles of 256 rows x 32 columns: half the reference bytes per MFMA) where the
+            // launch is large enough; the quantised image then holds an even number of panels.  VSC_I8P_PAIR=0: off
+            f.pair = idx->i8p_pair && sim_i8p_pairs(idx->dpad8, f.npanel, f.nsteps, f.slice, idx->i8p_pair == 2) ? 1 : 0;
+            const int npanel_q = f.pair ? (f.npanel + 1) & ~1 : f.npanel;
             VSC_TRY(idx->ws.slices.reserve(((size_t)f.npanel + 1) * sizeof(int)));
-            VSC_TRY(idx->ws.q8.reserve((size_t)f.npanel * F16P_PANEL_ROWS * idx->dpad8));
-            VSC_TRY(idx->ws.pstat.reserve((size_t)f.npanel * sizeof(float4)));
+            VSC_TRY(idx->ws.q8.reserve((size_t)npanel_q * F16P_PANEL_ROWS * idx->dpad8));
+            VSC_TRY(idx->ws.pstat.reserve((size_t)npanel_q * sizeof(float4)));
             hipEvent_t prep_stop;
             VSC_TRY(prof_begin(idx, &prep_stop, 6));
             const int32_t* perm = nullptr;
@@ -731,12 +737,12 @@ static int enqueue_f16(vsc_index* idx, const float* qpacked, int64_t i0, int64_t
             // VSC_I8_SORT=0: rows in their own order (A/B; the kernel then gates blocks of unrelated thresholds)
             const bool sort_rows = idx->i8_sort_rows;
             if (thr_src && !sort_rows) {
-                VSC_TRY(idx->ws.rt8.reserve((size_t)f.npanel * F16P_PANEL_ROWS * sizeof(float)));
+                VSC_TRY(idx->ws.rt8.reserve((size_t)npanel_q * F16P_PANEL_ROWS * sizeof(float)));
                 rt_pos = idx->ws.rt8.as<float>();
             } else if (thr_src) {
                 // thresholds that differ from row to row: the launch sees its rows sorted by threshold (the kernel
                 // gates a tile by its panel's smallest threshold and a 16-row block by the block's)
-                VSC_TRY(idx->ws.rt8.reserve((size_t)f.npanel * F16P_PANEL_ROWS * sizeof(float)));
+                VSC_TRY(idx->ws.rt8.reserve((size_t)npanel_q * F16P_PANEL_ROWS * sizeof(float)));
                 rt_pos = idx->ws.rt8.as<float>();
                 if (idx->i8_group_shift > 0 && !row_thr && nqb >= (4 << idx->i8_group_shift)) {
                     // ... and, inside groups of 512 positions of that order, by the rows' largest element (sortpairs.hip).
@@ -763,7 +769,7 @@ static int enqueue_f16(vsc_index* idx, const float* qpacked, int64_t i0, int64_t
                 VSC_TRY(sort_rows_by_threshold(idx->ws.rt8b.as<float>(), nqb, idx->ws.w0, idx->ws.w1, idx->ws.w2, idx->ws.w3,
                                                idx->ws.tmp, &perm, idx->stream));
             }
-            VSC_TRY(launch_quant_query_panels(qpacked + i0 * idx->dpad, idx->dpad, nqb, f.npanel, idx->ws.q8.p, idx->dpad8,
+            VSC_TRY(launch_quant_query_panels(qpacked + i0 * idx->dpad, idx->dpad, nqb, npanel_q, idx->ws.q8.p, idx->dpad8,
                                               idx->ws.pstat.as<float4>(), perm, thr_src, rt_pos, idx->i8_ex, idx->stream));
             f.Q = idx->ws.q8.p;
             f.pstat = idx->ws.pstat.as<float4>();

@@ -68,6 +68,7 @@ struct SimI8PArgs {
     int npanel; int nsteps; int slice;     // work split (sim_f16p_plan)
     int* next_slice;                       // [npanel + 1]: per-panel slice counters + one global item counter
     int order;                             // 0: panel-major with stealing; 1: slice-major (all panels of a slice first)
+    int pair;                              // 1: work items of TWO panels, wave tiles of 256 rows x 32 columns (sim_i8p_pairs)
     float c_acc;                           // rounding of the exact fp32 chain per |q||r|
     const float* radius; const float* row_thr;  // as in SimF16Args (row_thr indexed by POSITION inside the launch)
     int32_t* out_i; int32_t* out_j;
@@ -149,6 +150,7 @@ int sort_candidates_by_ref(uint32_t*, uint32_t*, uint32_t*, uint32_t*, int64_t, 
 void sim_f16p_plan(int64_t nq, int64_t nr, int* npanel, int* nsteps, int* slice, int* grid);
 int launch_sim_f16p(const SimF16PArgs&, int grid, hipStream_t);
 int launch_sim_i8p(const SimI8PArgs&, int grid, hipStream_t);
+bool sim_i8p_pairs(int dpad8, int npanel, int nsteps, int slice, bool force);  // does a launch of this size use work items of two panels?
 int launch_quant_ref_frag(const float*, int, void*, float4*, int64_t, int64_t, int, const ExcludedDims&, hipStream_t);
 int launch_dim_minmax(const float*, int64_t, int, unsigned*, unsigned*, hipStream_t);
 int launch_meta_looseness(const float4*, int64_t, double*, hipStream_t);

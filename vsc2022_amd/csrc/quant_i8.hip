@@ -191,7 +191,7 @@ __global__ __launch_bounds__(512) void quant_query_panels_kernel(const float* __
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int row = tid >> 2, part = tid & 3;
     const int64_t grow = (int64_t)blockIdx.x * 128 + row;  // position inside the launch
-    const int64_t srow = perm ? (grow < nq ? (int64_t)perm[grow] : -1) : grow;
+    const int64_t srow = grow < nq ? (perm ? (int64_t)perm[grow] : grow) : -1;  // (positions past the batch: zero rows)
     const float4* src = reinterpret_cast<const float4*>(qpacked + (srow < 0 ? 0 : srow) * dpad);
     const int ngroup = srow < 0 ? 0 : dpad / 8, ngroup8 = dpad8 / 8;
     if (thr_out && part == 0) thr_out[grow] = grow < nq ? thr_src[srow] : INFINITY;

@@ -24,6 +24,14 @@
 // fp16 one (eps ~ 0.018 for unit 512-d rows: 4-5x as many candidates), which is why api.hip uses this kernel only
 // where hits are sparse.
 //
+// Two shapes (round 4, profiles/r04_i8_tiles_ubench.md V10).  HALVES = 1: the geometry above.  HALVES = 2 (512-d and below,
+// launches with enough panels): a work item holds TWO consecutive 128-row panels (128 KiB of LDS) and a wave tile is
+// 256 rows x 32 columns -- the same 128 accumulators, but every reference fragment a wave fetches from the L2 now
+// feeds 16 MFMAs instead of 8, and the panel reads (LDS) double instead.  The reference stream is the expensive operand
+// on this power-bound kernel (skeleton: no stream +19 %, no panel reads +6 %), the trade measured +5 % on the skeleton.
+// The two halves keep their own scale, bound coefficients and thresholds (quantisation stays per 128 rows), so the
+// candidate set is the same as HALVES = 1's, bit for bit.
+//
 // Epilogue.  C layout of the 16x16 MFMA: lane l holds column l & 15, rows 4 (l >> 4) + r of the block, r = 0..3.  A
 // wave tile is 8 row blocks x 4 column blocks; lane l owns the threshold arithmetic of ONE column, col0 + l (one
 // coalesced 16-byte meta load per lane and tile), and the four columns it holds accumulators of get their integer
@@ -45,7 +53,7 @@ namespace i8p {
 #endif
 
 constexpr int PR = F16P_PANEL_ROWS;  // 128
-constexpr int CSW = F16P_COL_STEP;   // 512
+static_assert(F16P_COL_STEP == 512, "a col-step is 8 waves x 64 columns (or 2 steps of 8 x 32)");
 #ifndef VSC_I8P_PF
 #define VSC_I8P_PF 2
 #endif
@@ -55,7 +63,7 @@ constexpr int CSW = F16P_COL_STEP;   // 512
 // slots with v_mov at the loop's back edge and copies registers whose loads have not landed (seen with PF = 3).
 constexpr int PF = VSC_I8P_PF;
 static_assert(PF == 2 || PF == 4, "the ring must divide the 4 steps of a 256-byte chunk");
-constexpr int MB = 8, CB = 4;   // 16-row / 16-column blocks of a wave tile
+constexpr int HB = 8;           // 16-row blocks of a 128-row panel (= of a half of a paired wave tile)
 constexpr int AW = 4;           // A operands in registers: a rolling window of AW row blocks (the next AW blocks of the m-major order)
 
 __device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rsrc, int voff, char* lds) {
@@ -78,8 +86,12 @@ __device__ __forceinline__ void meta_wait(f32x4v& m) {
     asm volatile("s_waitcnt vmcnt(%1)" : "+v"(m) : "n"(N));
 }
 template <int N>
-__device__ __forceinline__ void ring_wait(i32x4 (&b)[CB]) {
+__device__ __forceinline__ void ring_wait(i32x4 (&b)[4]) {
     asm volatile("s_waitcnt vmcnt(%4)" : "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]) : "n"(N));
+}
+template <int N>
+__device__ __forceinline__ void ring_wait(i32x4 (&b)[2]) {
+    asm volatile("s_waitcnt vmcnt(%2)" : "+v"(b[0]), "+v"(b[1]) : "n"(N));
 }
 __device__ __forceinline__ const char* uniform_ptr(const char* p) {
     const uint64_t v = reinterpret_cast<uint64_t>(p);
@@ -100,18 +112,19 @@ __device__ __forceinline__ float lane_f(float x, int l) {
 // 4 KiB of consecutive image (column block n: 1 KiB at n * 1024), refilled PF - 1 steps ahead; the stream continues
 // into the wave's next tile at `so_next`.  Straight-line code, every LDS address = base register + immediate; issue
 // order pinned.
-template <int NKC>
+template <int NKC, int MB, int CB>
 __device__ __forceinline__ void tile_mma(const char* smem, const int (&abase)[4], i32x4 (&a)[AW], i32x4 (&ring)[PF][CB],
                                          __amdgpu_buffer_rsrc_t rs, int so_tile, int so_next, int lane16,
                                          i32x4 (&acc)[MB][CB]) {
     const i32x4 zero = {0, 0, 0, 0};
     constexpr int NK4 = NKC * 4;
+    constexpr int KCB = MB * 4096;  // bytes per 256-byte k chunk of the LDS panel (MB * 16 rows x 256 B)
 #pragma unroll
     for (int k4 = 0; k4 < NK4; ++k4) {
         const int t = k4 + PF - 1;  // step that goes into the ring slot freed by step k4 - 1
         const int so = (t < NK4) ? so_tile + t * 4096 : so_next + (t - NK4) * 4096;
         // all four fragments of this step have landed once at most the 4 (PF - 2) loads of the younger steps are out
-        ring_wait<4 * (PF - 2)>(ring[k4 % PF]);
+        ring_wait<CB * (PF - 2)>(ring[k4 % PF]);
 #pragma unroll
         for (int m = 0; m < MB; ++m) {
 #pragma unroll
@@ -120,12 +133,14 @@ __device__ __forceinline__ void tile_mma(const char* smem, const int (&abase)[4]
             {
                 // the block AW places on (the next tile starts at step 0 again)
                 const int kn = (k4 + (m + AW) / MB) % NK4, mn = (m + AW) % MB;
-                a[m % AW] = *reinterpret_cast<const i32x4*>(smem + (kn >> 2) * 32768 + abase[kn & 3] + mn * 4096);
+                a[m % AW] = *reinterpret_cast<const i32x4*>(smem + (kn >> 2) * KCB + abase[kn & 3] + mn * 4096);
             }
             if (m == 0) bload_asm<0>(ring[(k4 + PF - 1) % PF][0], rs, lane16, so);
             if (m == 1) bload_asm<1024>(ring[(k4 + PF - 1) % PF][1], rs, lane16, so);
-            if (m == 2) bload_asm<2048>(ring[(k4 + PF - 1) % PF][2], rs, lane16, so);
-            if (m == 3) bload_asm<3072>(ring[(k4 + PF - 1) % PF][3], rs, lane16, so);
+            if (CB > 2) {
+                if (m == 2) bload_asm<2048>(ring[(k4 + PF - 1) % PF][2 % CB], rs, lane16, so);
+                if (m == 3) bload_asm<3072>(ring[(k4 + PF - 1) % PF][3 % CB], rs, lane16, so);
+            }
         }
 #pragma unroll
         for (int m = 0; m < MB; ++m) {
@@ -175,7 +190,8 @@ __device__ __forceinline__ int bperm(int src_lane, int v) { return __builtin_amd
 // (the radius; the panel's smallest row threshold).  ROWTHR: a column block that passes is re-tested per 16-row
 // block against rt16[m], the block's smallest row threshold, with the column's own (eps, inv) fetched from the lane
 // that owns it.  General form: edge tiles, full segments, pass-everything columns.
-template <bool ROWTHR>
+// (M0: the first 16-row block of the half this call is about -- its HB blocks share tc / cm / eps_own / inv_own)
+template <bool ROWTHR, int MB, int CB, int M0>
 __device__ __forceinline__ void emit_candidates(const SimI8PArgs& a, const int (&tc)[CB], const int (&cm)[CB],
                                                 const float (&rt16)[MB], float eps_own, float inv_own, int row0, int col0,
                                                 bool interior, const i32x4 (&acc)[MB][CB], int64_t seg_base, int& count,
@@ -190,7 +206,7 @@ __device__ __forceinline__ void emit_candidates(const SimI8PArgs& a, const int (
             inv_c = __builtin_bit_cast(float, bperm(src, __builtin_bit_cast(int, inv_own)));
         }
 #pragma unroll
-        for (int m = 0; m < MB; ++m) {
+        for (int m = M0; m < M0 + HB; ++m) {
             // a block is tested against the tile's common threshold first: a block's own threshold is never below it
             // (rt16[m] >= the panel's smallest row threshold, and column_threshold is monotone in t), so the
             // arithmetic of the block's threshold is spent only on blocks that can hold a candidate (PMC, round 4: with
@@ -232,7 +248,7 @@ __device__ __forceinline__ void emit_candidates(const SimI8PArgs& a, const int (
 
 // The fast path: interior tile, room for a whole tile (8192 entries) left in the wave's segment: position = count +
 // (lanes of this register's ballot below me), two buffer stores with a 32-bit offset.
-template <bool ROWTHR>
+template <bool ROWTHR, int MB, int CB, int M0>
 __device__ __forceinline__ void emit_candidates_seg(const SimI8PArgs& a, const int (&tc)[CB], const int (&cm)[CB],
                                                     const float (&rt16)[MB], float eps_own, float inv_own, int row0,
                                                     int col0, const i32x4 (&acc)[MB][CB], __amdgpu_buffer_rsrc_t rs_i,
@@ -250,7 +266,7 @@ __device__ __forceinline__ void emit_candidates_seg(const SimI8PArgs& a, const i
             inv_c = __builtin_bit_cast(float, bperm(src, __builtin_bit_cast(int, inv_own)));
         }
 #pragma unroll
-        for (int m = 0; m < MB; ++m) {
+        for (int m = M0; m < M0 + HB; ++m) {
             // a block is tested against the tile's common threshold first: a block's own threshold is never below it
             // (rt16[m] >= the panel's smallest row threshold, and column_threshold is monotone in t), so the
             // arithmetic of the block's threshold is spent only on blocks that can hold a candidate (PMC, round 4: with
@@ -279,11 +295,15 @@ __device__ __forceinline__ void emit_candidates_seg(const SimI8PArgs& a, const i
 
 }  // namespace i8p
 
-template <int NKC, bool ROWTHR>
+template <int NKC, bool ROWTHR, int HALVES>
 __global__ __launch_bounds__(512) void sim_i8p_kernel(SimI8PArgs a) {
     using namespace i8p;
-    extern __shared__ __attribute__((aligned(16))) char smem[];  // the panel: NKC x 32 KiB
-    __shared__ float rt_sh[ROWTHR ? PR : 1];
+    constexpr int MB = HB * HALVES, CB = 4 / HALVES;  // 16-row / 16-column blocks of a wave tile: 8 x 4 or 16 x 2
+    constexpr int PRW = PR * HALVES;                  // rows of a work item's panel (HALVES consecutive 128-row panels)
+    constexpr int WCOLS = 16 * CB;                    // columns of a wave tile; 8 waves side by side = one step
+    constexpr int TPS = 8 / HALVES;                   // 64-column image tiles per step
+    extern __shared__ __attribute__((aligned(16))) char smem[];  // the panel: NKC x 32 KiB x HALVES
+    __shared__ float rt_sh[ROWTHR ? PRW : 1];
     __shared__ int item_sh[2];
     __shared__ TailExt tail_sh[8];
 #if VSC_I8P_ABLATE
@@ -294,7 +314,9 @@ __global__ __launch_bounds__(512) void sim_i8p_kernel(SimI8PArgs a) {
     constexpr int NK4 = NKC * 4;
     constexpr int ROWB = NKC * 256;    // bytes per int8 row
     constexpr int TILEB = NK4 * 4096;  // bytes per 64-row wave tile of the fragment-major image
-    const int lane16 = lane * 16;
+    // byte offset of this lane's piece inside a 4 KiB step of an image tile (paired shape: the odd waves take the
+    // tile's column blocks 2 and 3)
+    const int lane16 = lane * 16 + (HALVES == 2 ? (wave & 1) * 2048 : 0);
     // A operand of row block m at step k4: row 16 m + (lane & 15), 16-byte piece 4 (k4 & 3) + (lane >> 4) of chunk
     // k4 >> 2; LDS image [k chunk of 256 B][row][piece ^ (row & 15)] (conflict-free: the 16 lanes of a ds_read_b128
     // phase hold 16 different pieces ^ rows)
@@ -313,13 +335,19 @@ __global__ __launch_bounds__(512) void sim_i8p_kernel(SimI8PArgs a) {
         (void*)uniform_ptr(reinterpret_cast<const char*>(a.out_i + seg_base)), 0, a.seg_cap * 4, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_cj = __builtin_amdgcn_make_buffer_rsrc(
         (void*)uniform_ptr(reinterpret_cast<const char*>(a.out_j + seg_base)), 0, a.seg_cap * 4, 0x00020000);
+    // work items: (slice of a.slice 512-column col-steps, panel of PRW rows); a.npanel counts 128-row panels
+    const int npan = (a.npanel + HALVES - 1) / HALVES;
     const int nslice = (a.nsteps + a.slice - 1) / a.slice;
     int cur_panel = -1;
-    // per panel (wave-uniform): 1 / s_q and the coefficients of N'_r, E_r and N_r in eps
-    float inv_sq = 1.0f, coef_k = 0.0f, coef_e = 0.0f, coef_n = 0.0f;
-    float rt16[MB] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};  // smallest row threshold per 16-row block
-    float rt_panel = 0.f;                                        // ... and of the whole panel
-    int panel = blockIdx.x % a.npanel;
+    // per 128-row panel (wave-uniform): 1 / s_q and the coefficients of N'_r, E_r and N_r in eps
+    float inv_sq[HALVES], coef_k[HALVES], coef_e[HALVES], coef_n[HALVES];
+    float rt16[MB];         // smallest row threshold per 16-row block
+    float rt_half[HALVES];  // ... and per 128-row panel
+#pragma unroll
+    for (int h = 0; h < HALVES; ++h) { inv_sq[h] = 1.0f; coef_k[h] = coef_e[h] = coef_n[h] = 0.0f; rt_half[h] = 0.0f; }
+#pragma unroll
+    for (int m = 0; m < MB; ++m) rt16[m] = 0.0f;
+    int panel = blockIdx.x % npan;
     for (;;) {
         // ---- next work item: a slice of this workgroup's panel, else of the panel with the most left
         __syncthreads();
@@ -332,11 +360,11 @@ __global__ __launch_bounds__(512) void sim_i8p_kernel(SimI8PArgs a) {
             if (a.order == 1 && !lost) {
                 // slice-major: items (slice, panel) in one global order -- every workgroup of the chip is inside
                 // the same few MB of the reference image, each XCD fetches a slice once; the price is a panel load
-                // (64 KiB at 512-d) per item
+                // (64 KiB per 128 rows at 512-d) per item
                 int t = 0;
                 if (lane == 0) t = atomicAdd(&a.next_slice[a.npanel], 1);
                 t = __shfl(t, 0);
-                if (t >= nslice * a.npanel) { p = -1; } else { s = t / a.npanel; p = t - s * a.npanel; }
+                if (t >= nslice * npan) { p = -1; } else { s = t / npan; p = t - s * npan; }
             } else
             for (;;) {
                 if (lost) { p = -1; break; }
@@ -344,11 +372,11 @@ __global__ __launch_bounds__(512) void sim_i8p_kernel(SimI8PArgs a) {
                 s = __shfl(s, 0);
                 if (s < nslice) break;
                 int best = 0x7fffffff, bp = 0x7fffffff;
-                for (int q0 = 0; q0 < a.npanel; q0 += 64) {
+                for (int q0 = 0; q0 < npan; q0 += 64) {
                     const int q = q0 + lane;
-                    const int pp = (q + (int)blockIdx.x) % a.npanel;  // ties: nearest after the workgroup's own
-                    const int v = q < a.npanel ? __hip_atomic_load(&a.next_slice[pp], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
-                                               : 0x7fffffff;
+                    const int pp = (q + (int)blockIdx.x) % npan;  // ties: nearest after the workgroup's own
+                    const int v = q < npan ? __hip_atomic_load(&a.next_slice[pp], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                                           : 0x7fffffff;
                     if (v < best) { best = v; bp = pp; }
                 }
 #pragma unroll
@@ -365,126 +393,158 @@ __global__ __launch_bounds__(512) void sim_i8p_kernel(SimI8PArgs a) {
         panel = item_sh[0];
         const int sl = item_sh[1];
         if (panel < 0) break;
-        const int cs0 = sl * a.slice, cs1 = min(a.nsteps, cs0 + a.slice);
+        // steps of 8 x WCOLS columns (HALVES per 512-column col-step)
+        const int cs0 = sl * a.slice * HALVES, cs1 = min(a.nsteps, (sl + 1) * a.slice) * HALVES;
         if (panel != cur_panel) {
             __syncthreads();  // (item_sh is read; nobody reads the old panel any more)
             // query panel -> LDS [k chunk of 256 B][row][slot ^ (row & 15)]: the swizzle is applied to the SOURCE
-            // address, an LDS-DMA instruction writes its 64 x 16 bytes to consecutive LDS addresses
+            // address, an LDS-DMA instruction writes its 64 x 16 bytes to consecutive LDS addresses.  (Paired shape:
+            // the host quantises an even number of 128-row panels, the last one possibly all rows past the batch.)
             const __amdgpu_buffer_rsrc_t qrs = __builtin_amdgcn_make_buffer_rsrc(
-                (void*)uniform_ptr(reinterpret_cast<const char*>(a.Q) + (int64_t)panel * PR * ROWB), 0, PR * ROWB, 0x00020000);
+                (void*)uniform_ptr(reinterpret_cast<const char*>(a.Q) + (int64_t)panel * PRW * ROWB), 0, PRW * ROWB, 0x00020000);
 #pragma unroll
-            for (int n = 0; n < NKC * 4; ++n) {
+            for (int n = 0; n < NKC * 4 * HALVES; ++n) {
                 const int p = n * 512 + tid;
-                const int kc = p >> 11, row = (p >> 4) & 127, slot = p & 15;
+                const int kc = p / (PRW * 16), row = (p >> 4) % PRW, slot = p & 15;
                 const int c = kc * 16 + (slot ^ (row & 15));
                 dma16(qrs, row * ROWB + c * 16, smem + (n * 512 + wave * 64) * 16);
             }
-            const float4 ps = a.pstat[panel];  // {1 / s_q, max E_q, max N_q, max N'_q}
-            inv_sq = uniform_f(ps.x);
-            // eps_j = E_q N'_r + (N'_q + E_q) E_r + c_acc N_q N_r   (N' = norm over the coordinates the images hold)
-            coef_k = uniform_f(ps.y);
-            coef_e = uniform_f(ps.w + ps.y);
-            coef_n = uniform_f(a.c_acc * ps.z);
-            if (ROWTHR && tid < PR) rt_sh[tid] = panel * PR + tid < a.nq ? a.row_thr[(int64_t)panel * PR + tid] : INFINITY;
+#pragma unroll
+            for (int h = 0; h < HALVES; ++h) {
+                const float4 ps = a.pstat[panel * HALVES + h];  // {1 / s_q, max E_q, max N_q, max N'_q}
+                inv_sq[h] = uniform_f(ps.x);
+                // eps_j = E_q N'_r + (N'_q + E_q) E_r + c_acc N_q N_r   (N' = norm over the coordinates the images hold)
+                coef_k[h] = uniform_f(ps.y);
+                coef_e[h] = uniform_f(ps.w + ps.y);
+                coef_n[h] = uniform_f(a.c_acc * ps.z);
+            }
+            if (ROWTHR && tid < PRW) rt_sh[tid] = panel * PRW + tid < a.nq ? a.row_thr[(int64_t)panel * PRW + tid] : INFINITY;
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's DMA pieces have landed ...
             __syncthreads();                                  // ... and so have everybody else's
             if (ROWTHR) {
-                float v0 = rt_sh[lane], v1 = rt_sh[64 + lane];
 #pragma unroll
-                for (int off = 8; off > 0; off >>= 1) {
-                    v0 = fminf(v0, __shfl_xor(v0, off));
-                    v1 = fminf(v1, __shfl_xor(v1, off));
+                for (int g = 0; g < PRW / 64; ++g) {
+                    float v = rt_sh[64 * g + lane];
+#pragma unroll
+                    for (int off = 8; off > 0; off >>= 1) v = fminf(v, __shfl_xor(v, off));
+#pragma unroll
+                    for (int m = 0; m < 4; ++m) rt16[4 * g + m] = lane_f(v, 16 * m);
                 }
 #pragma unroll
-                for (int m = 0; m < 4; ++m) {
-                    rt16[m] = lane_f(v0, 16 * m);
-                    rt16[4 + m] = lane_f(v1, 16 * m);
-                }
-                rt_panel = fminf(fminf(fminf(rt16[0], rt16[1]), fminf(rt16[2], rt16[3])),
-                                 fminf(fminf(rt16[4], rt16[5]), fminf(rt16[6], rt16[7])));
+                for (int h = 0; h < HALVES; ++h)
+                    rt_half[h] = fminf(fminf(fminf(rt16[8 * h], rt16[8 * h + 1]), fminf(rt16[8 * h + 2], rt16[8 * h + 3])),
+                                       fminf(fminf(rt16[8 * h + 4], rt16[8 * h + 5]), fminf(rt16[8 * h + 6], rt16[8 * h + 7])));
                 // (NaN row thresholds: fminf drops them unless a whole block holds nothing else -- that block then passes
                 // everything on the re-test; the exact stage keeps nothing of a row whose threshold is NaN either way)
             }
             cur_panel = panel;
         }
-        // ---- this wave's stream: tiles (cs * 8 + wave), cs = cs0 .. cs1-1, TILEB contiguous bytes each
+        // ---- this wave's stream: image tiles cs * TPS + wave / HALVES, cs = cs0 .. cs1-1, TILEB contiguous bytes each
         const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
-            (void*)uniform_ptr(reinterpret_cast<const char*>(a.Rf) + (int64_t)cs0 * 8 * TILEB), 0, (cs1 - cs0) * 8 * TILEB,
+            (void*)uniform_ptr(reinterpret_cast<const char*>(a.Rf) + (int64_t)cs0 * TPS * TILEB), 0, (cs1 - cs0) * TPS * TILEB,
             0x00020000);
-        int so_tile = wave * TILEB;
+        int so_tile = (wave / HALVES) * TILEB;
         i32x4 ring[PF][CB];
 #pragma unroll
         for (int dd = 0; dd < PF - 1; ++dd) {
             bload_asm<0>(ring[dd][0], rs, lane16, so_tile + dd * 4096);
             bload_asm<1024>(ring[dd][1], rs, lane16, so_tile + dd * 4096);
-            bload_asm<2048>(ring[dd][2], rs, lane16, so_tile + dd * 4096);
-            bload_asm<3072>(ring[dd][3], rs, lane16, so_tile + dd * 4096);
+            if (CB > 2) {
+                bload_asm<2048>(ring[dd][2 % CB], rs, lane16, so_tile + dd * 4096);
+                bload_asm<3072>(ring[dd][3 % CB], rs, lane16, so_tile + dd * 4096);
+            }
         }
         i32x4 afr[AW];
 #pragma unroll
         for (int m = 0; m < AW; ++m) afr[m] = *reinterpret_cast<const i32x4*>(smem + abase[0] + m * 4096);
         for (int cs = cs0; cs < cs1; ++cs) {
-            const int col0 = cs * CSW + wave * 64;
-            // {1 / s_r, E_r, N_r, N'_r} of column col0 + lane (the table is padded to whole col-steps): issued behind the
-            // stream loads of the previous tile, ahead of this tile's -- after the K loop only the 4 (PF - 1) stream
-            // loads of the next tile are younger
+            const int col0 = cs * (8 * WCOLS) + wave * WCOLS;
+            // {1 / s_r, E_r, N_r, N'_r} of the column this lane does the threshold arithmetic of (the table is padded to
+            // whole col-steps): issued behind the stream loads of the previous tile, ahead of this tile's -- after the K
+            // loop only the CB (PF - 1) stream loads of the next tile are younger
             f32x4v mt;
-            gload_asm(mt, a.rmeta + col0 + lane);
+            gload_asm(mt, a.rmeta + col0 + (lane & (WCOLS - 1)));
             i32x4 acc[MB][CB];
-            tile_mma<NKC>(smem, abase, afr, ring, rs, so_tile, so_tile + 8 * TILEB, lane16, acc);
-            so_tile += 8 * TILEB;
-            meta_wait<4 * (PF - 1)>(mt);
-            // this lane's column: eps, 1 / (s_q s_r); +inf eps = "pass everything" (see column_threshold)
-            float eps_own = (coef_k * mt.w + coef_e * mt.y + coef_n * mt.z) * 1.001f;
-            const float inv_own = inv_sq * mt.x;
-            if (!(eps_own < INFINITY) || !(inv_own >= 1e-30f && inv_own < INFINITY)) eps_own = INFINITY;
-            const int t_own = column_threshold<ROWTHR>(ROWTHR ? rt_panel : radius, eps_own, inv_own);
-            // ... and the thresholds of the four columns this lane holds accumulators of
-            int tc[CB], cm[CB];
+            tile_mma<NKC, MB, CB>(smem, abase, afr, ring, rs, so_tile, so_tile + TPS * TILEB, lane16, acc);
+            so_tile += TPS * TILEB;
+            meta_wait<CB * (PF - 1)>(mt);
+            // this lane's column: eps, 1 / (s_q s_r) per 128-row panel; +inf eps = "pass everything" (see column_threshold)
+            float eps_own[HALVES], inv_own[HALVES];
+            int tc[HALVES][CB], cm[HALVES][CB];
             bool any_col = false;
+#pragma unroll
+            for (int h = 0; h < HALVES; ++h) {
+                eps_own[h] = (coef_k[h] * mt.w + coef_e[h] * mt.y + coef_n[h] * mt.z) * 1.001f;
+                inv_own[h] = inv_sq[h] * mt.x;
+                if (!(eps_own[h] < INFINITY) || !(inv_own[h] >= 1e-30f && inv_own[h] < INFINITY)) eps_own[h] = INFINITY;
+                const int t_own = column_threshold<ROWTHR>(ROWTHR ? rt_half[h] : radius, eps_own[h], inv_own[h]);
+                // ... and the thresholds of the columns this lane holds accumulators of
 #if VSC_I8P_ABLATE == 2
 #pragma unroll
-            for (int n = 0; n < CB; ++n) {
-                // no maxima: one accumulator of every block stands in for the block (keeps the MFMAs alive)
-                tc[n] = t_own;
-                int y = acc[0][n][0];
-                for (int m = 1; m < MB; ++m) y |= acc[m][n][m & 3];
-                cm[n] = y;
-                any_col |= y == 0x12345678;
-            }
+                for (int n = 0; n < CB; ++n) tc[h][n] = t_own;
 #else
 #pragma unroll
-            for (int n = 0; n < CB; ++n) tc[n] = bperm(n * 16 + (lane & 15), t_own);
-            // the lane's 32 accumulators of each column block (8 row blocks x 4 registers): 16 v_max3 per block, the
-            // four blocks' chains advanced together (a chain of dependent v_max3 issues every ~8 cycles, four
+                for (int n = 0; n < CB; ++n) tc[h][n] = bperm(n * 16 + (lane & 15), t_own);
+#endif
+            }
+#if VSC_I8P_ABLATE == 2
+#pragma unroll
+            for (int h = 0; h < HALVES; ++h)
+#pragma unroll
+                for (int n = 0; n < CB; ++n) {
+                    // no maxima: one accumulator of every block stands in for the block (keeps the MFMAs alive)
+                    int y = acc[HB * h][n][0];
+                    for (int m = 1; m < HB; ++m) y |= acc[HB * h + m][n][m & 3];
+                    cm[h][n] = y;
+                    any_col |= y == 0x12345678;
+                }
+#else
+            // the lane's 32 accumulators of each (128-row panel, column block) (8 row blocks x 4 registers): 16 v_max3
+            // each, the four chains advanced together (a chain of dependent v_max3 issues every ~8 cycles, four
             // independent ones keep the VALU fed).  Measured (round 4, -DVSC_I8P_ABLATE): these maxima + the threshold
             // distribution cost 9 % of the kernel, the emission of this workload's candidates 1 %; starting the second
             // wave of every SIMD 2000-4000 cycles late so that the two waves' epilogues do not coincide: +-0
             {
-                int x[CB];
+                int x[HALVES][CB];
 #pragma unroll
-                for (int n = 0; n < CB; ++n) x[n] = max(max(acc[0][n][0], acc[0][n][1]), acc[0][n][2]);
+                for (int h = 0; h < HALVES; ++h)
+#pragma unroll
+                    for (int n = 0; n < CB; ++n) x[h][n] = max(max(acc[HB * h][n][0], acc[HB * h][n][1]), acc[HB * h][n][2]);
 #pragma unroll
                 for (int k = 3; k < 31; k += 2)
 #pragma unroll
-                    for (int n = 0; n < CB; ++n) x[n] = max(max(x[n], acc[k >> 2][n][k & 3]), acc[(k + 1) >> 2][n][(k + 1) & 3]);
+                    for (int h = 0; h < HALVES; ++h)
 #pragma unroll
-                for (int n = 0; n < CB; ++n) {
-                    cm[n] = max(x[n], acc[7][n][3]);
-                    any_col |= cm[n] > tc[n];
-                }
+                        for (int n = 0; n < CB; ++n)
+                            x[h][n] = max(max(x[h][n], acc[HB * h + (k >> 2)][n][k & 3]), acc[HB * h + ((k + 1) >> 2)][n][(k + 1) & 3]);
+#pragma unroll
+                for (int h = 0; h < HALVES; ++h)
+#pragma unroll
+                    for (int n = 0; n < CB; ++n) {
+                        cm[h][n] = max(x[h][n], acc[HB * h + 7][n][3]);
+                        any_col |= cm[h][n] > tc[h][n];
+                    }
             }
 #endif
 #if VSC_I8P_ABLATE
             if (__any(any_col) && lane == 0) ablate_sink = col0;  // (keeps the accumulators alive)
 #endif
             if (VSC_I8P_ABLATE == 0 && __any(any_col)) {
-                const bool interior = panel * PR + PR <= a.nq && col0 + 64 <= a.nr;
+                const bool interior = panel * PRW + PRW <= a.nq && col0 + WCOLS <= a.nr;
                 if (interior && count + 8192 <= a.seg_cap) {
-                    emit_candidates_seg<ROWTHR>(a, tc, cm, rt16, eps_own, inv_own, panel * PR, col0, acc, rs_ci, rs_cj, count);
+                    emit_candidates_seg<ROWTHR, MB, CB, 0>(a, tc[0], cm[0], rt16, eps_own[0], inv_own[0], panel * PRW, col0, acc,
+                                                           rs_ci, rs_cj, count);
+                    if (HALVES == 2)
+                        emit_candidates_seg<ROWTHR, MB, CB, HB*(HALVES - 1)>(a, tc[HALVES - 1], cm[HALVES - 1], rt16, eps_own[HALVES - 1],
+                                                                              inv_own[HALVES - 1], panel * PRW, col0, acc, rs_ci, rs_cj,
+                                                                              count);
                 } else {
-                    emit_candidates<ROWTHR>(a, tc, cm, rt16, eps_own, inv_own, panel * PR, col0, interior, acc, seg_base, count,
-                                            &tail_sh[wave]);
+                    emit_candidates<ROWTHR, MB, CB, 0>(a, tc[0], cm[0], rt16, eps_own[0], inv_own[0], panel * PRW, col0, interior, acc,
+                                                       seg_base, count, &tail_sh[wave]);
+                    if (HALVES == 2)
+                        emit_candidates<ROWTHR, MB, CB, HB*(HALVES - 1)>(a, tc[HALVES - 1], cm[HALVES - 1], rt16, eps_own[HALVES - 1],
+                                                                          inv_own[HALVES - 1], panel * PRW, col0, interior, acc, seg_base,
+                                                                          count, &tail_sh[wave]);
                 }
             }
         }
@@ -497,24 +557,34 @@ __global__ __launch_bounds__(512) void sim_i8p_kernel(SimI8PArgs a) {
     if (lane == 0) a.seg_count[seg] = count;
 }
 
-template <int NKC>
+template <int NKC, int HALVES>
 static int launch_nkc(const SimI8PArgs& a, int grid, hipStream_t stream) {
-    const int lds = NKC * 32768;
+    const int lds = NKC * 32768 * HALVES;
     static PerDeviceOnce once;
     if (once.first()) {
-        VSC_HIP(hipFuncSetAttribute((const void*)sim_i8p_kernel<NKC, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        VSC_HIP(hipFuncSetAttribute((const void*)sim_i8p_kernel<NKC, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        VSC_HIP(hipFuncSetAttribute((const void*)sim_i8p_kernel<NKC, false, HALVES>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        VSC_HIP(hipFuncSetAttribute((const void*)sim_i8p_kernel<NKC, true, HALVES>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         once.commit();
     }
     if (a.row_thr)
-        hipLaunchKernelGGL((sim_i8p_kernel<NKC, true>), dim3((unsigned)grid), dim3(512), lds, stream, a);
+        hipLaunchKernelGGL((sim_i8p_kernel<NKC, true, HALVES>), dim3((unsigned)grid), dim3(512), lds, stream, a);
     else
-        hipLaunchKernelGGL((sim_i8p_kernel<NKC, false>), dim3((unsigned)grid), dim3(512), lds, stream, a);
+        hipLaunchKernelGGL((sim_i8p_kernel<NKC, false, HALVES>), dim3((unsigned)grid), dim3(512), lds, stream, a);
     VSC_HIP(hipGetLastError());
     return VSC_OK;
 }
 
-// (the work split is sim_f16p_plan's: same panel and col-step geometry)
+// The paired shape needs 2 x NKC x 32 KiB of LDS (512-d and below) and enough items to fill the chip; an odd number of
+// 128-row panels leaves half of the last item empty.  api.hip asks before it sizes the quantised image.
+bool sim_i8p_pairs(int dpad8, int npanel, int nsteps, int slice, bool force) {
+    if (dpad8 > 512 || npanel < 1) return false;
+    if (force) return true;  // (tests: every launch the shape can take)
+    if (npanel < 2) return false;
+    const long long items = (long long)((npanel + 1) / 2) * ((nsteps + slice - 1) / slice);
+    return items >= 512 && (npanel % 2 == 0 || npanel >= 25);
+}
+
+// (the work split is sim_f16p_plan's: same panel and col-step geometry; a.pair: work items of two panels)
 int launch_sim_i8p(const SimI8PArgs& a, int grid, hipStream_t stream) {
     if (grid <= 0 || a.npanel <= 0 || a.nsteps <= 0) {
         // nothing to search: the caller's exact stage must see empty segments, not stale fill levels
@@ -522,11 +592,19 @@ int launch_sim_i8p(const SimI8PArgs& a, int grid, hipStream_t stream) {
         return VSC_OK;
     }
     VSC_HIP(hipMemsetAsync(a.next_slice, 0, ((size_t)a.npanel + 1) * sizeof(int), stream));
+    if (a.pair) {
+        switch (a.dpad8) {
+            case 256: return launch_nkc<1, 2>(a, grid, stream);
+            case 512: return launch_nkc<2, 2>(a, grid, stream);
+        }
+        set_error("sim_i8p: the paired shape takes dpad8 256 or 512, not %d", a.dpad8);
+        return VSC_ERR_INVALID;
+    }
     switch (a.dpad8) {
-        case 256: return launch_nkc<1>(a, grid, stream);
-        case 512: return launch_nkc<2>(a, grid, stream);
-        case 768: return launch_nkc<3>(a, grid, stream);
-        case 1024: return launch_nkc<4>(a, grid, stream);
+        case 256: return launch_nkc<1, 1>(a, grid, stream);
+        case 512: return launch_nkc<2, 1>(a, grid, stream);
+        case 768: return launch_nkc<3, 1>(a, grid, stream);
+        case 1024: return launch_nkc<4, 1>(a, grid, stream);
     }
     set_error("sim_i8p: dpad8 %d is not one of 256, 512, 768, 1024", a.dpad8);
     return VSC_ERR_INVALID;
