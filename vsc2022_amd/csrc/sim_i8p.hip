@@ -61,8 +61,14 @@ static_assert(F16P_COL_STEP == 512, "a col-step is 8 waves x 64 columns (or 2 st
 // steps of a tile (4 per 256 bytes of row): the ring is carried from tile to tile in REGISTERS that asynchronous loads
 // are still writing, so the slot a step lands in must not depend on the tile -- otherwise the compiler rotates the
 // slots with v_mov at the loop's back edge and copies registers whose loads have not landed (seen with PF = 3).
-constexpr int PF = VSC_I8P_PF;
-static_assert(PF == 2 || PF == 4, "the ring must divide the 4 steps of a 256-byte chunk");
+#ifndef VSC_I8P_PF2
+#define VSC_I8P_PF2 4  // ... of the paired shape (2 KiB per step and wave there; ring of 2 / 4: 1366 / 1341 ms of int8 kernel per configs[3] step)
+#endif
+// (256-d paired: the deeper ring drives the compiler into hundreds of spills -- and a spilled ring register is read
+// before its load has landed; every variant's "VGPRs Spill" is checked after a change here)
+template <int HALVES, int NKC> struct RingDepth { static constexpr int v = HALVES == 2 && NKC == 2 ? VSC_I8P_PF2 : VSC_I8P_PF; };
+static_assert((VSC_I8P_PF == 2 || VSC_I8P_PF == 4) && (VSC_I8P_PF2 == 2 || VSC_I8P_PF2 == 4),
+              "the ring must divide the 4 steps of a 256-byte chunk");
 constexpr int HB = 8;           // 16-row blocks of a 128-row panel (= of a half of a paired wave tile)
 constexpr int AW = 4;           // A operands in registers: a rolling window of AW row blocks (the next AW blocks of the m-major order)
 
@@ -73,9 +79,15 @@ __device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rsrc, int voff, cha
 // which otherwise drains the whole stream with vmcnt(0) at the start of every tile -- it loses count of the
 // outstanding loads across the emission branches).  A load's destination must not be touched before ring_wait has
 // named it (the "+v" ties keep every use behind the wait).
+// s_nop 4: a VMEM instruction that reads an SGPR written by a VALU instruction (v_readlane / v_readfirstlane: the
+// compiler keeps spilled scalars in VGPR lanes and reloads `soff` with v_readlane right in front of the load) needs 5
+// wait states, and the compiler's hazard recognizer does not look inside inline assembly.  Found in round 4 with a ring
+// of 4 on the paired shape (three prologue loads, the 2nd and 3rd with a freshly reloaded soffset): 16 % of the runs of
+// one top-K case lost a hit in an item's first tile (scripts/experiments/dbg_pair_ring.py); 0 of 200 with the nops.
 template <int OFF>
 __device__ __forceinline__ void bload_asm(i32x4& dst, __amdgpu_buffer_rsrc_t rs, int voff, int soff) {
-    asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen offset:%4" : "=&v"(dst) : "v"(voff), "s"(rs), "s"(soff), "n"(OFF) : "memory");
+    asm volatile("s_nop 4\n\tbuffer_load_dwordx4 %0, %1, %2, %3 offen offset:%4"
+                 : "=&v"(dst) : "v"(voff), "s"(rs), "s"(soff), "n"(OFF) : "memory");
 }
 typedef float f32x4v __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void gload_asm(f32x4v& dst, const float4* p) {
@@ -112,7 +124,7 @@ __device__ __forceinline__ float lane_f(float x, int l) {
 // 4 KiB of consecutive image (column block n: 1 KiB at n * 1024), refilled PF - 1 steps ahead; the stream continues
 // into the wave's next tile at `so_next`.  Straight-line code, every LDS address = base register + immediate; issue
 // order pinned.
-template <int NKC, int MB, int CB>
+template <int NKC, int MB, int CB, int PF>
 __device__ __forceinline__ void tile_mma(const char* smem, const int (&abase)[4], i32x4 (&a)[AW], i32x4 (&ring)[PF][CB],
                                          __amdgpu_buffer_rsrc_t rs, int so_tile, int so_next, int lane16,
                                          i32x4 (&acc)[MB][CB]) {
@@ -302,6 +314,7 @@ __global__ __launch_bounds__(512) void sim_i8p_kernel(SimI8PArgs a) {
     constexpr int PRW = PR * HALVES;                  // rows of a work item's panel (HALVES consecutive 128-row panels)
     constexpr int WCOLS = 16 * CB;                    // columns of a wave tile; 8 waves side by side = one step
     constexpr int TPS = 8 / HALVES;                   // 64-column image tiles per step
+    constexpr int PF = RingDepth<HALVES, NKC>::v;
     extern __shared__ __attribute__((aligned(16))) char smem[];  // the panel: NKC x 32 KiB x HALVES
     __shared__ float rt_sh[ROWTHR ? PRW : 1];
     __shared__ int item_sh[2];
@@ -465,7 +478,7 @@ __global__ __launch_bounds__(512) void sim_i8p_kernel(SimI8PArgs a) {
             f32x4v mt;
             gload_asm(mt, a.rmeta + col0 + (lane & (WCOLS - 1)));
             i32x4 acc[MB][CB];
-            tile_mma<NKC, MB, CB>(smem, abase, afr, ring, rs, so_tile, so_tile + TPS * TILEB, lane16, acc);
+            tile_mma<NKC, MB, CB, PF>(smem, abase, afr, ring, rs, so_tile, so_tile + TPS * TILEB, lane16, acc);
             so_tile += TPS * TILEB;
             meta_wait<CB * (PF - 1)>(mt);
             // this lane's column: eps, 1 / (s_q s_r) per 128-row panel; +inf eps = "pass everything" (see column_threshold)
@@ -548,8 +561,12 @@ __global__ __launch_bounds__(512) void sim_i8p_kernel(SimI8PArgs a) {
                 }
             }
         }
+        // The stream ran PF - 1 steps past the item's end (out-of-range loads: zeros, no memory traffic) and those loads
+        // still target ring registers: they must have landed before the hand-over code reuses the registers.  (Found with
+        // the ring of 4 on the paired shape: the item index was computed in registers that late loads then overwrote;
+        // with a ring of 2 the barrier at the top of the loop happened to outlast the single step in flight.)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the stream ran a few steps past its end)
     tail_close(a.tail_base, a.tail_shift, a.tail_fill, lane, &tail_sh[wave]);
 #if VSC_I8P_ABLATE
     if (ablate_sink == 0x7fffffff) count = -1;
