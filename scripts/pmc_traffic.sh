@@ -8,7 +8,7 @@ out=$PWD/gpurun_out/$tag; mkdir -p $out
 export TMPDIR=/tmp
 cmd="python $PWD/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-extra $*"
 for grp in FETCH_SIZE WRITE_SIZE; do
-  for attempt in 1 2; do
+  for attempt in 1 2 3; do
     d=/tmp/pmc_${tag}_$grp; rm -rf $d
     (cd /tmp && timeout 900 rocprofv3 --pmc $grp --kernel-trace -d $d -o r -- $cmd > $out/pmc_run_$grp.log 2>&1)
     db=$(find $d -name "*.db" | head -1)
