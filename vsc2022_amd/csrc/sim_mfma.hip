@@ -412,6 +412,30 @@ __global__ __launch_bounds__(256, 1) void sim_knn_kernel(SimKnnArgs a) {
         // survivors of this tile against the thresholds as they stood before the tile
         const int rl_base = wr * 64 + 4 * (lane >> 5);
         const int col_base = r0 + wc * 64 + (lane & 31);
+        if (k == 1 && tri == t_begin) {
+            // k = 1, first tile of the run: every score beats the empty list and all 128 x 128 of them would go through
+            // the serial insertion (the "insertion storm").  The row maxima of the tile become the
+            // thresholds first -- a wave reduces each of its 32 row registers over the 32 lanes that share the row, the
+            // two waves of a row meet in LDS -- and only the maxima (and their exact ties) are inserted.
+            int* thr_bits = reinterpret_cast<int*>(thr);
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    float v = col_base < a.nr ? acc[m][0][r] : -INFINITY;   // (padded reference rows do not count)
+                    const float v1 = col_base + 32 < a.nr ? acc[m][1][r] : -INFINITY;
+                    v = fmaxf(v, v1);                                       // (fmaxf drops NaN scores: never inserted)
+#pragma unroll
+                    for (int off = 16; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off));
+                    if ((lane & 31) == 0 && v > -INFINITY) {
+                        const int rl = rl_base + m * 32 + (r & 3) + 8 * (r >> 2);
+                        // float maximum on the bits: non-negative floats order like ints, negative ones like reversed unsigneds
+                        if (v >= 0.0f) atomicMax(&thr_bits[rl], __float_as_int(v));
+                        else atomicMin(reinterpret_cast<unsigned int*>(&thr_bits[rl]), __float_as_uint(v));
+                    }
+                }
+            __syncthreads();
+        }
         unsigned long long mask = 0;
 #pragma unroll
         for (int m = 0; m < 2; ++m)
