@@ -366,3 +366,28 @@ def test_parity_suites_with_paired_int8_work_items():
                         "and not parity_suites and not paired_work_items and not ring_kernel"],
                        cwd=ROOT, env=e, capture_output=True, text=True, timeout=1800)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("k", [1, 5])
+def test_knn_rows_per_launch_do_not_change_results(gpu, k):
+    """api.hip knn_threshold_pass: over short reference ranges a k-NN threshold pass takes up to 262144 query rows per
+    launch instead of 32768 (VSC_KNN_STEP / VSC_KNN_STEP_MAX).  150 000 x 40 000 x 64: the default, the fixed 32768 and the
+    exact fp32 route give the same bits."""
+    from vsc2022_amd.vsc.index import FlatIndex
+
+    rng = np.random.default_rng(77 + k)
+    q, r = unit(rng, 150000, 64), unit(rng, 40000, 64)
+    outs = []
+    for kv in (dict(VSC_KNN_STEP=None, VSC_PREFILTER="2", VSC_I8="2"), dict(VSC_KNN_STEP="32768", VSC_PREFILTER="2", VSC_I8="2"),
+               dict(VSC_KNN_STEP=None, VSC_PREFILTER="0", VSC_I8=None)):
+        with env(**kv):
+            idx = FlatIndex(64)
+        idx.profile(True)
+        idx.add(r)
+        D, I = idx.search(q, k)
+        outs.append((D, I, idx.profile_read(reset=True)))
+    assert outs[0][2]["i8_launches"] > 0 and outs[2][2]["i8_launches"] == 0
+    assert outs[0][2]["i8_launches"] < outs[1][2]["i8_launches"]      # fewer, larger launches
+    for o in outs[1:]:
+        assert np.array_equal(outs[0][1], o[1]) and np.array_equal(bits(outs[0][0]), bits(o[0]))
