@@ -87,8 +87,8 @@ int vsc_device_count(void);
  *   VSC_I8P_PAIR=0 / 2        never / always (dims <= 512) use work items of two 128-row panels (256 x 32 wave tiles;
  *                             default 1: where a launch is large enough)
  *   VSC_I8_SCREEN=1           fp16 screen between the int8 pre-filter and the exact stage (measured neutral: off)
- *   VSC_KNN_STEP=n            query rows per launch of a k-NN threshold pass (default: 32768, doubled over short reference
- *                             ranges until rows x range reaches 32768 x 196608 or VSC_KNN_STEP_MAX = 262144 rows)
+ *   VSC_KNN_STEP=n            query rows per launch of a k-NN threshold pass (default: 32768, doubled until rows x range
+ *                             reaches VSC_KNN_STEP_WORK (64) x 32768 x 196608 or VSC_KNN_STEP_MAX (262144) rows)
  *   VSC_I8_KNN=0              k-NN threshold passes on the fp16 kernel
  *   VSC_RESCORE_SORT=0        exact stage over the waves' candidate segments as they are (default: compacted and
  *                             sorted by reference row)

@@ -167,6 +167,7 @@ struct vsc_index {
     int i8p_order = 1;           // VSC_I8P_ORDER: 1 slice-major work items (default), 0 panel-major with stealing
     int i8p_pair = 1;            // VSC_I8P_PAIR: 1 work items of two panels where the launch is large enough (default), 0 never, 2 wherever legal
     int64_t knn_step = 0;        // VSC_KNN_STEP: query rows per launch of a k-NN threshold pass (0: 32768, more over short ranges)
+    double knn_step_work = 64.0;  // VSC_KNN_STEP_WORK: x 32768 x 196608 = rows x range a launch should reach
     int64_t knn_step_max = 262144;  // VSC_KNN_STEP_MAX: ... at most this many (131072 / 262144 / 524288: 2125 / 2120 / 2121 ms per configs[3] step)
     int i8p_slice = 0;           // VSC_I8P_SLICE: col-steps per work item (0: 16 slice-major / the plan's panel-major)
     bool i8_sort_rows = true;    // VSC_I8_SORT=0: the rows of a launch keep their order
@@ -348,6 +349,7 @@ int vsc_index_create(int dim, int metric, int device, vsc_index_t** out) {
         idx->i8p_slice = (int)num("VSC_I8P_SLICE", 0.0);
         idx->knn_step = std::max<int64_t>(0, (int64_t)num("VSC_KNN_STEP", 0.0)) / 256 * 256;
         idx->knn_step_max = std::max<int64_t>(32768, (int64_t)num("VSC_KNN_STEP_MAX", 262144.0));
+        idx->knn_step_work = std::max(0.0, num("VSC_KNN_STEP_WORK", 64.0));
         idx->i8p_pair = std::max(0, std::min(2, (int)num("VSC_I8P_PAIR", 1.0)));
         idx->i8_sort_rows = !is("VSC_I8_SORT", '0');
         idx->i8_group_shift = getenv("VSC_I8_GROUP") ? std::max(0, std::min(16, (int)num("VSC_I8_GROUP", 9.0))) : 9;
@@ -358,7 +360,7 @@ int vsc_index_create(int dim, int metric, int device, vsc_index_t** out) {
         idx->knn_subset_factor = num("VSC_KNN_SUBSET", 300.0);
         idx->knn_s0_div = num("VSC_KNN_S0DIV", 0.0) > 0.0 ? (int)num("VSC_KNN_S0DIV", 0.0) : 7;
         idx->knn_ratio = num("VSC_KNN_RATIO", 0.0);
-        idx->knn_s0_min = num("VSC_KNN_S0MIN", 0.0) >= 64.0 ? (int)num("VSC_KNN_S0MIN", 0.0) : 4096;
+        idx->knn_s0_min = num("VSC_KNN_S0MIN", 0.0) >= 64.0 ? (int)num("VSC_KNN_S0MIN", 0.0) : 1024;
         idx->knn_nchunk = (int)num("VSC_KNN_NCHUNK", 0.0);
         idx->debug_i8 = getenv("VSC_DEBUG_I8") != nullptr;
         idx->debug_screen = getenv("VSC_DEBUG_SCREEN") != nullptr;
@@ -1282,13 +1284,16 @@ static int knn_exact_ip(vsc_index* idx, const float* qp, int64_t nq, int64_t nr,
 static int knn_threshold_pass(vsc_index* idx, const float* qp, int64_t nq, int64_t r_begin, int64_t r_end, int k,
                               double per_row, float* ds, int64_t* dj, bool use_i8 = false) {
     const int64_t nrange = r_end - r_begin;
-    // Rows per launch: 32768 -- except over a short reference range (the first ranges of a k-NN: 12 k / 48 k rows at
-    // k = 1), where such a launch is ~0.4 / 1.6 TOP: too little for 256 workgroups to reach the kernel's rate (measured
-    // 1100 / 2260 TOP/s against 2900) and as much preamble (row sort, quantisation, candidate count) as a big one.
-    // The rows double until rows x range reaches 32768 x 196608 (or VSC_KNN_STEP_MAX rows): configs[3] step 2163 ->
-    // 2120 ms, its score normalisation 826 -> 791 ms.  VSC_KNN_STEP=<rows>: fixed
+    // Rows per launch.  Round 4 started from 32768 everywhere; every launch carries ~0.3 ms of its own (row sort +
+    // quantisation of its panels, candidate count + compaction + sort, one sync, the exact stage's ramp), and over a
+    // short reference range (the first ranges of a k-NN: 12 k / 48 k rows at k = 1) a 32768-row launch is 0.4 / 1.6 TOP:
+    // too little for 256 workgroups to reach the kernel's rate (1100 / 2260 TOP/s against 2900).  The rows double until
+    // rows x range reaches VSC_KNN_STEP_WORK x 32768 x 196608 or VSC_KNN_STEP_MAX rows.  configs[3], score normalisation
+    // per step (one box): work 1 / 2 / 4 / 8+ with max 262144 ... 1 M: 791 / 782 / 773 / 746-748 ms (32768 rows
+    // everywhere: 826); max 65536 / 131072: 809 / 768.  Default: 64 and 262144 = 262144 rows over every range of a 2 M
+    // index.  VSC_KNN_STEP=<rows>: fixed
     int64_t step = 32768;
-    while (step < idx->knn_step_max && step * nrange < ((int64_t)32768 * 196608)) step *= 2;
+    while (step < idx->knn_step_max && step * nrange < (int64_t)(idx->knn_step_work * 32768.0 * 196608.0)) step *= 2;
     if (idx->knn_step > 0) step = idx->knn_step;
     int64_t cap = (int64_t)((double)nq * per_row) + (r_begin > 0 ? nq * k : 0) + (1 << 20);
     cap = std::min<int64_t>(cap, nq * (nrange + k) + 1024);
