@@ -75,7 +75,7 @@ int vsc_device_count(void);
  *   VSC_F16_KERNEL=ring       the 256x256 LDS-ring fp16 pre-filter instead of the panel-stationary one (A/B)
  *   VSC_I8=0                  no int8 image (fp16 pre-filter only); =2 forces the int8 kernel onto every
  *                             pre-filtered batch (tests)
- *   VSC_I8_DENSITY=f          expected hit density below which a pre-filtered batch runs on int8 (default 3e-4)
+ *   VSC_I8_DENSITY=f          expected hit density below which a pre-filtered batch runs on int8 (default 5e-4)
  *   VSC_I8_MAX_REL=f          sqrt(dim) x mean(E_r / N'_r) of the references above which the index never starts
  *                             on int8 (default 0.35: the 8-bit bound would pass too much of the matrix)
  *   VSC_I8_EXCLUDE=0          keep coordinates on which all references agree inside the int8 images

@@ -143,7 +143,7 @@ struct vsc_index {
     // pre-filtered batch (tests)
     DevBuf ref8, ref8m;
     int dpad8 = 0, i8_mode = 0;
-    double i8_density = 3e-4;
+    double i8_density = 5e-4;
     // sum / count of E_r / N_r over the reference rows: sqrt(dim) x their mean is the references' share of eps / sigma
     // (0.17 for unit-norm Gaussian-like rows); above i8_max_rel the 8-bit bound passes too much and the batches stay
     // on the fp16 kernel (e.g. score-normalised descriptors: one coordinate of every row is 1, the scale follows it)
@@ -332,7 +332,7 @@ int vsc_index_create(int dim, int metric, int device, vsc_index_t** out) {
         const char* d = getenv("VSC_PREFILTER_DENSITY");
         if (d && atof(d) > 0.0) idx->prefilter_density = atof(d);
         // VSC_I8=0: no int8 image; VSC_I8=2: every pre-filtered batch goes through the int8 kernel (tests);
-        // VSC_I8_DENSITY: expected hit density below which a batch does (default 3e-4: the looser int8 bound
+        // VSC_I8_DENSITY: expected hit density below which a batch does (default 5e-4: the looser int8 bound
         // brings ~4x the candidates, each ~0.3 ns of exact re-scoring, against 0.36 ps saved per pair)
         idx->dpad8 = round_up(dim, 256);
         const char* i8 = getenv("VSC_I8");
