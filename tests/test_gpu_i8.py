@@ -372,12 +372,12 @@ def test_parity_suites_with_paired_int8_work_items():
 @pytest.mark.parametrize("k", [1, 5])
 def test_knn_rows_per_launch_do_not_change_results(gpu, k):
     """api.hip knn_threshold_pass: over short reference ranges a k-NN threshold pass takes up to 262144 query rows per
-    launch instead of 32768 (VSC_KNN_STEP / VSC_KNN_STEP_MAX).  150 000 x 40 000 x 64: the default, the fixed 32768 and the
-    exact fp32 route give the same bits."""
+    launch instead of 32768 (VSC_KNN_STEP / VSC_KNN_STEP_MAX).  300 000 x 40 000 x 64: the default, the fixed 32768 and the
+    exact fp32 route give the same bits (300 000 query rows: more than one launch per range either way)."""
     from vsc2022_amd.vsc.index import FlatIndex
 
     rng = np.random.default_rng(77 + k)
-    q, r = unit(rng, 150000, 64), unit(rng, 40000, 64)
+    q, r = unit(rng, 300000, 64), unit(rng, 40000, 64)      # 262144 + 37856 rows: two launches per range
     outs = []
     for kv in (dict(VSC_KNN_STEP=None, VSC_PREFILTER="2", VSC_I8="2"), dict(VSC_KNN_STEP="32768", VSC_PREFILTER="2", VSC_I8="2"),
                dict(VSC_KNN_STEP=None, VSC_PREFILTER="0", VSC_I8=None)):
