@@ -93,7 +93,7 @@ int vsc_device_count(void);
  *   VSC_RESCORE_SORT=0        exact stage over the waves' candidate segments as they are (default: compacted and
  *                             sorted by reference row)
  *   VSC_KNN_LEVELS=1          pre-filtered k-NN with one refinement level; VSC_KNN_SUBSET=<factor> (default 300),
- *   VSC_KNN_S0DIV=<n> (7), VSC_KNN_RATIO=<r> (by k), VSC_KNN_NCHUNK=<n>: sizes of its exact subset pass / levels
+ *   VSC_KNN_S0DIV=<n> (28), VSC_KNN_S0MIN=<rows> (1024), VSC_KNN_RATIO=<r> (by k), VSC_KNN_NCHUNK=<n>: sizes of its exact subset pass / levels
  *   VSC_DEBUG_I8 / VSC_DEBUG_SCREEN: notes on stderr when a search falls back from int8 / per screen launch
  * Process-wide (first use): VSC_SIM_GRID (persistent grid of the exact similarity kernel), VSC_POISON_ALLOC=1
  * (fresh device buffers filled with 0xFF). */

@@ -177,8 +177,8 @@ struct vsc_index {
     bool knn_i8 = true;          // VSC_I8_KNN=0: k-NN passes on the fp16 kernel
     bool knn_two_level = true;   // VSC_KNN_LEVELS=1: one refinement level
     double knn_subset_factor = 300.0;  // VSC_KNN_SUBSET
-    int knn_s0_div = 7;          // VSC_KNN_S0DIV
-    int knn_s0_min = 4096;       // VSC_KNN_S0MIN: smallest exact subset
+    int knn_s0_div = 28;         // VSC_KNN_S0DIV
+    int knn_s0_min = 1024;       // VSC_KNN_S0MIN: smallest exact subset
     double knn_ratio = 0.0;      // VSC_KNN_RATIO (0: by k)
     int knn_nchunk = 0;          // VSC_KNN_NCHUNK: reference chunks of the exact k-NN kernel (0: by size)
     bool debug_i8 = false, debug_screen = false;  // VSC_DEBUG_I8 / VSC_DEBUG_SCREEN: stderr notes
@@ -358,7 +358,7 @@ int vsc_index_create(int dim, int metric, int device, vsc_index_t** out) {
         idx->knn_i8 = !is("VSC_I8_KNN", '0');
         idx->knn_two_level = !is("VSC_KNN_LEVELS", '1');
         idx->knn_subset_factor = num("VSC_KNN_SUBSET", 300.0);
-        idx->knn_s0_div = num("VSC_KNN_S0DIV", 0.0) > 0.0 ? (int)num("VSC_KNN_S0DIV", 0.0) : 7;
+        idx->knn_s0_div = num("VSC_KNN_S0DIV", 0.0) > 0.0 ? (int)num("VSC_KNN_S0DIV", 0.0) : 28;
         idx->knn_ratio = num("VSC_KNN_RATIO", 0.0);
         idx->knn_s0_min = num("VSC_KNN_S0MIN", 0.0) >= 64.0 ? (int)num("VSC_KNN_S0MIN", 0.0) : 1024;
         idx->knn_nchunk = (int)num("VSC_KNN_NCHUNK", 0.0);
@@ -1345,7 +1345,9 @@ static int knn_prefiltered(vsc_index* idx, const float* qp, int64_t nq, int k, f
     const int s0_div = idx->knn_s0_div;
     // without levels: S0 = sqrt(300 k nr) balances the exact pass (~2 dim S0 / 1e14 s per row) against the per-hit cost of
     // the one pass over the rest (k nr / S0 hits per row, ~1 ns each).  With levels the exact kernel -- a tenth of the
-    // pre-filter's rate -- only has to get the thresholds started: S0 = that / 7 (at least 4096 rows).
+    // pre-filter's rate -- only has to get the thresholds started: S0 = that / 28, at least 1024 rows (/ 7 and 4096 until
+    // the threshold passes over the short first ranges became cheap -- 262144 query rows per launch: configs[3] step
+    // 2053 -> 2027 ms, 200 k x 2 M k-NN 169 -> 160 ms at k = 1 and 281 -> 273 ms at k = 20, profiles/r04_knn_launch_rows.md).
     // (range boundaries sit on col-steps; on whole 64-row wave tiles when VSC_PREFILTER=2, the tests' switch, forces the
     // levels on small problems)
     const int64_t unit = idx->prefilter_force ? 64 : F16P_COL_STEP;
