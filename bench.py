@@ -295,6 +295,15 @@ def extra_legs(args, torch, dev, matcher, queries, n_qv, qf, n_rv, rf, dim):
     dt = _t.perf_counter() - t0
     p = exact.profile_read(reset=True)
     ach = _rate(p["sim_flops"], p["sim_ms"], 1e12)
+    # ... and an exhaustive parity check while both results are in HBM: the default route (fp16 / int8 pre-filters +
+    # exact stage) must return the same (row, ref, score bits) list, all K entries of it, and the same radius
+    di, dj, ds, drad = matcher.search(1200 * n_qv)
+    out["fullsize_routes_identical"] = bool(
+        drad == hits[3] and ds.numel() == hits[2].numel() and torch.equal(di, hits[0]) and torch.equal(dj, hits[1])
+        and torch.equal(ds.view(torch.int32), hits[2].view(torch.int32)))
+    out["fullsize_routes_note"] = (f"default route vs VSC_PREFILTER=0 on the whole {nq} x {nr} score matrix, K = {1200 * n_qv}: "
+                                   "every hit's row, reference and fp32 score bits + the final radius compared")
+    del di, dj, ds
     out["roofline_fp32_route"] = {
         "kernel": "sim_thresh_kernel (fp32 MFMA 32x32x2 similarity + fused threshold compaction), VSC_PREFILTER=0",
         "bound": "mfma", "achieved": ach, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",

@@ -236,7 +236,7 @@ def test_sharded_hits_terminates_when_one_shard_holds_the_whole_topk(tmp_path):
     r0 = torch.load(f"{out}.0", weights_only=False)
     r1 = torch.load(f"{out}.1", weights_only=False)
     assert len(r0[0]) == 100 and len(r1[0]) == 0
-    assert r0[2][-1] == 100, r0[2]       # rank 0 doubled its budget up to K
+    assert r0[2][-1] == 101, r0[2]       # rank 0 doubled its budget up to K + 1 (the selection looks one past the cut)
     assert r1[2] == [63], r1[2]          # the exact rank kept its first result (no repeated search)
     assert np.float32(r0[1]) == np.float32(r1[1]) == r0[0][-1]
 
@@ -399,3 +399,192 @@ def test_bench_self_launches_n_ranks():
     assert rep["n_gpus"] == 3 and rep["process_group"]["ranks_answered"] == 3
     assert rep["process_group"]["backend"] == "gloo" and rep["process_group"]["launcher"] == "bench.py self-launch"
     assert sorted(rep["process_group"]["devices"]) == [0, 1, 2]
+
+
+# ---------------------------------------------------------------- round 5: the sharded result is provably the reference's
+def _tie_data(seed=0, nq=300, nr=400, dim=8):
+    """Rows on a coarse grid (massive exact score ties), static "videos" (duplicate rows) and continuous rows."""
+    rng = np.random.default_rng(seed)
+    q = rng.standard_normal((nq, dim))
+    r = rng.standard_normal((nr, dim))
+    q[: nq // 2] = np.round(q[: nq // 2] * 2) / 2
+    r[: nr // 2] = np.round(r[: nr // 2] * 2) / 2
+    q[40:52] = q[40]
+    q[nq - 100: nq - 70] = q[nq - 100]
+    r[100:120] = r[100]
+    return q.astype(np.float32), r.astype(np.float32)
+
+
+def _tie_classes(q, r, want=3):
+    """K values by what happens on the cut: no tie / tie kept by the reference / tie dropped by the reference."""
+    import oracle as orc
+
+    S = np.sort(orc.scores(q, r).ravel())[::-1]
+    cls = {"notie": [], "kept": [], "dropped": []}
+    for K in list(range(40, 4000, 31)) + list(range(4000, 70000, 797)):
+        tie = S[K - 1] == S[K]
+        if all(len(v) >= want for v in cls.values()):
+            break
+        name = "notie"
+        if tie:
+            _, _, s, info = orc.global_threshold_search(q, r, K, return_info=True)
+            name = "dropped" if np.float32(info["radius"]) == S[K - 1] else "kept"
+        if len(cls[name]) < want:
+            cls[name].append(K)
+    assert all(len(v) >= 1 for v in cls.values()), {k: len(v) for k, v in cls.items()}
+    return cls
+
+
+def test_prefix_select_reports_tie_on_cut():
+    sys.path[:0] = [ROOT]
+    from vsc2022_amd.dist import distributed_prefix_select
+
+    rng = np.random.default_rng(5)
+    seen = set()
+    for trial in range(300):
+        n = int(rng.integers(1, 300))
+        x = rng.normal(size=n).astype(np.float32)
+        if trial % 2 == 0:
+            x = np.round(x * 2) / 2
+        x = np.sort(x)[::-1].copy()
+        k = int(rng.integers(1, 320))
+        n_take, tau, info = distributed_prefix_select(torch.from_numpy(x), k, return_info=True)
+        want = k < n and x[k - 1] == x[k]
+        assert info.tie_on_cut == want, (trial, n, k)
+        assert info.total == n
+        if k < n:
+            assert info.n_above == int((x > x[k - 1]).sum())
+        seen.add(want)
+    assert seen == {True, False}
+
+
+def _qshard_tie_worker(rank, world, port, Ks, out_path):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        sys.path[:0] = [ROOT, os.path.join(ROOT, "oracle")]
+        import oracle as orc
+        from vsc2022_amd import dist as vdist
+
+        q, r = _tie_data()
+        lo, hi = vdist.shard_ranges(len(q), world)[rank]
+        Q = q[lo:hi]
+        res = {}
+        for K in Ks:
+            def local_search(k_local):
+                i, j, s, info = orc.global_threshold_search(Q, r, k_local, return_info=True)
+                return torch.from_numpy(i), torch.from_numpy(j), torch.from_numpy(s), info["radius"]
+
+            def range_scores(r0, r1, radius):  # this rank's rows of the batch [r0, r1) of the GLOBAL row order
+                a, b = max(r0, lo) - lo, min(r1, hi) - lo
+                if b <= a:
+                    return torch.zeros(0, dtype=torch.float32)
+                return torch.from_numpy(orc.range_search(Q[a:b], r, radius)[1])
+
+            hi_, hj_, hs_, tau, info = vdist.sharded_hits(local_search, Q.shape[0] * r.shape[0], K,
+                                                          k_local_start=max(1, K // 5), return_info=True)
+            keep, proven, dropped = vdist.resolve_tie_on_cut(
+                hs_, tau, info, lambda: vdist.emulate_schedule_radius(range_scores, len(q), K))
+            res[f"i{K}"], res[f"j{K}"], res[f"s{K}"] = (hi_[keep].numpy() + lo, hj_[keep].numpy(), hs_[keep].numpy())
+            res[f"f{K}"] = np.array([info.tie_on_cut, proven, dropped])
+        np.savez(f"{out_path}.{rank}.npz", **res)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_query_sharded_hits_are_the_references_with_ties_on_the_cut(tmp_path, world):
+    """A tie sits exactly on the K cut (s_K == s_(K+1)): the sharded search must return what vsc/index.py:142-165
+    returns -- all of the top K when the reference's final radius lies below the tie, NONE of the tied hits when the
+    reference's schedule ends on that score -- and must say which case it proved."""
+    sys.path[:0] = [ROOT, os.path.join(ROOT, "oracle")]
+    import oracle as orc
+
+    q, r = _tie_data()
+    cls = _tie_classes(q, r)
+    Ks = sorted(set(sum(cls.values(), [])))
+    out = str(tmp_path / "qs")
+    mp.spawn(_qshard_tie_worker, args=(world, 29100 + os.getpid() % 800, Ks, out), nprocs=world, join=True)
+    parts = [np.load(f"{out}.{k}.npz") for k in range(world)]
+    for K in Ks:
+        i, j, s = orc.global_threshold_search(q, r, K)
+        gi = np.concatenate([p[f"i{K}"] for p in parts])
+        gj = np.concatenate([p[f"j{K}"] for p in parts])
+        gs = np.concatenate([p[f"s{K}"] for p in parts])
+        order = np.lexsort((gj, gi, -gs.astype(np.float64)))
+        assert np.array_equal(gi[order], i) and np.array_equal(gj[order], j), K
+        assert np.array_equal(gs[order].view(np.uint32), s.view(np.uint32)), K
+        flags = parts[0][f"f{K}"]
+        assert all(np.array_equal(p[f"f{K}"], flags) for p in parts)
+        assert bool(flags[1]), K  # proven
+        assert bool(flags[0]) == (K not in cls["notie"]) and bool(flags[2]) == (K in cls["dropped"]), (K, flags)
+        if K in cls["dropped"]:
+            assert len(s) < K
+
+
+class _OracleIndexRS(_OracleIndex):
+    def range_scores(self, x, radius, k_hint, device_out=False):
+        import oracle as orc
+
+        return orc.range_search(np.ascontiguousarray(x, dtype=np.float32), self.rows, radius)[1]
+
+
+def _refshard_tie_worker(rank, world, port, Ks, out_path):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        sys.path[:0] = [ROOT, os.path.join(ROOT, "oracle")]
+        from vsc2022_amd import dist as vdist
+        from vsc2022_amd.refshard import RefShardedIndex
+
+        q, r = _tie_data(seed=3, nq=150, nr=500)
+        lo, hi = vdist.shard_ranges(len(r), world)[rank]
+        idx = RefShardedIndex(_OracleIndexRS(r[lo:hi]), lo, len(r))
+        res = {}
+        for K in Ks:
+            i, j, s, tau = idx.global_topk(q, K, k_local_start=K // 4 + 1)
+            res[f"i{K}"], res[f"j{K}"], res[f"s{K}"] = i.numpy(), j.numpy(), s.numpy()
+            res[f"f{K}"] = np.array([idx.last_select.tie_on_cut, idx.last_matches_reference, idx.last_ties_dropped])
+        np.savez(f"{out_path}.{rank}.npz", **res)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_ref_sharded_topk_is_the_references_with_ties_on_the_cut(tmp_path):
+    """Column shards, world 3: same statement as the query-sharded test; the reference's final radius comes from the
+    schedule's batches run on all shards at once (dist.emulate_schedule_radius)."""
+    sys.path[:0] = [ROOT, os.path.join(ROOT, "oracle")]
+    import oracle as orc
+
+    q, r = _tie_data(seed=3, nq=150, nr=500)
+    cls = _tie_classes(q, r)
+    Ks = sorted(set(sum(cls.values(), [])))
+    out = str(tmp_path / "rs")
+    world = 3
+    mp.spawn(_refshard_tie_worker, args=(world, 28100 + os.getpid() % 800, Ks, out), nprocs=world, join=True)
+    for K in Ks:
+        i, j, s = orc.global_threshold_search(q, r, K)
+        for rank in range(world):
+            got = np.load(f"{out}.{rank}.npz")
+            assert np.array_equal(got[f"i{K}"], i) and np.array_equal(got[f"j{K}"], j), (rank, K)
+            assert np.array_equal(got[f"s{K}"].view(np.uint32), s.view(np.uint32))
+            flags = got[f"f{K}"]
+            assert bool(flags[1])
+            assert bool(flags[0]) == (K not in cls["notie"]) and bool(flags[2]) == (K in cls["dropped"]), (K, flags)
+
+
+def test_emulated_schedule_radius_equals_the_oracles_single_process():
+    """dist.emulate_schedule_radius in one process (no shards) against the final radius of the C oracle's schedule."""
+    sys.path[:0] = [ROOT, os.path.join(ROOT, "oracle")]
+    import oracle as orc
+    from vsc2022_amd import dist as vdist
+
+    for seed in range(4):
+        q, r = _tie_data(seed=seed, nq=220 + 40 * seed, nr=300)
+        for K in (1, 7, 100, 1500, 9000, 40000, q.shape[0] * r.shape[0]):
+            info = orc.global_threshold_search(q, r, K, return_info=True)[3]
+            t = vdist.emulate_schedule_radius(
+                lambda r0, r1, rad: torch.from_numpy(orc.range_search(q[r0:r1], r, rad)[1]), len(q), K)
+            assert np.float32(t) == np.float32(info["radius"]), (seed, K, t, info)

@@ -24,6 +24,25 @@ def pair_scores(orc, a, b):
     return np.array([orc.scores(a[k : k + 1], b[k : k + 1])[0, 0] for k in range(len(a))], dtype=np.float32)
 
 
+def _exact_index(rows, dim):
+    """An index over `rows` whose searches run on the exact fp32 MFMA kernels alone (VSC_PREFILTER=0 is read when a
+    handle is created, include/vscmi.h): the route without bounds, candidate lists or thresholds to get wrong."""
+    from vsc2022_amd import _lib
+    from vsc2022_amd.vsc.index import FlatIndex
+
+    old = os.environ.get("VSC_PREFILTER")
+    os.environ["VSC_PREFILTER"] = "0"
+    try:
+        exact = FlatIndex(dim, _lib.METRIC_INNER_PRODUCT, 0)
+    finally:
+        if old is None:
+            os.environ.pop("VSC_PREFILTER", None)
+        else:
+            os.environ["VSC_PREFILTER"] = old
+    exact.add(rows)
+    return exact
+
+
 def test_config4_full_pipeline_40k_query_videos(gpu, orc):
     """vsc/baseline/sscd_baseline.py:185-231 at BASELINE configs[3]'s size on one GPU: score normalisation of 1 M query
     rows against 2 M noise rows, search K = 48 M over 2 M references, 1 M candidates, 200 k pairs localised with bias
@@ -47,8 +66,17 @@ def test_config4_full_pipeline_40k_query_videos(gpu, orc):
     rng = np.random.default_rng(9)
     rows = np.sort(rng.choice(nq, 8, replace=False))
     keep = norm.sel.cpu().numpy()
-    noise_prep = norm._prepare(noise).cpu().numpy()
+    noise_dev = norm._prepare(noise)
+    noise_prep = noise_dev.cpu().numpy()
     del noise
+    # ---- exhaustive: the WHOLE 1-NN column (1 M rows x 2 M noise rows through the int8 pre-filter's
+    # reference ranges) against the exact fp32 kernel over all noise rows -- every bit of every row
+    exact_noise = _exact_index(noise_dev, dim - 1)
+    del noise_dev
+    De, _ = exact_noise.search(qn[:, : dim - 1].contiguous(), 1, device_out=True)
+    assert torch.equal((De * (-beta)).view(torch.int32)[:, 0], qn[:, dim - 1].contiguous().view(torch.int32))
+    del exact_noise, De
+    torch.cuda.empty_cache()
     q_prep = orc.row_normalize(queries[torch.from_numpy(rows).to(dev)].cpu().numpy()[:, keep])
     got = qn[torch.from_numpy(rows).to(dev)].cpu().numpy()
     assert np.array_equal(got[:, : dim - 1].view(np.uint32), q_prep.view(np.uint32))
@@ -82,7 +110,14 @@ def test_config4_full_pipeline_40k_query_videos(gpu, orc):
     rr, cc = np.nonzero(sub > np.float32(last))
     for x, y in zip(rr, cc):
         assert int(y) in row_hits[int(x)], (int(rows[x]), int(y))
-    del hi, hj, hs, key, same
+    del key, same
+    # ---- exhaustive: all 48 M hits (row, ref, score bits) and the radius against the all-fp32 route (15 s of fp32 MFMA)
+    exact = _exact_index(rn, dim)
+    ei, ej, es, erad = exact.global_topk(qn, K, device_out=True)
+    assert erad == radius and torch.equal(ei, hi) and torch.equal(ej, hj)
+    assert torch.equal(es.view(torch.int32), hs.view(torch.int32))
+    del exact, ei, ej, es, hi, hj, hs
+    torch.cuda.empty_cache()
     # ---- candidates + localisation (bias 0.5, MaxSim), and the same result on a second run
     res = m.match(bias=0.5)
     assert res.n_hits == K and res.n_candidates == 25 * n_qv and res.n_localized == 5 * n_qv

@@ -74,6 +74,70 @@ def test_ref_sharded_index_equals_the_oracle(gpu, orc, tmp_path, seed, world, k,
     assert rows == len(r)
 
 
+# ---------------------------------------------------------------- round 5: a tie ON the K cut
+def _tie_data(seed):
+    """Rows on a coarse grid (massive exact ties) + duplicate rows: for most K the (K+1)-th best score equals the K-th."""
+    rng = np.random.default_rng(seed)
+    nq, nr, d = {11: (200, 3000, 16), 12: (120, 900, 8), 13: (260, 1200, 6)}[seed]
+    q = np.round(rng.standard_normal((nq, d)) * 2) / 2
+    r = np.round(rng.standard_normal((nr, d)) * 2) / 2
+    q[nq // 2:] = rng.standard_normal((nq - nq // 2, d))       # ... next to continuous rows
+    q[20:32] = q[20]
+    r[100:130] = r[100]
+    return q.astype(np.float32), r.astype(np.float32)
+
+
+def _tie_worker(rank, world, port, out_dir, seed, Ks):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), LOCAL_RANK="0")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        sys.path.insert(0, ROOT)
+        from vsc2022_amd import _lib
+        from vsc2022_amd.refshard import RefShardedIndex
+
+        q, r = _tie_data(seed)
+        idx = RefShardedIndex.build(r, r.shape[1], _lib.METRIC_INNER_PRODUCT, 0)
+        res = {}
+        for K in Ks:
+            i, j, s, tau = idx.global_topk(q, K)
+            res[f"i{K}"], res[f"j{K}"], res[f"s{K}"] = i.cpu().numpy(), j.cpu().numpy(), s.cpu().numpy()
+            res[f"f{K}"] = np.array([idx.last_select.tie_on_cut, idx.last_matches_reference, idx.last_ties_dropped])
+        np.savez(os.path.join(out_dir, f"tie{rank}.npz"), **res)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("seed,world", [(11, 2), (12, 3), (13, 4)])
+def test_ref_sharded_topk_with_ties_on_the_cut_equals_the_oracle(gpu, orc, tmp_path, seed, world):
+    """s_K == s_(K+1): the sharded search must return exactly what the reference's schedule returns -- the top K when
+    its final radius lies below the tie, none of the tied hits when it ends on that score (vsc/index.py:142-165;
+    vsc2022_amd/dist.py module docstring) -- with the final radius computed by the schedule's batches run on all shards
+    (`dist.emulate_schedule_radius` over `FlatIndex.range_scores`, HIP kernels)."""
+    q, r = _tie_data(seed)
+    S = np.sort(orc.scores(q, r).ravel())[::-1]
+    want = {"notie": [], "kept": [], "dropped": []}
+    for K in list(range(60, 6000, 53)) + list(range(6000, 120000, 1499)):
+        if all(len(v) >= 2 for v in want.values()):
+            break
+        cls = "notie"
+        if S[K - 1] == S[K]:
+            info = orc.global_threshold_search(q, r, K, return_info=True)[3]
+            cls = "dropped" if np.float32(info["radius"]) == S[K - 1] else "kept"
+        if len(want[cls]) < 2:
+            want[cls].append(K)
+    assert want["kept"] and want["dropped"], {k: len(v) for k, v in want.items()}
+    Ks = sorted(sum(want.values(), []))
+    mp.spawn(_tie_worker, args=(world, 29850 + os.getpid() % 100, str(tmp_path), seed, Ks), nprocs=world, join=True)
+    for K in Ks:
+        i, j, s = orc.global_threshold_search(q, r, K)
+        for rank in range(world):
+            got = np.load(tmp_path / f"tie{rank}.npz")
+            assert np.array_equal(got[f"i{K}"], i) and np.array_equal(got[f"j{K}"], j.astype(np.int64)), (rank, K)
+            assert np.array_equal(got[f"s{K}"].view(np.uint32), s.view(np.uint32)), (rank, K)
+            f = got[f"f{K}"]
+            assert bool(f[1]) and bool(f[0]) == (K not in want["notie"]) and bool(f[2]) == (K in want["dropped"]), (K, f)
+
+
 # ---------------------------------------------------------------- BASELINE configs[4] at full size
 FULL = dict(world=4, refs_per_rank=4_000_000, dim=512, nq=4096, k=20, K=200_000)
 

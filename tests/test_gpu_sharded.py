@@ -14,13 +14,18 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _data(seed=5):
+def _data(seed=5, static=0.0, grid=0):
+    """static: fraction of static videos (all frames identical: exact score ties); grid > 0: every coordinate rounded
+    to multiples of 1 / grid (massive ties: nearly every K then cuts through a group of equal scores)."""
     sys.path.insert(0, ROOT)
     from vsc2022_amd import synth
 
-    shape = {5: (64, 120, 128), 6: (37, 80, 64), 7: (90, 60, 256)}[seed]
+    shape = {5: (64, 120, 128), 6: (37, 80, 64), 7: (90, 60, 256), 8: (48, 70, 32)}[seed]
     q, r, gts = synth.make_dataset(seed=seed, n_query=shape[0], n_ref=shape[1], dim=shape[2], q_frames=(8, 30),
-                                   r_frames=(8, 40), planted_frac=0.3, static_frac=0.0)
+                                   r_frames=(8, 40), planted_frac=0.3, static_frac=static)
+    if grid:
+        for v in q + r:
+            v.feature[:] = np.round(v.feature * grid) / grid
     return q, r
 
 
@@ -34,10 +39,11 @@ def _result_arrays(res):
     nbox = res.nbox.cpu().numpy()
     return dict(cq=res.cand_q.cpu().numpy(), cr=res.cand_r.cpu().numpy(), cs=res.cand_score.cpu().numpy(),
                 loc=res.loc_index.cpu().numpy(), nbox=nbox, boxes=res.boxes.cpu().numpy(),
-                bscore=res.box_score.cpu().numpy(), n=np.array([res.n_hits, res.n_candidates, res.n_localized, res.n_matches]))
+                bscore=res.box_score.cpu().numpy(), n=np.array([res.n_hits, res.n_candidates, res.n_localized, res.n_matches]),
+                flags=np.array([res.matches_reference, res.tie_on_cut, res.ties_dropped]))
 
 
-def _worker(rank, world, port, out_dir, seed, seed_rows):
+def _worker(rank, world, port, out_dir, seed, seed_rows, static=0.0, grid=0):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), LOCAL_RANK="0")
     if seed_rows:
         # a sample of `seed_rows` rows over all ranks seeds every rank's local search (engine.DeviceMatcher.seed_radius);
@@ -49,7 +55,7 @@ def _worker(rank, world, port, out_dir, seed, seed_rows):
         from vsc2022_amd import dist as vdist
         from vsc2022_amd.engine import DeviceMatcher
 
-        q, r = _data(seed)
+        q, r = _data(seed, static, grid)
         rf, roff = _pack(r)
         lo, hi = vdist.shard_ranges(len(q), world)[rank]
         qf, qoff = _pack(q[lo:hi])
@@ -57,16 +63,24 @@ def _worker(rank, world, port, out_dir, seed, seed_rows):
         m.set_queries(qf, qoff)
         row_base = sum(len(v.feature) for v in q[:lo])
         res = m.match(n_qvid_global=len(q), qvid_base=lo, row_base=row_base)
-        np.savez(os.path.join(out_dir, f"rank{rank}.npz"), **_result_arrays(res))
+        allbox = m.gather_boxes(res).cpu().numpy()
+        np.savez(os.path.join(out_dir, f"rank{rank}.npz"), allbox=allbox, **_result_arrays(res))
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("seed,world,seed_rows", [(5, 2, 0), (6, 3, 0), (7, 2, 0), (5, 2, 120), (6, 3, 40), (7, 2, 300), (7, 3, 12)])
-def test_sharded_engine_equals_single_process(gpu, tmp_path, seed, world, seed_rows):
+# static / grid > 0 (round 5): exact score ties -- static videos as in the bench's data, and descriptors on a
+# coarse grid, where nearly every query set has a tie ON the K cut: the sharded pipeline then has to find out what the
+# reference's schedule does with the tied hits (dist.py module docstring) -- and must equal the single-process engine,
+# which replays that schedule, in every case
+@pytest.mark.parametrize("seed,world,seed_rows,static,grid", [
+    (5, 2, 0, 0.0, 0), (6, 3, 0, 0.0, 0), (7, 2, 0, 0.0, 0), (5, 2, 120, 0.0, 0), (6, 3, 40, 0.0, 0), (7, 2, 300, 0.0, 0),
+    (7, 3, 12, 0.0, 0), (5, 2, 0, 0.2, 0), (6, 3, 40, 0.3, 0), (7, 2, 300, 0.1, 0), (8, 2, 0, 0.1, 4), (8, 3, 60, 0.0, 4),
+    (6, 2, 0, 0.2, 8), (5, 3, 120, 0.2, 6), (8, 4, 0, 0.3, 3)])
+def test_sharded_engine_equals_single_process(gpu, tmp_path, seed, world, seed_rows, static, grid):
     from vsc2022_amd.engine import DeviceMatcher
 
-    q, r = _data(seed)
+    q, r = _data(seed, static, grid)
     rf, roff = _pack(r)
     qf, qoff = _pack(q)
     m = DeviceMatcher(rf, roff, 0)
@@ -75,12 +89,16 @@ def test_sharded_engine_equals_single_process(gpu, tmp_path, seed, world, seed_r
     del m
     torch.cuda.empty_cache()
     port = 29650 + os.getpid() % 500
-    mp.spawn(_worker, args=(world, port, str(tmp_path), seed, seed_rows), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, port, str(tmp_path), seed, seed_rows, static, grid), nprocs=world, join=True)
     parts = [np.load(tmp_path / f"rank{k}.npz") for k in range(world)]
     for p in parts:  # every rank holds the same global candidate table = the single-process one
         assert np.array_equal(p["cq"], single["cq"]) and np.array_equal(p["cr"], single["cr"])
         assert np.array_equal(p["cs"].view(np.uint32), single["cs"].view(np.uint32))
         assert np.array_equal(p["n"], single["n"])
+        assert bool(p["flags"][0]), "the sharded run must have proven its result to be the reference's"
+        assert np.array_equal(p["flags"], parts[0]["flags"]) and np.array_equal(p["allbox"], parts[0]["allbox"])
+    if grid == 0 and static == 0.0:
+        assert not parts[0]["flags"][1]  # continuous descriptors: no tie on the cut
     # localisation results, reassembled by candidate index
     n_loc = int(single["n"][2])
     nbox = np.full(n_loc, -1, dtype=np.int64)
@@ -94,4 +112,24 @@ def test_sharded_engine_equals_single_process(gpu, tmp_path, seed, world, seed_r
     for k in range(n_loc):
         assert np.array_equal(boxes[k, : nbox[k]], single["boxes"][k, : nbox[k]])
         assert np.array_equal(bscore[k, : nbox[k]].view(np.uint32), single["bscore"][k, : nbox[k]].view(np.uint32))
-    assert single["n"][3] > 0
+    assert single["n"][3] > 0 or grid
+    # the gathered box table (what rank 0 writes matches.csv from) = the single-process localisation, in its order
+    exp = [(k, *single["boxes"][k, b], int(single["bscore"][k, b : b + 1].view(np.int32)[0]))
+           for k in range(n_loc) for b in range(single["nbox"][k])]
+    assert np.array_equal(parts[0]["allbox"], np.array(exp, dtype=np.int64).reshape(-1, 6))
+
+
+def test_tie_on_the_cut_happens_and_is_resolved_both_ways(gpu, tmp_path):
+    """Over a handful of grid datasets both outcomes must occur: ties kept (the reference's final radius lies below the
+    tie) and ties dropped (its schedule ends on the tied score) -- otherwise the parametrised test above proves less
+    than it claims."""
+    seen = set()
+    for k, (seed, world, static, grid) in enumerate([(8, 2, 0.1, 4), (8, 3, 0.0, 4), (6, 2, 0.2, 8), (5, 3, 0.2, 6),
+                                                      (8, 4, 0.3, 3), (6, 2, 0.0, 3), (7, 2, 0.0, 2), (5, 2, 0.0, 2)]):
+        d = tmp_path / f"c{k}"
+        d.mkdir()
+        mp.spawn(_worker, args=(world, 29250 + os.getpid() % 300 + k, str(d), seed, 0, static, grid), nprocs=world, join=True)
+        f = np.load(d / "rank0.npz")["flags"]
+        assert f[0]
+        seen.add((bool(f[1]), bool(f[2])))
+    assert (True, True) in seen and (True, False) in seen, seen

@@ -1125,7 +1125,7 @@ int vsc_index_global_topk(vsc_index_t* idx, const float* q, int64_t nq, int q_me
 int vsc_index_global_topk_seeded(vsc_index_t* idx, const float* q, int64_t nq, int q_mem, int64_t K, float radius0,
                                  int32_t* out_i, int32_t* out_j, float* out_s, int64_t cap_out, int out_mem,
                                  int64_t* n_out, float* final_radius) {
-    if (!(radius0 == radius0) || std::fabs(radius0) > 1e9f) {
+    if (!(radius0 == radius0) || std::fabs(radius0) > 1e10f) {
         set_error("vsc_index_global_topk_seeded: the seed radius must be a finite score (got %g)", (double)radius0);
         return VSC_ERR_INVALID;
     }

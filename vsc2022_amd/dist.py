@@ -18,20 +18,33 @@ buckets are needed.  Everything here works on torch tensors of any device, so th
 under gloo on CPU tensors in the tests (with the per-rank search results supplied by the oracle)
 and under RCCL on HBM tensors in production.
 
-Result contract: identical to the single-GPU result whenever the reference's own batch schedule
-does not drop hits tied with a re-threshold radius (vsc/index.py semantics are schedule-dependent
-only in that case); i.e. the sharded search returns the exact global top-K under the
-total order (score desc, query row asc, ref row asc).
+Result contract: the reference's own result (vsc/index.py:142-165), proven per query set.  The
+reference returns the top K of {s > t} under (score desc, query row asc, ref row asc), t = the final
+radius of range_search_max_results = the (K+1)-th best score of the row PREFIX that ended at the last
+re-threshold event, hence t <= s_(K+1) <= s_K.  The sharded search computes the exact global top-K
+under the same total order; the two differ only if {s > t} holds fewer than K hits, i.e. only if
+t == s_K == s_(K+1):
+
+  * s_K > s_(K+1) (or the whole matrix holds <= K scores): identical, no further work -- the
+    selection below reports this from the tie counts it gathers anyway (`SelectInfo.tie_on_cut`);
+  * s_K == s_(K+1) (a tie sits on the cut; duplicate frames of static videos make this a few percent
+    of the query sets): the final radius of the reference's schedule is computed -- query shards:
+    rank 0 replays the schedule on the gathered query rows (engine.DeviceMatcher); reference shards:
+    `emulate_schedule_radius` runs the schedule's batches on all shards at once -- and the hits tied
+    with the cut are dropped iff t == s_K, exactly as the reference drops them.
 """
-from typing import List, Optional, Tuple
+from dataclasses import dataclass
+from typing import Callable, List, Optional, Tuple
 
 import torch
 import torch.distributed as dist
 
 
 def score_keys(scores: torch.Tensor) -> torch.Tensor:
-    """Order-preserving fp32 -> integer key (int64 holding a uint32): larger score, larger key."""
+    """Order-preserving fp32 -> integer key (int64 holding a uint32): larger score, larger key; -0.0 and +0.0 share
+    a key, as they compare equal in the reference's float comparisons."""
     bits = scores.contiguous().view(torch.int32).to(torch.int64) & 0xFFFFFFFF
+    bits = torch.where(bits == 0x80000000, torch.zeros_like(bits), bits)
     neg = (bits & 0x80000000) != 0
     return torch.where(neg, (~bits) & 0xFFFFFFFF, bits | 0x80000000)
 
@@ -113,8 +126,17 @@ def _all_gather_vec(v: torch.Tensor, group) -> torch.Tensor:
     return torch.stack(out).to(v.device)
 
 
-def distributed_prefix_select(sorted_scores: torch.Tensor, k_total: int, group=None, ties: str = "rank"
-                              ) -> Tuple[int, float]:
+@dataclass
+class SelectInfo:
+    """What the selection saw at the cut (identical on every rank)."""
+    total: int = 0          # elements over all ranks' lists
+    n_above: int = 0        # ... strictly beyond tau
+    n_ties: int = 0         # ... equal to tau (each rank's list counted up to its first k_total + 1 elements)
+    tie_on_cut: bool = False  # the (k_total+1)-th best equals the k_total-th best: s_K == s_(K+1)
+
+
+def distributed_prefix_select(sorted_scores: torch.Tensor, k_total: int, group=None, ties: str = "rank",
+                              return_info: bool = False):
     """How many leading elements of this rank's score-DESCENDING list belong to the global top
     `k_total` of the union of all ranks' lists.  Returns (n_take, tau) with tau the k_total-th best
     score (-inf when the union is shorter than k_total).
@@ -127,16 +149,20 @@ def distributed_prefix_select(sorted_scores: torch.Tensor, k_total: int, group=N
     Three collectives (all-reduce of a 65537-entry histogram that also carries the list lengths,
     all-reduce of the second-level histogram, all-gather of the tie counts) and ONE host sync at the end:
     everything in between stays on the device.
+
+    return_info: a third result, `SelectInfo` -- whether the (k_total+1)-th best equals tau (the lists are looked
+    at one element past k_total for this: the tie counts are exact as long as every list is complete down to tau,
+    which is what the callers' exactness tests establish).
     """
     rank, world = _world(group)
     device = sorted_scores.device
     n_local = int(sorted_scores.numel())
     if k_total <= 0:
-        return 0, float("inf")
+        return (0, float("inf"), SelectInfo()) if return_info else (0, float("inf"))
     # The list is sorted, and a rank can contribute at most k_total elements: everything below is
     # O(65536 log n) searchsorted calls on the (ascending copy of the) leading k_total keys -- no pass
     # over the list besides the key conversion (a full histogram of 10 M scores cost 70 ms per call).
-    lead = sorted_scores[: min(n_local, k_total)]
+    lead = sorted_scores[: min(n_local, k_total + 1)]
     n_lead = int(lead.numel())
     asc = score_keys(lead).flip(0).contiguous() if n_lead else torch.zeros(0, dtype=torch.int64, device=device)
     steps = torch.arange(65537, dtype=torch.int64, device=device)
@@ -167,11 +193,14 @@ def distributed_prefix_select(sorted_scores: torch.Tensor, k_total: int, group=N
     before = eq_all[:rank].sum()
     m = k_t - (above1 + above2)  # elements tied with tau that still fit
     take_ties = n_eq if ties == "all" else torch.minimum(n_eq, (m - before).clamp(min=0))
-    res = torch.stack([n_gt + take_ties, tau_key, total]).cpu()  # the one host sync
-    n_take, tau_key_h, total_h = (int(x) for x in res)
+    res = torch.stack([n_gt + take_ties, tau_key, total, above1 + above2, eq_all.sum()]).cpu()  # the one host sync
+    n_take, tau_key_h, total_h, above_h, ties_h = (int(x) for x in res)
     if total_h <= k_total:
-        return n_local, float("-inf")
-    return n_take, float(key_to_score(tau_key_h))
+        info = SelectInfo(total_h, total_h, 0, False)
+        return (n_local, float("-inf"), info) if return_info else (n_local, float("-inf"))
+    info = SelectInfo(total_h, above_h, ties_h, above_h + ties_h > k_total)
+    tau = float(key_to_score(tau_key_h))
+    return (n_take, tau, info) if return_info else (n_take, tau)
 
 
 def all_gather_varlen(t: torch.Tensor, group=None) -> torch.Tensor:
@@ -202,21 +231,21 @@ class ShardedCandidates:
 
 
 def merge_hits(local_scores_sorted: torch.Tensor, k_global: int, complete_above: float, group=None,
-               ties: str = "rank") -> Tuple[int, float, bool]:
+               ties: str = "rank", return_info: bool = False):
     """Step 1: prefix of the local hit list that survives the global K cut.
 
     `complete_above`: every local hit with score > complete_above is present in the local list
-    (the local search's own cut).  Returns (n_take, tau, exact): exact is False on ranks whose
+    (the local search's own cut).  Returns (n_take, tau, exact[, SelectInfo]): exact is False on ranks whose
     local cut is not strictly below the global one -- the caller must then rerun that rank's
     local search with a larger local K (all ranks call merge_hits again).
     """
-    n_take, tau = distributed_prefix_select(local_scores_sorted, k_global, group, ties)
+    n_take, tau, info = distributed_prefix_select(local_scores_sorted, k_global, group, ties, return_info=True)
     exact = (complete_above == float("-inf")) or (tau > complete_above)
-    return n_take, tau, exact
+    return (n_take, tau, exact, info) if return_info else (n_take, tau, exact)
 
 
 def sharded_hits(local_search, local_matrix_size: int, k_global: int, group=None, device=None,
-                 k_local_start: Optional[int] = None, ties: str = "rank"):
+                 k_local_start: Optional[int] = None, ties: str = "rank", return_info: bool = False):
     """Exact global top-`k_global` hits from per-rank searches.
 
     local_search(k_local) -> (i, j, s, radius): this rank's global-threshold search with budget
@@ -225,25 +254,28 @@ def sharded_hits(local_search, local_matrix_size: int, k_global: int, group=None
     1.25*K/world and doubles the budget of any rank whose own cut is not strictly below the global cut
     (skewed shards), until the result is exact everywhere.  A rank that already is exact keeps its
     result across the retries (its list stays complete above a cut that can only rise) and only takes
-    part in the collectives; a rank whose budget has reached K is exact by construction (nothing beyond
-    its K best can be among the global K best).  Every rank leaves the loop on the same, all-reduced
-    flag.  Returns (i, j, s, tau) = this rank's share of the global top-K (ties="all": including every
-    hit tied with tau, see distributed_prefix_select).
+    part in the collectives; a rank whose budget has reached K + 1 is exact by construction (nothing beyond
+    its K + 1 best can be among the global K + 1 best -- one more than K, so that the selection also sees whether
+    the (K+1)-th best ties with the K-th: `SelectInfo.tie_on_cut`, the one case in which the reference's schedule
+    can return something else than the exact top-K, see the module docstring).  Every rank leaves the loop on the
+    same, all-reduced flag.  Returns (i, j, s, tau[, SelectInfo]) = this rank's share of the global top-K
+    (ties="all": including every hit tied with tau, see distributed_prefix_select).
 
     local_search may return a fifth element, True for a SEEDED search (engine.DeviceMatcher.seed_radius: the rank
-    searched with the full budget k_global from a radius agreed over a row sample instead of replaying the
+    searched with the full budget k_global + 1 from a radius agreed over a row sample instead of replaying the
     reference's doubling schedule; k_local is ignored).  Its list holds every local hit beyond the returned radius,
-    cut at k_global: exact when it is full (k_global hits: nothing beyond a rank's K best can be among the global K
-    best) or when the global cut lies strictly beyond that radius; otherwise -- the seed was too high -- the rank
-    retries, and local_search is expected to answer the retry with the unseeded search.
+    cut at k_global + 1: exact when it is full or when the global cut lies strictly beyond that radius; otherwise
+    -- the seed was too high -- the rank retries, and local_search is expected to answer the retry with the
+    unseeded search.
     """
     rank, world = _world(group)
+    k_cap = k_global + 1
     # A rank's share of the global top-K is K/world up to sampling noise when the shards are alike; the
     # local search costs more the larger its budget (re-scoring, selection and sorting scale with it), so
     # start 25 % above the even share and let the doubling below handle skewed shards.
-    k_local = max(1, min(k_global, (5 * k_global) // (4 * max(world, 1)) + 1))
+    k_local = max(1, min(k_cap, (5 * k_global) // (4 * max(world, 1)) + 1))
     if k_local_start is not None:
-        k_local = max(1, min(k_global, int(k_local_start)))
+        k_local = max(1, min(k_cap, int(k_local_start)))
     cached = None
     while True:
         if cached is None:
@@ -255,22 +287,94 @@ def sharded_hits(local_search, local_matrix_size: int, k_global: int, group=None
             if n >= local_matrix_size:
                 complete_above = float("-inf")      # the whole local matrix was kept
             elif seeded:
-                complete_above = float(radius)      # every local hit beyond the radius is listed (cut at k_global)
-                full = n >= k_global
+                complete_above = float(radius)      # every local hit beyond the radius is listed (cut at k_cap)
+                full = n >= k_cap
             elif n >= k_local:
                 complete_above = float(hs[-1].item())  # truncated at k_local: ties with the last may be missing
             else:
                 complete_above = float(radius)      # hits <= radius were dropped by the schedule
             cached = (hi, hj, hs, complete_above, seeded, full)
         hi, hj, hs, complete_above, seeded, full = cached
-        n_take, tau, exact = merge_hits(hs, k_global, complete_above, group, ties)
-        exact = exact or full or (k_local >= k_global and not seeded)
+        n_take, tau, exact, info = merge_hits(hs, k_global, complete_above, group, ties, return_info=True)
+        exact = exact or full or (k_local >= k_cap and not seeded)
         all_exact = all_reduce_max_int(0 if exact else 1, hs.device if device is None else device, group) == 0
         if all_exact:
-            return hi[:n_take], hj[:n_take], hs[:n_take], tau
+            out = (hi[:n_take], hj[:n_take], hs[:n_take], tau)
+            return out + (info,) if return_info else out
         if not exact:
-            k_local = min(k_global, k_local * 2)
+            k_local = min(k_cap, k_local * 2)
             cached = None
+
+
+def resolve_tie_on_cut(hs: torch.Tensor, tau: float, info: SelectInfo, final_radius: Callable[[], float],
+                       enabled: bool = True) -> Tuple[torch.Tensor, bool, bool]:
+    """What the reference does with the hits tied with the K-th best score (module docstring).
+
+    hs: this rank's share of the exact global top-K (any order); tau: the K-th best score; info: the selection's
+    report; final_radius(): the final radius t of the reference's schedule over the WHOLE score matrix -- called (by
+    every rank: it may run collectives) only when a tie sits on the cut.  Returns (keep mask over hs, proven, dropped):
+    proven = the result is the reference's (False only when `enabled` is off and the case could not be excluded),
+    dropped = the reference's schedule ends on tau, the tied hits go."""
+    keep = torch.ones(hs.shape, dtype=torch.bool, device=hs.device)
+    if not info.tie_on_cut:
+        return keep, True, False
+    if not enabled:
+        return keep, False, False
+    import numpy as np
+
+    t = final_radius()
+    if np.float32(t) == np.float32(tau):
+        return hs > tau, True, True
+    assert np.float32(t) < np.float32(tau), (t, tau)  # t <= s_(K+1) == s_K by construction
+    return keep, True, False
+
+
+def exponential_batches(n_rows: int, start: int = 32, max_bs: int = 20000) -> List[Tuple[int, int]]:
+    """[begin, end) query-row ranges of faiss.contrib.exhaustive_search.exponential_query_iterator: 32, 64, ...
+    rows, doubling while the batch size is below 20000 (the call of vsc/index.py:149)."""
+    out, i, bs = [], 0, start
+    while i < n_rows:
+        out.append((i, min(n_rows, i + bs)))
+        i += bs
+        if bs < max_bs:
+            bs *= 2
+    return out
+
+
+def emulate_schedule_radius(range_scores: Callable[[int, int, float], torch.Tensor], n_rows: int, k_global: int,
+                            group=None, device=None) -> float:
+    """The final radius t of range_search_max_results(max_results=2K, min_results=K) over the reference's batch
+    schedule (vsc/index.py:147-154, inner product), computed over SHARDS of the score matrix: the value that decides
+    whether hits tied with the K-th best score are dropped (module docstring).
+
+    range_scores(r0, r1, radius) -> 1-D fp32 tensor: the scores > radius (STRICT) of this rank's part of the query
+    rows [r0, r1) -- reference shards: rows [r0, r1) against the rank's columns; query shards: the rank's own rows of
+    that range against all columns (an empty tensor for a batch the rank owns no row of).  Every rank walks the same
+    batches: one all-reduce of the kept count per batch, and at every event (more than 2K kept) the exact distributed
+    selection of the (K+1)-th best kept score, which becomes the radius; everything at or below it is dropped.
+    Only scores are kept (4 B per hit, <= 2K + one batch of them over all ranks).
+    """
+    rank, world = _world(group)
+    radius = -1e10
+    kept: List[torch.Tensor] = []
+    n_kept = 0
+    dev = device
+    for r0, r1 in exponential_batches(n_rows):
+        s = range_scores(r0, r1, radius)
+        if dev is None:
+            dev = s.device
+        if s.numel():
+            kept.append(s)
+            n_kept += int(s.numel())
+        total = all_reduce_sum_int(n_kept, dev, group)
+        if total > 2 * k_global:
+            allk = torch.cat(kept) if kept else torch.zeros(0, dtype=torch.float32, device=dev)
+            allk = torch.sort(allk, descending=True).values
+            _, tau = distributed_prefix_select(allk, k_global + 1, group)
+            radius = float(tau)
+            allk = allk[allk > radius]
+            kept, n_kept = ([allk] if allk.numel() else []), int(allk.numel())
+    return float(radius)
 
 
 def merge_candidates(q_vid: torch.Tensor, r_vid: torch.Tensor, score: torch.Tensor, first_i: torch.Tensor,

@@ -41,6 +41,12 @@ class MatchResult:
     boxes: torch.Tensor       # [n_localized_here, 16, 4] int32
     box_score: torch.Tensor   # [n_localized_here, 16] fp32 (MaxSim - bias)
     radius: float
+    # Sharded runs (vsc2022_amd/dist.py, module docstring): the exact global top-K IS the reference's result unless a tie
+    # sits on the K cut; then the reference's final radius decides whether the tied hits are dropped.
+    matches_reference: bool = True   # proven identical to vsc/index.py:142-165 on this query set (False only when a tie
+    #                                  sits on the cut and VSC_SHARD_TIE_RESOLVE=0 switched the resolution off)
+    tie_on_cut: bool = False         # s_K == s_(K+1) over the whole score matrix
+    ties_dropped: bool = False       # ... and the reference's schedule ends on that very score: hits tied with it dropped
 
 
 def _dev_ptr(t: torch.Tensor) -> int:
@@ -285,14 +291,26 @@ class DeviceMatcher:
                                pq[:n_cand], pr[:n_cand], ps[:n_cand],
                                torch.arange(n_loc, device=self.tdev), nbox, boxes, bmax, radius)
         radius_box = [float("nan")]
-        # The sharded result is the exact global top-K (vsc2022_amd/dist.py), not the reference's tie-dropping schedule,
-        # so a rank need not replay the 32, 64, ... doubling batches on its own rows: a radius agreed over a row sample
-        # seeds every rank's FIRST local search; a retry (seed too high, skewed shard) takes the unseeded search.
+        # The sharded search computes the exact global top-K (vsc2022_amd/dist.py) -- which is the reference's result
+        # unless a tie sits on the K cut (resolved below) --, so a rank need not replay the 32, 64, ... doubling batches on
+        # its own rows: a radius agreed over a row sample seeds every rank's FIRST local search; a retry (seed too high,
+        # skewed shard) takes the unseeded search.  Budgets go up to K + 1: the selection must see whether the (K+1)-th
+        # best ties with the K-th.
         seed = [self.seed_radius(K, group) if os.environ.get("VSC_SHARD_SEED", "1") != "0" else None]
 
         def local_search(k_local):
             if seed[0] is not None:
-                i, j, sc, rad = self.search(K, seed_radius=seed[0])  # (full budget: see dist.sharded_hits)
+                try:
+                    i, j, sc, rad = self.search(K + 1, seed_radius=seed[0])  # (full budget: see dist.sharded_hits)
+                except _lib.VscError as e:
+                    # a seed far too low (unrepresentative sample) can overflow the kept-hit buffer: the unseeded
+                    # schedule bounds its own buffers
+                    if e.code not in (_lib.VSC_ERR_OVERFLOW, _lib.VSC_ERR_CAPACITY, _lib.VSC_ERR_NOMEM):
+                        raise
+                    seed[0] = None
+                    i, j, sc, rad = self.search(k_local)
+                    radius_box[0] = rad
+                    return i, j, sc, rad
                 seed[0] = None
                 radius_box[0] = rad
                 return i, j, sc, rad, True
@@ -300,8 +318,15 @@ class DeviceMatcher:
             radius_box[0] = rad
             return i, j, sc, rad
 
-        hi, hj, hs, _tau = vdist.sharded_hits(local_search, int(self.q_feats.shape[0]) * self.index.ntotal, K,
-                                              group, self.tdev)
+        hi, hj, hs, tau, info = vdist.sharded_hits(local_search, int(self.q_feats.shape[0]) * self.index.ntotal, K,
+                                                   group, self.tdev, return_info=True)
+        # s_K == s_(K+1): the reference drops every hit tied with the cut iff its schedule's final radius is that score
+        # (dist.py module docstring).  Rare (duplicate frames of static videos put a few percent of the query sets here)
+        # and decided exactly: rank 0 replays the reference's schedule on the gathered query rows.
+        keep, proven, dropped = vdist.resolve_tie_on_cut(hs, tau, info, lambda: self.reference_radius(K, group),
+                                                         os.environ.get("VSC_SHARD_TIE_RESOLVE", "1") != "0")
+        if dropped:
+            hi, hj, hs = hi[keep], hj[keep], hs[keep]
         radius = radius_box[0]
         n_take = int(hs.numel())
         pq, pr, ps, pf = self.pair_max(hi, hj, hs)
@@ -316,4 +341,40 @@ class DeviceMatcher:
         n_matches = vdist.all_reduce_sum_int(int(nbox.sum().item()), self.tdev, group)
         n_hits = vdist.all_reduce_sum_int(n_take, self.tdev, group)
         return MatchResult(n_hits, int(ps.numel()), n_cand, n_loc, n_matches,
-                           cands.q_vid, cands.r_vid, cands.score, loc_index, nbox, boxes, bmax, radius)
+                           cands.q_vid, cands.r_vid, cands.score, loc_index, nbox, boxes, bmax, radius,
+                           matches_reference=proven, tie_on_cut=info.tie_on_cut, ties_dropped=dropped)
+
+    def reference_radius(self, K: int, group=None) -> float:
+        """The final radius of the reference's schedule (vsc/index.py:147-154) over ALL ranks' query rows: the query
+        rows are gathered (rank order = query order) and rank 0 runs the single-GPU search on them -- the code whose
+        parity with the oracle the single-process suites pin --, then tells everybody.  Only the sharded pipeline's
+        tie-on-the-cut case calls this."""
+        allq = vdist.all_gather_varlen(self.q_feats, group)
+        rank, world = vdist._world(group)
+        rad = 0.0
+        if rank == 0:
+            _, _, _, rad = self.search(K, rows=allq)
+        t = torch.tensor([float(rad) if rank == 0 else 0.0], dtype=torch.float64, device=self.tdev)
+        vdist._all_reduce_sum(t, group)
+        return float(t.item())
+
+    def gather_boxes(self, res: MatchResult, group=None) -> torch.Tensor:
+        """Every rank's localisation results in one table (the hand-over of vsc/baseline/sscd_baseline.py:139-152 when
+        the pairs were localised by the ranks that own their query videos): int64 [n_boxes, 6] = (index into the
+        candidate table, q_lo, r_lo, q_hi, r_hi, bits of the fp32 box score), ordered by (candidate, box) -- the
+        order in which the single-process pipeline emits its Match rows.  Identical on every rank."""
+        n_here = int(res.loc_index.numel())
+        if n_here:
+            slot = torch.arange(_lib.TN_MAX_BOXES, device=self.tdev).unsqueeze(0).expand(n_here, -1)
+            valid = slot < res.nbox.to(torch.int64).unsqueeze(1)
+            cand = res.loc_index.to(torch.int64).unsqueeze(1).expand(-1, _lib.TN_MAX_BOXES)
+            rows = torch.cat([cand[valid].unsqueeze(1), slot[valid].unsqueeze(1).to(torch.int64),
+                              res.boxes.to(torch.int64)[valid],
+                              res.box_score.contiguous().view(torch.int32).to(torch.int64)[valid].unsqueeze(1)], dim=1)
+        else:
+            rows = torch.zeros((0, 7), dtype=torch.int64, device=self.tdev)
+        allr = vdist.all_gather_varlen(rows, group)
+        if allr.shape[0]:
+            order = torch.sort(allr[:, 0] * _lib.TN_MAX_BOXES + allr[:, 1]).indices
+            allr = allr[order]
+        return torch.cat([allr[:, :1], allr[:, 2:]], dim=1)

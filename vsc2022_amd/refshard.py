@@ -16,9 +16,12 @@ This is what the reference gets from FAISS when the index does not fit one devic
                            survivors, final order (score desc, query row asc, ref row asc).
 
 Result contract: identical to a single index over all rows (bit for bit: scores are the same fp32 fma
-chains) whenever the reference's own batch schedule does not drop hits tied with a re-threshold radius
-(the same caveat as the query-sharded path).
+chains), the reference's tie-dropping included: when the (K+1)-th best score equals the K-th the final radius
+of the reference's schedule is computed over the shards (`dist.emulate_schedule_radius`: every batch of the
+schedule on all shards at once) and the hits tied with the cut are dropped iff the reference drops them
+(`vsc2022_amd/dist.py`, module docstring).
 """
+import os
 from typing import Optional, Tuple
 
 import numpy as np
@@ -82,6 +85,16 @@ class RefShardedIndex:
             gD = -gD
         return gD.cpu().numpy(), gI.cpu().numpy()
 
+    def _range_scores(self, rows, radius: float, k_hint: int) -> torch.Tensor:
+        """fp32 scores > radius (strict) of `rows` against this shard, on `self.device`."""
+        n_loc = int(self.local.ntotal)
+        if int(rows.shape[0]) == 0 or n_loc == 0:
+            return torch.zeros(0, dtype=torch.float32, device=self.device)
+        s = self.local.range_scores(rows, radius, k_hint, device_out=self.device.type == "cuda")
+        if not isinstance(s, torch.Tensor):
+            s = torch.from_numpy(np.ascontiguousarray(s))
+        return s.to(self.device)
+
     # ---- global top-K of the whole score matrix
     def global_topk(self, x, K: int, k_local_start: Optional[int] = None):
         """(i int32, j int64 GLOBAL ref row, s float32, tau): the K best (query row, ref row) pairs over all
@@ -98,8 +111,19 @@ class RefShardedIndex:
                 i, j, s = (torch.from_numpy(np.ascontiguousarray(a)).to(self.device) for a in (i, j, s))
             return i, j, s, rad
 
-        hi, hj, hs, tau = vdist.sharded_hits(local_search, n * n_loc, int(K), self.group, self.device,
-                                             k_local_start=k_local_start, ties="all")
+        if getattr(self.local, "metric_type", 0) != 0:
+            raise NotImplementedError("RefShardedIndex.global_topk: inner-product indexes only (the matching pipeline's metric)")
+        hi, hj, hs, tau, info = vdist.sharded_hits(local_search, n * n_loc, int(K), self.group, self.device,
+                                                   k_local_start=k_local_start, ties="all", return_info=True)
+        self.last_select = info
+        # s_K == s_(K+1): the reference keeps the tied hits unless its schedule's final radius is that very score
+        keep, self.last_matches_reference, self.last_ties_dropped = vdist.resolve_tie_on_cut(
+            hs, tau, info,
+            lambda: vdist.emulate_schedule_radius(lambda r0, r1, rad: self._range_scores(x[r0:r1], rad, 2 * int(K)),
+                                                  n, int(K), self.group, self.device),
+            os.environ.get("VSC_SHARD_TIE_RESOLVE", "1") != "0")
+        if self.last_ties_dropped:
+            hi, hj, hs = hi[keep], hj[keep], hs[keep]
         packed = torch.stack([hi.to(torch.int64), hj.to(torch.int64) + self.row0,
                               hs.contiguous().view(torch.int32).to(torch.int64)], dim=1)
         allp = vdist.all_gather_varlen(packed, self.group)

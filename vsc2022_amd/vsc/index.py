@@ -248,6 +248,21 @@ class FlatIndex:
         m = n_out.value
         return oi[:m], oj[:m], os_[:m], radius.value
 
+    def range_scores(self, x, radius: float, k_hint: int, device_out: bool = False):
+        """The scores STRICTLY beyond `radius` of x against the index (inner product), no ids: what one batch of
+        range_search_max_results keeps (vsc/index.py:147-154) when the caller drives the schedule itself
+        (dist.emulate_schedule_radius over shards).  Runs `vsc_index_global_topk_seeded` with a budget that is raised
+        until the list is provably complete: its radius never moved and it is shorter than the budget."""
+        n = int(x.shape[0])
+        total = n * max(self.ntotal, 1)
+        kk = max(int(k_hint), 1024)
+        while True:
+            k_try = min(kk, total)
+            _, _, s, rad = self.global_topk(x, k_try, device_out=device_out, seed_radius=float(radius))
+            if k_try >= total or (np.float32(rad) == np.float32(radius) and len(s) < k_try):
+                return s
+            kk *= 4
+
     def set_hit_capacity(self, cap: int):
         _lib.check(_lib.lib().vsc_index_set_hit_capacity(self._h, int(cap)))
 
