@@ -67,7 +67,10 @@ int vsc_device_count(void);
  * hand to that exact stage every pair whose low-precision score plus a rigorous error bound reaches the threshold;
  * the outputs are bit-identical to the all-fp32 route.
  *
- * Environment.  Every switch below is read ONCE, when a handle is created, and stays with that handle:
+ * Options.  Every switch below is an option of the handle: `vsc_index_set_option(idx, "<name>", value)` with the name in
+ * lower case and without the VSC_ prefix ("i8_density", "prefilter", "knn_step", ...; "f16_kernel": 1 = ring), and the
+ * environment variable of the same name supplies its initial value when a handle is created (read once, then it stays
+ * with that handle):
  *   VSC_PREFILTER=0           no pre-filter (every search on the exact fp32 MFMA kernel); =2 forces it onto every
  *                             batch / every k-NN regardless of size (tests)
  *   VSC_PREFILTER_DENSITY=f   expected hit density below which a batch of the thresholded search is pre-filtered
@@ -99,6 +102,19 @@ int vsc_device_count(void);
  * (fresh device buffers filled with 0xFF). */
 int vsc_index_create(int dim, int metric, int device, vsc_index_t** out);
 int vsc_index_destroy(vsc_index_t* idx);
+/* Programmatic form of the switches above (the reference's analogue: faiss.ParameterSpace().set_index_parameter(index,
+ * name, value) on the object vsc/index.py:82 creates).  Options that decide which images of the reference rows are kept
+ * ("prefilter" 0 <-> non-0, "i8" 0 <-> non-0, "f16_kernel", "i8_exclude") can only change while the index is empty:
+ * VSC_ERR_INVALID otherwise, as for an unknown name or an out-of-range value.  "cand_budget": entries of the candidate
+ * list a k-NN threshold pass may ask for (default 2^28; the rows per launch are halved until it fits). */
+int vsc_index_set_option(vsc_index_t* idx, const char* name, double value);
+int vsc_index_get_option(const vsc_index_t* idx, const char* name, double* value);
+/* Run every launch and copy of this handle on the caller's HIP stream (a hipStream_t, e.g. torch's current stream) instead
+ * of the handle's own non-blocking stream: work the caller queued on that stream before a call -- the kernel that
+ * produced the query rows -- is then ordered before the library's reads without a device-wide synchronisation.
+ * hip_stream = NULL is HIP's default stream (torch's default); own != 0 goes back to the handle's own stream (hip_stream
+ * is ignored then).  Calls still return only when their results are complete. */
+int vsc_index_set_stream(vsc_index_t* idx, void* hip_stream, int own);
 int vsc_index_add(vsc_index_t* idx, const float* x, int64_t n, int x_mem);
 int64_t vsc_index_ntotal(const vsc_index_t* idx);
 int vsc_index_dim(const vsc_index_t* idx);
@@ -169,6 +185,10 @@ int vsc_pair_max(const int32_t* hit_i, const int32_t* hit_j, const float* hit_s,
                  int64_t nr_rows, int maps_mem, int32_t* out_q, int32_t* out_r, float* out_s,
                  int64_t* out_first, int64_t cap, int out_mem, int64_t* n_pairs, int device);
 
+/* The stream of the entry points that own no handle on `device` (vsc_pair_max, vsc_row_normalize, vsc_tn_forward_sim):
+ * as vsc_index_set_stream. */
+int vsc_set_aux_stream(int device, void* hip_stream, int own);
+
 /* Replaces sklearn.preprocessing.normalize(x) (row L2; vsc/baseline/score_normalization.py:84,
  * vsc/baseline/sscd_baseline.py:129-130): out = x / max(||x||, 0 -> 1). */
 int vsc_row_normalize(const float* x, int64_t n, int dim, int x_mem, float* out, int out_mem,
@@ -199,6 +219,8 @@ int vsc_tn_create(const float* qfeat, const int64_t* q_off, int64_t n_qvid, cons
                   const int64_t* r_off, int64_t n_rvid, int dim, int feat_mem, int device,
                   vsc_tn_ctx_t** out);
 int vsc_tn_destroy(vsc_tn_ctx_t* ctx);
+/* As vsc_index_set_stream, for a localisation context. */
+int vsc_tn_set_stream(vsc_tn_ctx_t* ctx, void* hip_stream, int own);
 /* Replace the QUERY side of a context (a new query batch against the same, resident references: the per-query-set
  * step of vsc/baseline/sscd_baseline.py:90-176 when many query sets meet one reference set).  The reference rows
  * stay packed in HBM; only the nq query rows are uploaded and packed.  Same argument meaning as vsc_tn_create. */

@@ -35,7 +35,7 @@ from collections import deque
 
 LLVM = os.environ.get("VSC_LLVM_BIN", "/opt/rocm/lib/llvm/bin")
 
-_REG = re.compile(r"\b([vsa])(?:\[(\d+):(\d+)\]|(\d+))\b")
+_REG = re.compile(r"\b([vsa])(?:\[(\d+):(\d+)\]|(\d+)\b)")
 _SPECIAL = re.compile(r"\b(vcc_lo|vcc_hi|vcc|exec_lo|exec_hi|exec|m0)\b")
 _ADDR = re.compile(r"//\s*([0-9A-Fa-f]+):")
 _TARGET = re.compile(r"<([^>+]+)\+0x([0-9a-fA-F]+)>\s*$")
@@ -60,10 +60,11 @@ def regs_of(text):
 
 
 class Inst:
-    __slots__ = ("addr", "mnem", "ops", "text", "target", "line")
+    __slots__ = ("addr", "mnem", "ops", "text", "target", "line", "facts")
 
     def __init__(self, addr, mnem, ops, text, target, line):
         self.addr, self.mnem, self.ops, self.text, self.target, self.line = addr, mnem, ops, text, target, line
+        self.facts = None
 
 
 def parse_disassembly(path):
@@ -172,7 +173,36 @@ def vmcnt_of(i):
     return None
 
 
-def lint_function(name, insts, base_addr, verbose=False, max_visits=24):
+class Facts:
+    """everything the walk needs about one instruction, parsed once"""
+    __slots__ = ("vregs", "sregs", "vmem", "lds_dma", "dest", "ws", "vmcnt", "valu_w", "m0_w", "lane_sel", "sendmsg")
+
+    def __init__(self, ins):
+        mentioned = regs_of(ins.ops)
+        self.vmem = is_vmem(ins)
+        self.dest = vmem_dest(ins)
+        if self.vmem and self.dest:
+            # a load may overwrite the destination of an older outstanding load (they retire in order): only its
+            # address / data operands count as "touched"
+            mentioned = regs_of(",".join(split_operands(ins.ops)[1:]))
+        self.vregs = frozenset(r for r in mentioned if r[0] in "va")
+        self.sregs = frozenset(r for r in mentioned if r[0] == "s" or r == "vcc")
+        self.lds_dma = self.vmem and (ins.text.rstrip().endswith(" lds") or " lds " in ins.text + " ")
+        self.ws = wait_states(ins)
+        self.vmcnt = vmcnt_of(ins)
+        self.valu_w = frozenset(valu_scalar_writes(ins)) if is_valu(ins) else frozenset()
+        self.m0_w = False
+        if ins.mnem.startswith("s_") and not ins.mnem.startswith(("s_waitcnt", "s_nop", "s_cbranch", "s_branch")):
+            ops = split_operands(ins.ops)
+            self.m0_w = bool(ops) and "m0" in regs_of(ops[0])
+        self.lane_sel = frozenset()
+        if ins.mnem.startswith(("v_readlane", "v_writelane")):
+            ops = split_operands(ins.ops)
+            self.lane_sel = frozenset(regs_of(ops[2])) if len(ops) > 2 else frozenset()
+        self.sendmsg = ins.mnem.startswith("s_sendmsg")
+
+
+def lint_function(name, insts, base_addr, verbose=False, max_visits=12):
     """-> list of violation strings"""
     if not insts:
         return []
@@ -220,55 +250,48 @@ def lint_function(name, insts, base_addr, verbose=False, max_visits=24):
         fall = True
         while k < end:
             ins = insts[k]
-            mentioned = regs_of(ins.ops)
+            f = ins.facts
+            if f is None:
+                f = ins.facts = Facts(ins)
             # ---- D: touching a register an outstanding load will still write
-            if pending:
-                vregs = {r for r in mentioned if r[0] in "va"}
-                if vregs:
-                    for p in pending:
-                        hit = vregs & p
-                        if hit:
-                            report(ins, "D", f"{sorted(hit)} is the destination of a VMEM load that no s_waitcnt has retired yet")
-                            break
+            if pending and f.vregs:
+                for p in pending:
+                    if p and (f.vregs & p):
+                        report(ins, "D", f"{sorted(f.vregs & p)} is the destination of a VMEM load that no s_waitcnt has retired yet")
+                        break
             # ---- A / B / C
             if recent:
-                if is_vmem(ins):
-                    sregs = {r for r in mentioned if r[0] == "s" or r == "vcc"}
+                if f.vmem:
                     for reg, kind, age in recent:
-                        if kind == "valu" and reg in sregs and age < 5:
+                        if kind == "valu" and reg in f.sregs and age < 5:
                             report(ins, "A", f"{reg} was written by a VALU instruction {age} wait state(s) earlier (needs 5)")
-                    if ins.text.rstrip().endswith(" lds") or " lds " in ins.text + " ":
-                        for reg, kind, age in recent:
-                            if kind == "m0" and age < 1:
-                                report(ins, "C", "m0 was written by the previous SALU instruction (needs 1 wait state)")
-                elif ins.mnem.startswith(("v_readlane", "v_writelane")):
-                    ops = split_operands(ins.ops)
-                    sel = regs_of(ops[2]) if len(ops) > 2 else set()
+                        if kind == "m0" and f.lds_dma and age < 1:
+                            report(ins, "C", "m0 was written by the previous SALU instruction (needs 1 wait state)")
+                elif f.lane_sel:
                     for reg, kind, age in recent:
-                        if kind == "valu" and reg in sel and age < 4:
+                        if kind == "valu" and reg in f.lane_sel and age < 4:
                             report(ins, "B", f"lane select {reg} was written by a VALU instruction {age} wait state(s) earlier (needs 4)")
-                elif ins.mnem.startswith("s_sendmsg"):
+                elif f.sendmsg:
                     for reg, kind, age in recent:
                         if kind == "m0" and age < 1:
                             report(ins, "C", "m0 was written by the previous SALU instruction (needs 1 wait state)")
             # ---- advance the state past this instruction
-            ws = wait_states(ins)
-            recent = [(r, kd, a + ws) for (r, kd, a) in recent if a + ws < 5]
-            if is_valu(ins):
-                for r in valu_scalar_writes(ins):
-                    recent.append((r, "valu", 0))
-            elif ins.mnem.startswith("s_") and not ins.mnem.startswith(("s_waitcnt", "s_nop", "s_cbranch", "s_branch")):
-                ops = split_operands(ins.ops)
-                if ops and "m0" in regs_of(ops[0]):
-                    recent.append(("m0", "m0", 0))
-            n = vmcnt_of(ins)
-            if n is not None:
-                while len(pending) > n:
+            if recent:
+                recent = [(r, kd, a + f.ws) for (r, kd, a) in recent if a + f.ws < 5]
+            for r in f.valu_w:
+                recent.append((r, "valu", 0))
+            if f.m0_w:
+                recent.append(("m0", "m0", 0))
+            if f.vmcnt is not None:
+                while len(pending) > f.vmcnt:
                     pending.pop(0)
-            if is_vmem(ins):
-                pending.append(vmem_dest(ins))
+            if f.vmem:
+                pending.append(f.dest)
                 if len(pending) > 63:
                     pending.pop(0)
+            # operations older than the oldest outstanding LOAD protect nothing
+            while pending and not pending[0]:
+                pending.pop(0)
             # ---- control flow
             if ins.mnem in ("s_endpgm", "s_setpc_b64"):
                 fall = False

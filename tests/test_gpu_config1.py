@@ -104,3 +104,61 @@ def test_sscd_baseline_main_with_score_normalisation(gpu, files):
     assert n_same >= 0.97 * len(ref_rows), (n_same, len(ref_rows), len(got_rows))
     seg = matching_eval.main(["--predictions", os.path.join(p["out"], "matches.csv"), "--ground_truth", p["gt.csv"]])
     assert abs(seg.segment_ap.ap - float(fx["sn_segment_ap"])) < 1e-4
+
+
+# ---------------------------------------------------------------- round 5: the same entry points started as N ranks
+def _run_cli(module, argv, nproc=0, port=0):
+    """`python -m <module> argv` as one process, or as `nproc` ranks under torch.distributed.run (the ranks share the test
+    box's one GPU, so the process group is gloo; on a multi-GPU node the same command line runs over RCCL)."""
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+    env["MPLBACKEND"] = "Agg"
+    cmd = [sys.executable]
+    if nproc:
+        cmd += ["-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}", "--master-addr", "127.0.0.1",
+                "--master-port", str(port)]
+    cmd += ["-m", module] + argv
+    out = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    return out
+
+
+@pytest.mark.parametrize("nproc,score_norm", [(2, True), (3, False), (4, True)])
+def test_sharded_cli_writes_the_same_files(gpu, files, tmp_path, nproc, score_norm):
+    """`python -m torch.distributed.run --nproc-per-node N -m vsc2022_amd.vsc.baseline.sscd_baseline`
+    shards the query videos over N ranks, gathers the Match rows and lets rank 0 write candidates.csv / matches.csv (and
+    the score-normalised descriptors): the SAME BYTES as the single-process command (vsc/baseline/sscd_baseline.py:155-231;
+    the reference uses all GPUs through faiss, vsc/index.py:153)."""
+    fx, p = files
+    base = ["--query_features", p["q.npz"], "--ref_features", p["r.npz"], "--ground_truth", p["gt.csv"], "--overwrite"]
+    if score_norm:
+        base += ["--score_norm_features", p["noise.npz"]]
+    one, many = str(tmp_path / "one"), str(tmp_path / "many")
+    _run_cli("vsc2022_amd.vsc.baseline.sscd_baseline", base + ["--output_path", one])
+    log = _run_cli("vsc2022_amd.vsc.baseline.sscd_baseline", base + ["--output_path", many], nproc,
+                   29100 + os.getpid() % 400 + nproc)
+    assert sorted(os.listdir(one)) == sorted(os.listdir(many))
+    for name in ("candidates.csv", "matches.csv"):
+        a, b = open(os.path.join(one, name), "rb").read(), open(os.path.join(many, name), "rb").read()
+        assert len(a) > 1000 and a == b, name
+    if score_norm:
+        for name in ("sn_queries.npz", "sn_refs.npz"):
+            a, b = np.load(os.path.join(one, name)), np.load(os.path.join(many, name))
+            assert sorted(a.files) == sorted(b.files)
+            for k in a.files:
+                assert a[k].dtype == b[k].dtype and np.array_equal(a[k], b[k]), (name, k)
+    assert "sharded search" in log.stderr   # (the sharded route did run)
+
+
+def test_sharded_descriptor_eval_cli(gpu, files, tmp_path):
+    """descriptor_eval (BASELINE configs[0]) as 3 ranks: the candidate file of the single-process command, byte for byte"""
+    fx, p = files
+    base = ["--query_features", p["q.npz"], "--ref_features", p["r.npz"], "--ground_truth", p["gt.csv"]]
+    one, many = str(tmp_path / "one.csv"), str(tmp_path / "many.csv")
+    _run_cli("vsc2022_amd.cli.descriptor_eval", base + ["--candidates_output", one])
+    _run_cli("vsc2022_amd.cli.descriptor_eval", base + ["--candidates_output", many], 3, 29600 + os.getpid() % 300)
+    a, b = open(one, "rb").read(), open(many, "rb").read()
+    assert len(a) > 1000 and a == b

@@ -1,0 +1,118 @@
+"""GPU: the programmatic options of a handle (vsc_index_set_option / _get_option: the VSC_* switches without the
+environment) and caller-supplied streams (vsc_index_set_stream, vsc_tn_set_stream, vsc_set_aux_stream)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _data(seed=0, nq=700, nr=5000, d=128):
+    rng = np.random.default_rng(seed)
+    q = rng.standard_normal((nq, d)).astype(np.float32)
+    r = rng.standard_normal((nr, d)).astype(np.float32)
+    q /= np.linalg.norm(q, axis=1, keepdims=True)
+    r /= np.linalg.norm(r, axis=1, keepdims=True)
+    r[100:110] = r[5]          # ties
+    return q, r
+
+
+def test_options_round_trip_and_validation(gpu):
+    from vsc2022_amd import _lib
+    from vsc2022_amd.vsc.index import FlatIndex
+
+    idx = FlatIndex(64, _lib.METRIC_INNER_PRODUCT, 0)
+    assert idx.get_option("prefilter") == 1 and idx.get_option("i8") == 1 and idx.get_option("i8_density") == 5e-4
+    for name, value in (("i8_density", 3e-4), ("prefilter_density", 0.02), ("i8p_pair", 2), ("knn_step", 65536),
+                        ("knn_ratio", 3.0), ("cand_budget", 2 ** 24), ("i8_group", 7), ("rescore_sort", 0)):
+        idx.set_option(name, value)
+        assert idx.get_option(name) == value, name
+    with pytest.raises(ValueError):
+        idx.set_option("no_such_option", 1)
+    with pytest.raises(ValueError):
+        idx.get_option("no_such_option")
+    with pytest.raises(ValueError):
+        idx.set_option("i8_density", -1.0)
+    with pytest.raises(ValueError):
+        idx.set_option("prefilter", 3)
+    # which images of the rows are kept is decided before the first add
+    idx.set_option("prefilter", 0)
+    assert idx.get_option("prefilter") == 0 and idx.get_option("i8") == 0
+    idx.set_option("prefilter", 2)
+    idx.set_option("i8", 2)
+    idx.add(np.zeros((10, 64), dtype=np.float32))
+    with pytest.raises(ValueError):
+        idx.set_option("prefilter", 0)
+    with pytest.raises(ValueError):
+        idx.set_option("i8", 0)
+    with pytest.raises(ValueError):
+        idx.set_option("i8_exclude", 0)
+    idx.set_option("i8", 1)          # 2 -> 1 keeps the image: allowed
+    idx.set_option("prefilter", 1)
+
+
+@pytest.mark.parametrize("opts", [{"prefilter": 0}, {"prefilter": 2}, {"prefilter": 2, "i8": 2}, {"prefilter": 2, "i8": 0},
+                                  {"prefilter": 2, "i8": 2, "i8p_pair": 2}, {"prefilter": 2, "f16_kernel": 1, "i8": 0},
+                                  {"prefilter": 2, "i8": 2, "i8_sort": 0, "rescore_sort": 0}])
+def test_every_route_chosen_by_option_matches_the_oracle(gpu, orc, opts):
+    """the routes the test-suite forces through the environment, forced through vsc_index_set_option instead"""
+    from vsc2022_amd import _lib
+    from vsc2022_amd.vsc.index import FlatIndex
+
+    q, r = _data()
+    idx = FlatIndex(q.shape[1], _lib.METRIC_INNER_PRODUCT, 0)
+    for k, v in opts.items():
+        idx.set_option(k, v)
+    idx.add(r[:3000])
+    idx.add(r[3000:])
+    for K in (50, 20000, 300000):
+        i, j, s, rad = idx.global_topk(q, K)
+        oi, oj, os_ = orc.global_threshold_search(q, r, K)
+        assert np.array_equal(i, oi) and np.array_equal(j, oj) and np.array_equal(s.view(np.uint32), os_.view(np.uint32))
+    D, I = idx.search(q, 7)
+    oD, oI = orc.knn(q, r, 7)
+    assert np.array_equal(I, oI) and np.array_equal(D.view(np.uint32), oD.view(np.uint32))
+
+
+def test_handles_on_torch_streams(gpu, orc):
+    """queries produced by torch kernels on a side stream, the library bound to that stream: no device synchronisation
+    in between, same bits as the oracle; then back on the handle's own stream"""
+    import torch
+    from vsc2022_amd import _lib
+    from vsc2022_amd.engine import DeviceMatcher
+    from vsc2022_amd.vsc.index import FlatIndex
+
+    q, r = _data(seed=3, nq=1200, nr=9000, d=64)
+    dev = torch.device("cuda", 0)
+    oi, oj, os_ = orc.global_threshold_search(q, r, 40000)
+    side = torch.cuda.Stream(device=dev)
+    idx = FlatIndex(q.shape[1], _lib.METRIC_INNER_PRODUCT, 0)
+    big = torch.randn((4096, 4096), device=dev)
+    with torch.cuda.stream(side):
+        idx.use_torch_stream()
+        assert idx._stream == side.cuda_stream
+        rt = torch.from_numpy(r).to(dev, non_blocking=True)
+        for _ in range(10):           # keep the stream busy in front of the rows the library will read
+            big = big @ big
+            big = big / big.abs().max()
+        qt = (torch.from_numpy(q).to(dev, non_blocking=True) * 2.0) * 0.5   # produced by kernels on `side`
+        idx.add(rt)
+        i, j, s, rad = idx.global_topk(qt, 40000, device_out=True)
+        assert np.array_equal(i.cpu().numpy(), oi) and np.array_equal(j.cpu().numpy(), oj)
+        assert np.array_equal(s.cpu().numpy().view(np.uint32), os_.view(np.uint32))
+    idx.use_stream(None)
+    assert idx._stream is None
+    i2, j2, s2, _ = idx.global_topk(qt, 40000, device_out=True)
+    assert torch.equal(i, i2) and torch.equal(j, j2) and torch.equal(s, s2)
+    # the engine binds index, localisation context and the handle-less entry points to torch's current stream
+    off_r = np.arange(0, 9001, 30, dtype=np.int64)
+    off_q = np.arange(0, 1201, 20, dtype=np.int64)
+    with torch.cuda.stream(side):
+        m = DeviceMatcher(rt, off_r, 0)
+        m.set_queries(qt, off_q)
+        res = m.match()
+        assert m.index._stream == side.cuda_stream and m._tn_stream == side.cuda_stream
+    m2 = DeviceMatcher(rt, off_r, 0)
+    m2.set_queries(qt, off_q)
+    res2 = m2.match()
+    assert torch.equal(res.cand_q, res2.cand_q) and torch.equal(res.cand_r, res2.cand_r)
+    assert torch.equal(res.cand_score, res2.cand_score) and torch.equal(res.boxes, res2.boxes) and torch.equal(res.nbox, res2.nbox)

@@ -36,6 +36,7 @@ EXPORTS = (
     "vsc_last_error", "vsc_version", "vsc_device_count",
     "vsc_index_create", "vsc_index_destroy", "vsc_index_add", "vsc_index_ntotal", "vsc_index_dim",
     "vsc_index_metric", "vsc_index_set_hit_capacity", "vsc_index_sync", "vsc_index_knn",
+    "vsc_index_set_option", "vsc_index_get_option", "vsc_index_set_stream", "vsc_tn_set_stream", "vsc_set_aux_stream",
     "vsc_index_range_search", "vsc_index_global_topk", "vsc_index_global_topk_seeded", "vsc_index_candidates", "vsc_pair_max", "vsc_row_normalize",
     "vsc_tn_create", "vsc_tn_set_queries", "vsc_tn_destroy", "vsc_tn_localize", "vsc_tn_forward_sim", "vsc_tn_similarity",
     "vsc_index_profile", "vsc_index_profile_read", "vsc_index_profile_read_class", "vsc_index_search_stats",
@@ -132,6 +133,11 @@ def lib():
         L.vsc_index_metric.argtypes = [vp]
         L.vsc_index_set_hit_capacity.argtypes = [vp, i64]
         L.vsc_index_sync.argtypes = [vp]
+        L.vsc_index_set_option.argtypes = [vp, ctypes.c_char_p, ctypes.c_double]
+        L.vsc_index_get_option.argtypes = [vp, ctypes.c_char_p, ctypes.POINTER(ctypes.c_double)]
+        L.vsc_index_set_stream.argtypes = [vp, vp, i32]
+        L.vsc_tn_set_stream.argtypes = [vp, vp, i32]
+        L.vsc_set_aux_stream.argtypes = [i32, vp, i32]
         L.vsc_index_knn.argtypes = [vp, vp, i64, i32, i32, vp, vp, i32]
         L.vsc_index_range_search.argtypes = [vp, vp, i64, i32, f32, vp, vp, vp, i64, pi64]
         L.vsc_index_global_topk.argtypes = [vp, vp, i64, i32, i64, vp, vp, vp, i64, i32, pi64, pf32]

@@ -28,7 +28,9 @@ def main(argv=None):
                         format="%(asctime)s %(levelname)-8s %(message)s")
     ap, candidates = descriptor_eval_lib.evaluate_descriptor_track(args.query_features, args.ref_features,
                                                                    args.ground_truth)
-    if args.candidates_output:
+    from vsc2022_amd.vsc.baseline import sharded
+
+    if args.candidates_output and sharded.is_main():
         metrics.CandidatePair.write_csv(candidates, args.candidates_output)
         logging.getLogger("descriptor_eval").info("wrote %d candidates to %s", len(candidates), args.candidates_output)
     return ap, candidates

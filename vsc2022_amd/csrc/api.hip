@@ -186,7 +186,9 @@ struct vsc_index {
     double prefilter_density = 0.05;  // expected hit density below which a batch goes through the pre-filter (r03: 0.02 -> 0.05 with the cheaper exact stage: -0.8 %)
     unsigned long long stat_candidates = 0, stat_hits = 0;  // last search (vsc_index_profile_read)
     DevBuf cand[3];  // sorted hits of vsc_index_candidates
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr;      // the stream every launch of this handle goes to: own_stream, or the caller's
+    hipStream_t own_stream = nullptr;  // (vsc_index_set_stream)
+    int64_t cand_budget = (int64_t)1 << 28;  // cand_budget: entries of the candidate list a k-NN threshold pass may ask for
     Workspace ws;
     int64_t hit_cap_user = 0;
     int64_t hit_cap_learned = 0;  // the capacity the last search ended with after overflow reruns (ties keep the radius low)
@@ -278,6 +280,126 @@ struct AuxTimer {
     }
 };
 
+// ------------------------------------------------------------------ options
+// One table for the environment switches (read when a handle is created) and vsc_index_set_option / _get_option.
+struct OptionName { const char* name; const char* env; };
+static const OptionName kOptions[] = {
+    {"prefilter", "VSC_PREFILTER"}, {"prefilter_density", "VSC_PREFILTER_DENSITY"}, {"f16_kernel", "VSC_F16_KERNEL"},
+    {"i8", "VSC_I8"}, {"i8_density", "VSC_I8_DENSITY"}, {"i8_max_rel", "VSC_I8_MAX_REL"}, {"i8_exclude", "VSC_I8_EXCLUDE"},
+    {"i8_sort", "VSC_I8_SORT"}, {"i8_group", "VSC_I8_GROUP"}, {"i8p_order", "VSC_I8P_ORDER"}, {"i8p_slice", "VSC_I8P_SLICE"},
+    {"i8p_pair", "VSC_I8P_PAIR"}, {"i8_screen", "VSC_I8_SCREEN"}, {"i8_knn", "VSC_I8_KNN"}, {"knn_step", "VSC_KNN_STEP"},
+    {"knn_step_max", "VSC_KNN_STEP_MAX"}, {"knn_step_work", "VSC_KNN_STEP_WORK"}, {"rescore_sort", "VSC_RESCORE_SORT"},
+    {"knn_levels", "VSC_KNN_LEVELS"}, {"knn_subset", "VSC_KNN_SUBSET"}, {"knn_s0div", "VSC_KNN_S0DIV"},
+    {"knn_s0min", "VSC_KNN_S0MIN"}, {"knn_ratio", "VSC_KNN_RATIO"}, {"knn_nchunk", "VSC_KNN_NCHUNK"},
+    {"cand_budget", "VSC_CAND_BUDGET"}, {"debug_i8", "VSC_DEBUG_I8"}, {"debug_screen", "VSC_DEBUG_SCREEN"},
+};
+
+// Options that decide which images of the reference rows are kept can only change while the index is empty.
+static int option_needs_empty(const vsc_index* idx, const char* name) {
+    if (idx->ntotal == 0) return VSC_OK;
+    set_error("vsc_index_set_option: '%s' decides which images of the reference rows exist and can only be set while "
+              "the index is empty", name);
+    return VSC_ERR_INVALID;
+}
+
+static int apply_option(vsc_index* idx, const char* name, double v) {
+    auto is = [&](const char* n) { return strcmp(name, n) == 0; };
+    const bool ip = idx->metric == VSC_METRIC_INNER_PRODUCT;
+    if (is("prefilter")) {  // 0 off, 1 by density (default), 2 every batch / every k-NN (tests)
+        const int m = (int)v;
+        if (m < 0 || m > 2) goto bad;
+        if ((m != 0) != idx->prefilter) VSC_TRY(option_needs_empty(idx, name));
+        idx->prefilter = ip && m != 0;
+        idx->prefilter_force = idx->prefilter && m == 2;
+        if (!idx->prefilter) idx->i8_mode = 0;
+        return VSC_OK;
+    }
+    if (is("i8")) {  // 0 no int8 image, 1 by density (default), 2 every pre-filtered batch (tests)
+        const int m = (int)v;
+        if (m < 0 || m > 2) goto bad;
+        const int want = (idx->prefilter && idx->dpad8 <= I8P_MAX_DPAD8) ? m : 0;
+        if ((want != 0) != (idx->i8_mode != 0)) VSC_TRY(option_needs_empty(idx, name));
+        idx->i8_mode = want;
+        return VSC_OK;
+    }
+    if (is("f16_kernel")) {  // 1 = the 256x256 LDS-ring kernel instead of the panel-stationary one (A/B)
+        const bool frag = !(v != 0.0) && idx->dpadh <= F16P_MAX_DPADH;
+        if (frag != idx->frag) VSC_TRY(option_needs_empty(idx, name));
+        idx->frag = frag;
+        return VSC_OK;
+    }
+    if (is("i8_exclude")) {
+        const bool e = v != 0.0;
+        if (e != idx->i8_exclude) VSC_TRY(option_needs_empty(idx, name));
+        idx->i8_exclude = e;
+        return VSC_OK;
+    }
+    if (is("prefilter_density")) { if (!(v > 0.0)) goto bad; idx->prefilter_density = v; return VSC_OK; }
+    if (is("i8_density")) { if (!(v > 0.0)) goto bad; idx->i8_density = v; return VSC_OK; }
+    if (is("i8_max_rel")) { if (!(v > 0.0)) goto bad; idx->i8_max_rel = v; return VSC_OK; }
+    if (is("i8_sort")) { idx->i8_sort_rows = v != 0.0; return VSC_OK; }
+    if (is("i8_group")) { idx->i8_group_shift = std::max(0, std::min(16, (int)v)); return VSC_OK; }
+    if (is("i8p_order")) { idx->i8p_order = (int)v == 1 ? 1 : 0; return VSC_OK; }
+    if (is("i8p_slice")) { if (v < 0.0) goto bad; idx->i8p_slice = (int)v; return VSC_OK; }
+    if (is("i8p_pair")) { idx->i8p_pair = std::max(0, std::min(2, (int)v)); return VSC_OK; }
+    if (is("i8_screen")) { idx->i8_screen = v == 1.0; return VSC_OK; }
+    if (is("i8_knn")) { idx->knn_i8 = v != 0.0; return VSC_OK; }
+    if (is("knn_step")) { idx->knn_step = std::max<int64_t>(0, (int64_t)v) / 256 * 256; return VSC_OK; }
+    if (is("knn_step_max")) { idx->knn_step_max = std::max<int64_t>(32768, (int64_t)v); return VSC_OK; }
+    if (is("knn_step_work")) { idx->knn_step_work = std::max(0.0, v); return VSC_OK; }
+    if (is("rescore_sort")) { idx->rescore_by_ref = v != 0.0; return VSC_OK; }
+    if (is("knn_levels")) { idx->knn_two_level = v != 1.0; return VSC_OK; }  // 1 = one refinement level only
+    if (is("knn_subset")) { if (!(v > 0.0)) goto bad; idx->knn_subset_factor = v; return VSC_OK; }
+    if (is("knn_s0div")) { idx->knn_s0_div = v > 0.0 ? (int)v : 28; return VSC_OK; }
+    if (is("knn_s0min")) { idx->knn_s0_min = v >= 64.0 ? (int)v : 1024; return VSC_OK; }
+    if (is("knn_ratio")) { idx->knn_ratio = v; return VSC_OK; }
+    if (is("knn_nchunk")) { idx->knn_nchunk = (int)v; return VSC_OK; }
+    if (is("cand_budget")) { if (!(v >= 1048576.0)) goto bad; idx->cand_budget = (int64_t)v; return VSC_OK; }
+    if (is("debug_i8")) { idx->debug_i8 = v != 0.0; return VSC_OK; }
+    if (is("debug_screen")) { idx->debug_screen = v != 0.0; return VSC_OK; }
+    set_error("vsc_index_set_option: unknown option '%s'", name);
+    return VSC_ERR_INVALID;
+bad:
+    set_error("vsc_index_set_option: value %g is out of range for '%s'", v, name);
+    return VSC_ERR_INVALID;
+}
+
+static int read_option(const vsc_index* idx, const char* name, double* out) {
+    auto is = [&](const char* n) { return strcmp(name, n) == 0; };
+    if (is("prefilter")) *out = idx->prefilter ? (idx->prefilter_force ? 2 : 1) : 0;
+    else if (is("i8")) *out = idx->i8_mode;
+    else if (is("f16_kernel")) *out = idx->frag ? 0 : 1;
+    else if (is("i8_exclude")) *out = idx->i8_exclude;
+    else if (is("prefilter_density")) *out = idx->prefilter_density;
+    else if (is("i8_density")) *out = idx->i8_density;
+    else if (is("i8_max_rel")) *out = idx->i8_max_rel;
+    else if (is("i8_sort")) *out = idx->i8_sort_rows;
+    else if (is("i8_group")) *out = idx->i8_group_shift;
+    else if (is("i8p_order")) *out = idx->i8p_order;
+    else if (is("i8p_slice")) *out = idx->i8p_slice;
+    else if (is("i8p_pair")) *out = idx->i8p_pair;
+    else if (is("i8_screen")) *out = idx->i8_screen;
+    else if (is("i8_knn")) *out = idx->knn_i8;
+    else if (is("knn_step")) *out = (double)idx->knn_step;
+    else if (is("knn_step_max")) *out = (double)idx->knn_step_max;
+    else if (is("knn_step_work")) *out = idx->knn_step_work;
+    else if (is("rescore_sort")) *out = idx->rescore_by_ref;
+    else if (is("knn_levels")) *out = idx->knn_two_level ? 0 : 1;
+    else if (is("knn_subset")) *out = idx->knn_subset_factor;
+    else if (is("knn_s0div")) *out = idx->knn_s0_div;
+    else if (is("knn_s0min")) *out = idx->knn_s0_min;
+    else if (is("knn_ratio")) *out = idx->knn_ratio;
+    else if (is("knn_nchunk")) *out = idx->knn_nchunk;
+    else if (is("cand_budget")) *out = (double)idx->cand_budget;
+    else if (is("debug_i8")) *out = idx->debug_i8;
+    else if (is("debug_screen")) *out = idx->debug_screen;
+    else {
+        set_error("vsc_index_get_option: unknown option '%s'", name);
+        return VSC_ERR_INVALID;
+    }
+    return VSC_OK;
+}
+
 extern "C" {
 
 int vsc_aux_profile(int enable) {
@@ -319,62 +441,32 @@ int vsc_index_create(int dim, int metric, int device, vsc_index_t** out) {
     idx->dim = dim;
     idx->dpad = round_up(dim, K_PAD);
     idx->dpadh = round_up(dim, 128);
-    idx->frag = idx->dpadh <= F16P_MAX_DPADH;  // VSC_F16_KERNEL=ring keeps the 256x256 LDS-ring kernel (A/B runs)
-    if (const char* e = getenv("VSC_F16_KERNEL"))
-        if (e[0] == 'r') idx->frag = false;
+    idx->frag = idx->dpadh <= F16P_MAX_DPADH;
     idx->metric = metric;
-    {
-        // VSC_PREFILTER=0 keeps every search on the all-fp32 kernel (A/B and debugging);
-        // VSC_PREFILTER=2 sends EVERY batch through the pre-filter, whatever its hit density (tests)
-        const char* e = getenv("VSC_PREFILTER");
-        idx->prefilter = metric == VSC_METRIC_INNER_PRODUCT && !(e && e[0] == '0');
-        idx->prefilter_force = idx->prefilter && e && e[0] == '2';
-        const char* d = getenv("VSC_PREFILTER_DENSITY");
-        if (d && atof(d) > 0.0) idx->prefilter_density = atof(d);
-        // VSC_I8=0: no int8 image; VSC_I8=2: every pre-filtered batch goes through the int8 kernel (tests);
-        // VSC_I8_DENSITY: expected hit density below which a batch does (default 5e-4: the looser int8 bound
-        // brings ~4x the candidates, each ~0.3 ns of exact re-scoring, against 0.36 ps saved per pair)
-        idx->dpad8 = round_up(dim, 256);
-        const char* i8 = getenv("VSC_I8");
-        idx->i8_mode = (idx->prefilter && idx->dpad8 <= I8P_MAX_DPAD8 && !(i8 && i8[0] == '0')) ? 1 : 0;
-        if (idx->i8_mode && i8 && i8[0] == '2') idx->i8_mode = 2;
-        const char* dd = getenv("VSC_I8_DENSITY");
-        if (dd && atof(dd) > 0.0) idx->i8_density = atof(dd);
-        const char* mr = getenv("VSC_I8_MAX_REL");
-        if (mr && atof(mr) > 0.0) idx->i8_max_rel = atof(mr);
-        auto is = [](const char* name, char c) { const char* v = getenv(name); return v && v[0] == c; };
-        auto num = [](const char* name, double dflt) { const char* v = getenv(name); return v ? atof(v) : dflt; };
-        idx->i8_exclude = !is("VSC_I8_EXCLUDE", '0');
-        idx->i8p_order = (int)num("VSC_I8P_ORDER", 1.0) == 1 ? 1 : 0;
-        idx->i8p_slice = (int)num("VSC_I8P_SLICE", 0.0);
-        idx->knn_step = std::max<int64_t>(0, (int64_t)num("VSC_KNN_STEP", 0.0)) / 256 * 256;
-        idx->knn_step_max = std::max<int64_t>(32768, (int64_t)num("VSC_KNN_STEP_MAX", 262144.0));
-        idx->knn_step_work = std::max(0.0, num("VSC_KNN_STEP_WORK", 64.0));
-        idx->i8p_pair = std::max(0, std::min(2, (int)num("VSC_I8P_PAIR", 1.0)));
-        idx->i8_sort_rows = !is("VSC_I8_SORT", '0');
-        idx->i8_group_shift = getenv("VSC_I8_GROUP") ? std::max(0, std::min(16, (int)num("VSC_I8_GROUP", 9.0))) : 9;
-        idx->rescore_by_ref = !is("VSC_RESCORE_SORT", '0');
-        idx->i8_screen = is("VSC_I8_SCREEN", '1');
-        idx->knn_i8 = !is("VSC_I8_KNN", '0');
-        idx->knn_two_level = !is("VSC_KNN_LEVELS", '1');
-        idx->knn_subset_factor = num("VSC_KNN_SUBSET", 300.0);
-        idx->knn_s0_div = num("VSC_KNN_S0DIV", 0.0) > 0.0 ? (int)num("VSC_KNN_S0DIV", 0.0) : 28;
-        idx->knn_ratio = num("VSC_KNN_RATIO", 0.0);
-        idx->knn_s0_min = num("VSC_KNN_S0MIN", 0.0) >= 64.0 ? (int)num("VSC_KNN_S0MIN", 0.0) : 1024;
-        idx->knn_nchunk = (int)num("VSC_KNN_NCHUNK", 0.0);
-        idx->debug_i8 = getenv("VSC_DEBUG_I8") != nullptr;
-        idx->debug_screen = getenv("VSC_DEBUG_SCREEN") != nullptr;
+    idx->dpad8 = round_up(dim, 256);
+    idx->prefilter = metric == VSC_METRIC_INNER_PRODUCT;
+    idx->i8_mode = (idx->prefilter && idx->dpad8 <= I8P_MAX_DPAD8) ? 1 : 0;
+    // every switch of include/vscmi.h: the environment supplies the handle's initial options, vsc_index_set_option
+    // changes them afterwards (the same names without the VSC_ prefix, lower case)
+    for (const OptionName& o : kOptions) {
+        const char* v = getenv(o.env);
+        if (!v || !v[0]) continue;
+        double x = atof(v);
+        if (strcmp(o.name, "f16_kernel") == 0) x = v[0] == 'r' ? 1.0 : 0.0;           // VSC_F16_KERNEL=ring
+        if (strcmp(o.name, "debug_i8") == 0 || strcmp(o.name, "debug_screen") == 0) x = 1.0;  // (set = on)
+        (void)apply_option(idx, o.name, x);  // (an out-of-range value in the environment keeps the default, as before)
     }
     idx->device = device;
-    hipError_t e = hipStreamCreateWithFlags(&idx->stream, hipStreamNonBlocking);
+    hipError_t e = hipStreamCreateWithFlags(&idx->own_stream, hipStreamNonBlocking);
     if (e != hipSuccess) {
         set_error("hipStreamCreate failed: %s", hipGetErrorString(e));
         delete idx;
         return VSC_ERR_HIP;
     }
+    idx->stream = idx->own_stream;
     int rc = set_thresh_kernel_attrs();
     if (rc != VSC_OK) {
-        (void)hipStreamDestroy(idx->stream);
+        (void)hipStreamDestroy(idx->own_stream);
         delete idx;
         return rc;
     }
@@ -397,9 +489,37 @@ int vsc_index_destroy(vsc_index_t* idx) {
         (void)hipEventDestroy(e.first);
         (void)hipEventDestroy(e.second);
     }
-    (void)hipStreamDestroy(idx->stream);
+    (void)hipStreamDestroy(idx->own_stream);
     delete idx;
     return VSC_OK;
+}
+
+int vsc_index_set_stream(vsc_index_t* idx, void* hip_stream, int own) {
+    if (!idx) {
+        set_error("vsc_index_set_stream: invalid argument");
+        return VSC_ERR_INVALID;
+    }
+    VSC_HIP(hipSetDevice(idx->device));
+    VSC_HIP(hipStreamSynchronize(idx->stream));  // nothing of this handle is left on the stream it leaves
+    VSC_TRY(prof_collect(idx));
+    idx->stream = own ? idx->own_stream : (hipStream_t)hip_stream;  // (NULL = HIP's default stream, torch's default)
+    return VSC_OK;
+}
+
+int vsc_index_set_option(vsc_index_t* idx, const char* name, double value) {
+    if (!idx || !name) {
+        set_error("vsc_index_set_option: invalid argument");
+        return VSC_ERR_INVALID;
+    }
+    return apply_option(idx, name, value);
+}
+
+int vsc_index_get_option(const vsc_index_t* idx, const char* name, double* value) {
+    if (!idx || !name || !value) {
+        set_error("vsc_index_get_option: invalid argument");
+        return VSC_ERR_INVALID;
+    }
+    return read_option(idx, name, value);
 }
 
 int64_t vsc_index_ntotal(const vsc_index_t* idx) { return idx ? idx->ntotal : 0; }
@@ -575,8 +695,14 @@ static int i8_prepare(vsc_index* idx) {
     if (!idx->i8_mode) return VSC_OK;
     if (idx->i8_seen < idx->ntotal) {
         const int64_t first_new = idx->i8_seen;
+        const int rc = i8_after_add(idx, first_new, idx->ntotal - first_new, round_up64(idx->ntotal, ROW_PAD_REF));
+        if (rc != VSC_OK) {
+            // (allocation / HIP failure half way: the rows stay "unseen" -- the min / max fold is idempotent -- and the
+            // whole image is rewritten before the next search may use it)
+            idx->i8_dirty = true;
+            return rc;
+        }
         idx->i8_seen = idx->ntotal;
-        VSC_TRY(i8_after_add(idx, first_new, idx->ntotal - first_new, round_up64(idx->ntotal, ROW_PAD_REF)));
     }
     if (!idx->i8_dirty) return VSC_OK;
     idx->i8_loose_sum = idx->i8_loose_cnt = 0.0;
@@ -1297,11 +1423,20 @@ static int knn_threshold_pass(vsc_index* idx, const float* qp, int64_t nq, int64
     if (idx->knn_step > 0) step = idx->knn_step;
     int64_t cap = (int64_t)((double)nq * per_row) + (r_begin > 0 ? nq * k : 0) + (1 << 20);
     cap = std::min<int64_t>(cap, nq * (nrange + k) + 1024);
-    if (idx->hit_cap_user > 0) cap = idx->hit_cap_user;
-    // the candidate list is consumed slab by slab, only the hits accumulate over the whole query set
+    if (idx->hit_cap_user > 0) {
+        cap = idx->hit_cap_user;
+        // the lists so far (nq x k triples) re-enter the hit buffer before anything else: a user capacity below that
+        // cannot hold them (knn_seed_hits writes unconditionally) -- the caller falls back to the exact kernel
+        if (r_begin > 0 && cap < nq * k + 1024) return VSC_ERR_OVERFLOW;
+    }
+    // The candidate list is consumed slab by slab, only the hits accumulate over the whole query set.  Its size grows
+    // with rows per launch x expected hits per row (k = 20: ~1500 entries per row on int8): bounded by a budget
+    // (VSC_CAND_BUDGET entries, default 2^28 = 8.6 GB of list) by halving the rows per launch, so that several ranks
+    // can share a GPU and smaller devices do not run out of memory
+    const double per_row_c = per_row * (use_i8 ? 6.0 : 1.0);  // (the int8 bound is looser: ~4-5x the candidates per hit)
+    while (step > 32768 && (double)std::min(nq, step) * per_row_c > (double)idx->cand_budget) step /= 2;
     const int64_t slab_rows = std::min(nq, step);
-    // (the int8 bound is looser: ~4-5x the candidates per hit)
-    int64_t ccap = std::min<int64_t>((int64_t)((double)slab_rows * per_row * (use_i8 ? 6.0 : 1.0)) + (1 << 20),
+    int64_t ccap = std::min<int64_t>((int64_t)((double)slab_rows * per_row_c) + (1 << 20),
                                      slab_rows * nrange + 1024);
     if (!use_i8) ccap = std::min(ccap, std::max<int64_t>(cap, 1024));
     VSC_TRY(ensure_hit_buffers(idx, cap, ccap, false));
@@ -1488,7 +1623,8 @@ int vsc_index_search_stats(vsc_index_t* idx, int64_t* candidates, int64_t* hits)
 // ------------------------------------------------------------------ stand-alone device ops
 
 struct DeviceCtx {
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr;      // own_stream, or the caller's (vsc_set_aux_stream)
+    hipStream_t own_stream = nullptr;
     Workspace ws;
     std::mutex mu;
 };
@@ -1499,10 +1635,11 @@ static DeviceCtx* device_ctx(int device) {
     if ((int)ctxs.size() <= device) ctxs.resize(device + 1, nullptr);
     if (!ctxs[device]) {
         DeviceCtx* c = new DeviceCtx();
-        if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
+        if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess) {
             delete c;
             return nullptr;
         }
+        c->stream = c->own_stream;
         ctxs[device] = c;
     }
     return ctxs[device];
@@ -1517,6 +1654,20 @@ static int to_device(const void* p, size_t bytes, int mem, DevBuf& buf, const vo
     VSC_TRY(buf.reserve(std::max<size_t>(bytes, 16)));
     if (bytes) VSC_HIP(hipMemcpyAsync(buf.p, p, bytes, hipMemcpyHostToDevice, s));
     *out = buf.p;
+    return VSC_OK;
+}
+
+int vsc_set_aux_stream(int device, void* hip_stream, int own) {
+    VSC_TRY(check_device(device));
+    VSC_HIP(hipSetDevice(device));
+    DeviceCtx* c = device_ctx(device);
+    if (!c) {
+        set_error("vsc_set_aux_stream: device context unavailable");
+        return VSC_ERR_HIP;
+    }
+    std::lock_guard<std::mutex> lk(c->mu);
+    VSC_HIP(hipStreamSynchronize(c->stream));
+    c->stream = own ? c->own_stream : (hipStream_t)hip_stream;
     return VSC_OK;
 }
 
@@ -1709,10 +1860,22 @@ struct vsc_tn_ctx {
     DevBuf qfeat, rfeat, d_qoff, d_roff;
     DevBuf d_pq, d_pr, d_work, d_nbox, d_boxes, d_bmax, slab, sims;
     Workspace ws;
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr;      // own_stream, or the caller's (vsc_tn_set_stream)
+    hipStream_t own_stream = nullptr;
 };
 
 extern "C" {
+
+int vsc_tn_set_stream(vsc_tn_ctx_t* c, void* hip_stream, int own) {
+    if (!c) {
+        set_error("vsc_tn_set_stream: invalid argument");
+        return VSC_ERR_INVALID;
+    }
+    VSC_HIP(hipSetDevice(c->device));
+    VSC_HIP(hipStreamSynchronize(c->stream));
+    c->stream = own ? c->own_stream : (hipStream_t)hip_stream;
+    return VSC_OK;
+}
 
 int vsc_tn_create(const float* qfeat, const int64_t* q_off, int64_t n_qvid, const float* rfeat,
                   const int64_t* r_off, int64_t n_rvid, int dim, int feat_mem, int device,
@@ -1736,7 +1899,8 @@ int vsc_tn_create(const float* qfeat, const int64_t* q_off, int64_t n_qvid, cons
         vsc_tn_destroy(c);
         return code;
     };
-    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
+    if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) == hipSuccess) c->stream = c->own_stream;
+    if (!c->own_stream) {
         set_error("hipStreamCreate failed");
         delete c;
         return VSC_ERR_HIP;
@@ -1801,7 +1965,7 @@ int vsc_tn_destroy(vsc_tn_ctx_t* c) {
     c->d_pq.release(); c->d_pr.release(); c->d_work.release(); c->d_nbox.release();
     c->d_boxes.release(); c->d_bmax.release(); c->slab.release(); c->sims.release();
     c->ws.release();
-    if (c->stream) (void)hipStreamDestroy(c->stream);
+    if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
     return VSC_OK;
 }

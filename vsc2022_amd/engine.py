@@ -54,12 +54,31 @@ def _dev_ptr(t: torch.Tensor) -> int:
     return t.data_ptr()
 
 
+# The entry points that own no handle (vsc_row_normalize, vsc_pair_max) run on a per-device stream of the library; bound to
+# torch's current stream (vsc_set_aux_stream) they need no device-wide synchronisation before they read torch's tensors.
+_AUX_STREAM = {}
+
+
+def bind_aux_stream(device: torch.device):
+    st = torch.cuda.current_stream(device).cuda_stream
+    if _AUX_STREAM.get(device.index) != st:
+        _lib.check(_lib.lib().vsc_set_aux_stream(device.index, ctypes.c_void_p(st), 0))
+        _AUX_STREAM[device.index] = st
+
+
+def _after_torch(device: torch.device):
+    if os.environ.get("VSC_TORCH_STREAM", "1") != "0":
+        bind_aux_stream(device)
+        return
+    torch.cuda.synchronize(device)
+
+
 def row_normalize_device(x: torch.Tensor) -> torch.Tensor:
     """Rows scaled to unit L2 norm by libvscmi (zero rows stay zero), HBM in, HBM out."""
     x = x.to(torch.float32).contiguous()
     out = torch.empty_like(x)
     if x.shape[0]:
-        torch.cuda.synchronize(x.device)
+        _after_torch(x.device)
         _lib.check(_lib.lib().vsc_row_normalize(_dev_ptr(x), x.shape[0], x.shape[1], _lib.MEM_DEVICE, _dev_ptr(out),
                                                 _lib.MEM_DEVICE, x.device.index))
     return out
@@ -87,7 +106,8 @@ class DeviceScoreNormalizer:
             self.sel = torch.tensor(keep, dtype=torch.int64, device=dev)
         noise = self._prepare(noise)
         self.noise_index = FlatIndex(int(noise.shape[1]), _lib.METRIC_INNER_PRODUCT, dev.index)
-        torch.cuda.synchronize(dev)
+        if os.environ.get("VSC_TORCH_STREAM", "1") != "0":
+            self.noise_index.use_torch_stream()
         self.noise_index.add(noise)
 
     def _prepare(self, x: torch.Tensor) -> torch.Tensor:
@@ -119,16 +139,24 @@ class DeviceMatcher:
     *_off: int64 numpy row offsets per video.
     """
 
-    def __init__(self, ref_feats, r_off: np.ndarray, device: Optional[int] = None):
+    def __init__(self, ref_feats, r_off: np.ndarray, device: Optional[int] = None, tn_ref_feats=None):
+        """tn_ref_feats: reference rows the ALIGNER sees when they differ from the rows that are searched
+        (vsc/baseline/sscd_baseline.py:128-135: without score normalisation the reference searches the descriptors as they
+        are and localises on their L2-normalised copies)."""
         self.device = _lib.default_device() if device is None else int(device)
         self.tdev = torch.device("cuda", self.device)
         torch.cuda.set_device(self.tdev)
         self.r_off = np.ascontiguousarray(r_off, dtype=np.int64)
         self.n_rvid = len(self.r_off) - 1
         self.ref_feats = self._as_dev(ref_feats)
+        self.tn_ref_feats = self.ref_feats if tn_ref_feats is None else self._as_dev(tn_ref_feats)
         self.dim = int(self.ref_feats.shape[1])
         self.index = FlatIndex(self.dim, _lib.METRIC_INNER_PRODUCT, self.device)
-        torch.cuda.synchronize(self.tdev)
+        # the library's handles run on torch's current stream (vsc_index_set_stream & co., round 5): no device-wide
+        # synchronisation in front of every call (VSC_TORCH_STREAM=0: the handles' own streams + synchronisations)
+        self.torch_stream = os.environ.get("VSC_TORCH_STREAM", "1") != "0"
+        if self.torch_stream:
+            self.index.use_torch_stream()
         self.index.add(self.ref_feats)
         lens = torch.from_numpy(np.diff(self.r_off)).to(self.tdev)
         self.row2r = torch.repeat_interleave(torch.arange(self.n_rvid, dtype=torch.int32, device=self.tdev), lens)
@@ -149,23 +177,42 @@ class DeviceMatcher:
         return b
 
     # ---- queries
-    def set_queries(self, q_feats, q_off: np.ndarray):
+    def set_queries(self, q_feats, q_off: np.ndarray, tn_q_feats=None):
         self.q_off = np.ascontiguousarray(q_off, dtype=np.int64)
         self.n_qvid = len(self.q_off) - 1
         self.q_feats = self._as_dev(q_feats)
+        self.tn_q_feats = self.q_feats if tn_q_feats is None else self._as_dev(tn_q_feats)
         lens = torch.from_numpy(np.diff(self.q_off)).to(self.tdev)
         self.row2q = torch.repeat_interleave(torch.arange(self.n_qvid, dtype=torch.int32, device=self.tdev), lens)
-        torch.cuda.synchronize(self.tdev)
         if self._tn is not None:
             # the references stay packed in the Temporal-Network context: only the query side is replaced
-            _lib.check(_lib.lib().vsc_tn_set_queries(self._tn, _dev_ptr(self.q_feats), self.q_off.ctypes.data,
+            self._order()
+            _lib.check(_lib.lib().vsc_tn_set_queries(self._tn, _dev_ptr(self.tn_q_feats), self.q_off.ctypes.data,
                                                      self.n_qvid, _lib.MEM_DEVICE))
             return
+        torch.cuda.synchronize(self.tdev)  # (once: a fresh context packs its rows on its own stream, bound below)
         ctx = ctypes.c_void_p()
         _lib.check(_lib.lib().vsc_tn_create(
-            _dev_ptr(self.q_feats), self.q_off.ctypes.data, self.n_qvid, _dev_ptr(self.ref_feats),
-            self.r_off.ctypes.data, self.n_rvid, self.dim, _lib.MEM_DEVICE, self.device, ctypes.byref(ctx)))
+            _dev_ptr(self.tn_q_feats), self.q_off.ctypes.data, self.n_qvid, _dev_ptr(self.tn_ref_feats),
+            self.r_off.ctypes.data, self.n_rvid, int(self.tn_ref_feats.shape[1]), _lib.MEM_DEVICE, self.device,
+            ctypes.byref(ctx)))
         self._tn = ctx
+        self._tn_stream = None
+        self._order()
+
+    def _order(self):
+        """torch's queued work before the library's next reads: (re)bind the handles to torch's current stream, or
+        synchronise the device when the library keeps its own streams"""
+        if not self.torch_stream:
+            torch.cuda.synchronize(self.tdev)
+            return
+        st = torch.cuda.current_stream(self.tdev).cuda_stream
+        if self.index._stream != st:
+            self.index.use_stream(st)
+        if self._tn is not None and getattr(self, "_tn_stream", None) != st:
+            _lib.check(_lib.lib().vsc_tn_set_stream(self._tn, ctypes.c_void_p(st), 0))
+            self._tn_stream = st
+        bind_aux_stream(self.tdev)
 
     def __del__(self):
         tn = getattr(self, "_tn", None)
@@ -191,7 +238,7 @@ class DeviceMatcher:
         oj = self._buf(tag + "_j", cap, torch.int32)
         os_ = self._buf(tag + "_s", cap, torch.float32)
         n_out, radius = ctypes.c_int64(0), ctypes.c_float(0.0)
-        torch.cuda.synchronize(self.tdev)
+        self._order()
         if seed_radius is None:
             _lib.check(_lib.lib().vsc_index_global_topk(
                 self.index.handle, _dev_ptr(q), nq, _lib.MEM_DEVICE, int(K),
@@ -242,7 +289,7 @@ class DeviceMatcher:
         n_pairs = ctypes.c_int64(0)
         if n:
             hi, hj, hs = hi.contiguous(), hj.contiguous(), hs.contiguous()
-            torch.cuda.synchronize(self.tdev)
+            self._order()
             _lib.check(_lib.lib().vsc_pair_max(
                 _dev_ptr(hi), _dev_ptr(hj), _dev_ptr(hs), n, _lib.MEM_DEVICE, _dev_ptr(self.row2q),
                 int(self.row2q.numel()), _dev_ptr(self.row2r), int(self.row2r.numel()), _lib.MEM_DEVICE,
@@ -260,7 +307,7 @@ class DeviceMatcher:
         if n:
             prm = tn_params(**(tn_kwargs or REFERENCE_TN))
             pq, pr = pair_q.to(torch.int32).contiguous(), pair_r.to(torch.int32).contiguous()
-            torch.cuda.synchronize(self.tdev)
+            self._order()
             _lib.check(_lib.lib().vsc_tn_localize(
                 self._tn, _dev_ptr(pq), _dev_ptr(pr), n, _lib.MEM_DEVICE, ctypes.byref(prm), float(bias),
                 _dev_ptr(nbox), _dev_ptr(boxes), _dev_ptr(bmax), _lib.MEM_DEVICE))
@@ -268,12 +315,13 @@ class DeviceMatcher:
 
     # ---- the whole hot path
     def match(self, n_qvid_global: Optional[int] = None, qvid_base: int = 0, row_base: int = 0, group=None,
-              bias: float = 0.0) -> MatchResult:
+              bias: float = 0.0, localize: bool = True) -> MatchResult:
         """search -> candidates -> localisation for the resident queries.
 
         Single process: n_qvid_global is None.  Sharded (one process per GPU): this rank owns the
         query videos [qvid_base, qvid_base + n_qvid) / rows [row_base, ...) of a global query set
         of n_qvid_global videos; the two global cuts are resolved with vsc2022_amd.dist.
+        localize=False stops after the candidate table (vsc/descriptor_eval_lib.py:42-49: no aligner).
         """
         sharded = n_qvid_global is not None and torch.distributed.is_initialized() and \
             (torch.distributed.get_world_size(group) > 1 or os.environ.get("VSC_FORCE_SHARDED") == "1")
@@ -285,7 +333,7 @@ class DeviceMatcher:
             hi, hj, hs, radius = self.search(K)
             pq, pr, ps, pf = self.pair_max(hi, hj, hs)
             n_cand = min(int(ps.numel()), n_cand_cut)
-            n_loc = min(n_cand, n_loc_cut)
+            n_loc = min(n_cand, n_loc_cut) if localize else 0
             nbox, boxes, bmax = self.localize(pq[:n_loc], pr[:n_loc], bias)
             return MatchResult(int(hs.numel()), int(ps.numel()), n_cand, n_loc, int(nbox.sum().item()),
                                pq[:n_cand], pr[:n_cand], ps[:n_cand],
@@ -334,7 +382,7 @@ class DeviceMatcher:
         first_j = hj[pf].to(torch.int64) if pf.numel() else pf
         cands = vdist.merge_candidates(pq + qvid_base, pr, ps, first_i, first_j, n_cand_cut, group)
         n_cand = len(cands)
-        n_loc = min(n_cand, n_loc_cut)
+        n_loc = min(n_cand, n_loc_cut) if localize else 0
         mine = (cands.q_vid[:n_loc] >= qvid_base) & (cands.q_vid[:n_loc] < qvid_base + self.n_qvid)
         loc_index = torch.nonzero(mine).flatten()
         nbox, boxes, bmax = self.localize(cands.q_vid[loc_index] - qvid_base, cands.r_vid[loc_index], bias)

@@ -7,6 +7,11 @@ Drop-in for `python -m vsc.baseline.sscd_baseline` of the reference (same flags,
 
     python -m vsc2022_amd.vsc.baseline.sscd_baseline --query_features q.npz --ref_features r.npz \
         --output_path out/ [--score_norm_features noise.npz] [--ground_truth gt.csv] [--overwrite]
+
+Several GPUs: start the same module as N ranks (`python -m torch.distributed.run --nproc-per-node N -m
+vsc2022_amd.vsc.baseline.sscd_baseline ...`): the query videos are sharded over the ranks, the files rank 0 writes are the
+single-process run's, byte for byte (vsc/baseline/sharded.py; the reference's analogue is FAISS spreading its index over
+all visible GPUs, /root/reference/vsc/index.py:153).
 """
 import argparse
 import logging
@@ -17,6 +22,7 @@ from typing import List, Optional, Sequence, Tuple
 from vsc2022_amd.vsc import metrics as M
 from vsc2022_amd.vsc import storage
 from vsc2022_amd.vsc.baseline import localization as loc
+from vsc2022_amd.vsc.baseline import sharded
 from vsc2022_amd.vsc.baseline.score_normalization import _normalize_videos, score_normalize
 from vsc2022_amd.vsc.candidates import CandidateGeneration, MaxScoreAggregation
 from vsc2022_amd.vsc.index import VideoFeature
@@ -85,6 +91,19 @@ def match(queries: List[VideoFeature], refs: List[VideoFeature], output_path: st
     os.makedirs(output_path, exist_ok=True)
     candidate_file = os.path.join(output_path, "candidates.csv")
     matches_file = os.path.join(output_path, "matches.csv")
+    if sharded.requested():
+        # N ranks: each searches and localises its range of the query videos; rank 0 writes the (identical) files
+        n_keep = int(CONSTANTS.candidates_per_query * len(queries))
+        pairs, found, res = sharded.match_sharded(
+            queries, refs, score_normalization, CONSTANTS.retrieve_per_query, CONSTANTS.candidates_per_query,
+            CONSTANTS.localize_per_query, CONSTANTS.tn_max_step, CONSTANTS.tn_min_length, CONSTANTS.score_norm_bias)
+        if sharded.is_main():
+            logger.info("sharded search: %d candidate pairs, %d segments (tie on the K cut: %s%s)", len(pairs), len(found),
+                        res.tie_on_cut, ", tied hits dropped as the reference drops them" if res.ties_dropped else "")
+            M.CandidatePair.write_csv(pairs[:n_keep], candidate_file)
+            M.Match.write_csv(found, matches_file)
+        sharded.barrier()
+        return candidate_file, matches_file
     pairs = search(queries, refs)
     M.CandidatePair.write_csv(pairs, candidate_file)
     M.Match.write_csv(localize_and_verify(queries, refs, pairs, score_normalization=score_normalization), matches_file)
@@ -126,20 +145,35 @@ def build_parser() -> argparse.ArgumentParser:
 
 
 def main(args):
+    multi = sharded.requested()
+    if multi:
+        sharded.init()
     if os.path.exists(args.output_path) and not args.overwrite:
         raise Exception(f"Output path already exists: {args.output_path}. Do you want to --overwrite?")
+    if multi:
+        sharded.barrier()  # (nobody creates the directory before everybody has looked)
     queries = storage.load_features(args.query_features, M.Dataset.QUERIES)
     refs = storage.load_features(args.ref_features, M.Dataset.REFS)
     normalised = bool(args.score_norm_features)
     if normalised:
         noise = storage.load_features(args.score_norm_features, M.Dataset.REFS)
-        queries, refs = score_normalize(queries, refs, noise, beta=CONSTANTS.score_norm_beta)
-        os.makedirs(args.output_path, exist_ok=True)
-        storage.store_features(os.path.join(args.output_path, "sn_queries.npz"), queries)
-        storage.store_features(os.path.join(args.output_path, "sn_refs.npz"), refs)
+        if multi:
+            # the 1-NN against the noise set is per query row: every rank adapts its own range of the query videos
+            # (and the references, which are cheap), then the adapted query descriptors are gathered
+            lo, hi = sharded.shard_of(queries)
+            mine, refs = score_normalize(queries[lo:hi], refs, noise, beta=CONSTANTS.score_norm_beta)
+            queries = sharded.gather_videos(mine, queries)
+        else:
+            queries, refs = score_normalize(queries, refs, noise, beta=CONSTANTS.score_norm_beta)
+        if sharded.is_main():
+            os.makedirs(args.output_path, exist_ok=True)
+            storage.store_features(os.path.join(args.output_path, "sn_queries.npz"), queries)
+            storage.store_features(os.path.join(args.output_path, "sn_refs.npz"), refs)
     candidate_file, match_file = match(queries, refs, args.output_path, score_normalization=normalised)
-    if args.ground_truth:
+    if args.ground_truth and sharded.is_main():
         _report(args.output_path, args.ground_truth, candidate_file, match_file)
+    if multi:
+        sharded.barrier()
 
 
 if __name__ == "__main__":

@@ -129,6 +129,7 @@ class FlatIndex:
         self.metric_type = metric
         self.device = _lib.default_device() if device is None else int(device)
         self._h = ctypes.c_void_p()
+        self._stream = None  # None: the handle's own stream; else the hipStream_t value it was bound to (0 = default stream)
         _lib.check(_lib.lib().vsc_index_create(self.d, metric, self.device, ctypes.byref(self._h)))
 
     def __del__(self):
@@ -148,6 +149,43 @@ class FlatIndex:
     def ntotal(self) -> int:
         return int(_lib.lib().vsc_index_ntotal(self._h))
 
+    # ---- options and stream (include/vscmi.h: vsc_index_set_option / _get_option / _set_stream)
+    def set_option(self, name: str, value: float):
+        """Programmatic form of the VSC_* switches (name = the variable's without the prefix, lower case), e.g.
+        `index.set_option("i8_density", 3e-4)`; ValueError for unknown names / values / options fixed once rows exist."""
+        _lib.check(_lib.lib().vsc_index_set_option(self._h, name.encode(), float(value)))
+
+    def get_option(self, name: str) -> float:
+        v = ctypes.c_double(0.0)
+        _lib.check(_lib.lib().vsc_index_get_option(self._h, name.encode(), ctypes.byref(v)))
+        return v.value
+
+    def use_stream(self, hip_stream: Optional[int]):
+        """Run this handle's work on the caller's HIP stream (an integer hipStream_t, e.g.
+        `torch.cuda.current_stream().cuda_stream`; 0 = the default stream); None: back to the handle's own stream."""
+        if hip_stream is None:
+            _lib.check(_lib.lib().vsc_index_set_stream(self._h, None, 1))
+        else:
+            _lib.check(_lib.lib().vsc_index_set_stream(self._h, ctypes.c_void_p(int(hip_stream)), 0))
+        self._stream = None if hip_stream is None else int(hip_stream)
+
+    def use_torch_stream(self):
+        """Bind the handle to torch's current stream on its device: tensors torch produced on that stream are then
+        ordered before the library's reads without a device-wide synchronisation."""
+        import torch
+
+        self.use_stream(torch.cuda.current_stream(torch.device("cuda", self.device)).cuda_stream)
+
+    def _after_torch(self, dev=None):
+        """Make torch's queued work visible to the handle's stream: nothing to do when the handle runs ON torch's current
+        stream, a device synchronisation otherwise (the handle's own stream is non-blocking)."""
+        import torch
+
+        dev = torch.device("cuda", self.device) if dev is None else dev
+        if self._stream is not None and torch.cuda.current_stream(dev).cuda_stream == self._stream:
+            return
+        torch.cuda.synchronize(dev)
+
     def _rows(self, x):
         """fp32 C-contiguous [n, d] as (pointer, mem kind, n, keep-alive)."""
         if isinstance(x, np.ndarray) or not hasattr(x, "data_ptr"):
@@ -157,9 +195,8 @@ class FlatIndex:
 
             x = x.to(torch.float32).contiguous()
             if x.is_cuda:
-                # libvscmi runs on its own non-blocking stream: whatever torch kernel produced (or converted)
-                # these rows must have finished before the library reads them
-                torch.cuda.synchronize(x.device)
+                # whatever torch kernel produced (or converted) these rows must be ordered before the library's reads
+                self._after_torch(x.device)
         if x.ndim != 2 or x.shape[1] != self.d:
             raise ValueError(f"expected [n, {self.d}] features, got {tuple(x.shape)}")
         p, mem = _lib.ptr(x)
@@ -179,7 +216,7 @@ class FlatIndex:
             dev = torch.device("cuda", self.device)
             D = torch.empty((n, k), dtype=torch.float32, device=dev)
             I = torch.empty((n, k), dtype=torch.int64, device=dev)
-            torch.cuda.synchronize(dev)
+            self._after_torch(dev)
             _lib.check(_lib.lib().vsc_index_knn(self._h, p, n, mem, int(k), D.data_ptr(), I.data_ptr(),
                                                 _lib.MEM_DEVICE))
             return D, I
@@ -237,7 +274,7 @@ class FlatIndex:
             oi = torch.empty(cap, dtype=torch.int32, device=dev)
             oj = torch.empty(cap, dtype=torch.int32, device=dev)
             os_ = torch.empty(cap, dtype=torch.float32, device=dev)
-            torch.cuda.synchronize(dev)
+            self._after_torch(dev)
             call(oi.data_ptr(), oj.data_ptr(), os_.data_ptr(), _lib.MEM_DEVICE)
             m = n_out.value
             return oi[:m], oj[:m], os_[:m], radius.value
