@@ -138,11 +138,26 @@ def plant_copies(torch, dev, seed, q, n_qvid, qf, r, n_rvid, rf, frac=0.2, noise
 
 
 def host_cores() -> int:
-    """The host cores this process may use (the pod's quota): ONE figure for every CPU leg."""
+    """The host cores this process may really use -- the affinity mask cut by the cgroup CPU quota (a pod on a 256-core
+    host sees every core in its mask; a thread team that size on a 16-core quota spends its time being throttled):
+    ONE figure for every CPU leg."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     try:
-        return max(1, len(os.sched_getaffinity(0)))
-    except AttributeError:
-        return os.cpu_count() or 1
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            quota, period = f.read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(quota) // int(period)))
+    except (OSError, ValueError):
+        try:
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as f:
+                quota = int(f.read())
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f:
+                period = int(f.read())
+            if quota > 0 and period > 0:
+                n = min(n, max(1, quota // period))
+        except (OSError, ValueError):
+            pass
+    return max(1, n)
 
 
 def cpu_baseline(args, strong):
@@ -180,13 +195,19 @@ def cpu_baseline(args, strong):
     n_rv = max(1, args.ref_videos // 10)
     n_noise = max(1, (args.noise_rows or args.ref_videos * args.ref_frames) // 10)
     nr = n_rv * rf
-    # ~15 s whatever the core count: 2 * 25 * (nr + noise) * dim flop per query video at ~15 GFLOP/s per core
-    per_video = 2.0 * qf * (nr + (n_noise if strong else 0)) * dim
-    n_qv = int(min(4096, max(64, 15.0 * cores * 15e9 / per_video)))
-
     def unit(n):
         x = rng.standard_normal((n, dim)).astype(np.float32)
         return x / np.linalg.norm(x, axis=1, keepdims=True)
+
+    # ~15-20 s whatever the host: the sample is sized from the sgemm rate these cores deliver (a 0.2 s probe); thresholds,
+    # selection and sorting take the flow to ~3x its pure sgemm time
+    probe_a, probe_b = unit(1024), unit(8192)
+    (probe_a @ probe_b.T).sum()
+    t_probe = time.perf_counter()
+    (probe_a @ probe_b.T).sum()
+    rate = 2.0 * 1024 * 8192 * dim / max(time.perf_counter() - t_probe, 1e-6)
+    per_video = 2.0 * qf * (nr + (n_noise if strong else 0)) * dim
+    n_qv = int(min(8192, max(64, 9.0 * rate / per_video)))
 
     q, r = unit(n_qv * qf), unit(nr)
     for v in range(0, n_qv, 5):  # planted copies
@@ -295,7 +316,7 @@ def cpu_baseline_exact_port(args, strong):
     orc.set_num_threads(host_cores())  # the same cores as `cpu_baseline`
     rng = np.random.default_rng(args.seed)
     # ~10-15 s of CPU work whatever the core count (0.2 s per query video per core at this size)
-    n_qv, qf = max(48, 4 * orc.num_threads()), args.query_frames
+    n_qv, qf = max(48, min(256, 4 * orc.num_threads())), args.query_frames
     n_rv, rf = max(1, args.ref_videos // 10), args.ref_frames
     n_noise = max(1, (args.noise_rows or args.ref_videos * args.ref_frames) // 10)
     dim = args.dim

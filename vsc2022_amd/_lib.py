@@ -76,6 +76,15 @@ def build(force: bool = False) -> str:
     ):
         return LIB_PATH
     subprocess.check_call(["make", "-C", CSRC, "-j", str(os.cpu_count() or 4)])
+    if os.environ.get("VSC_SKIP_LINT") != "1":
+        # a fresh library is checked for the hazards the compiler cannot see inside the kernels' inline assembly
+        # (scripts/lint_isa.py: VALU-written SGPRs read by VMEM too early, registers of outstanding stream loads touched
+        # before their s_waitcnt -- what a different register allocation could silently introduce)
+        import sys
+
+        lint = os.path.join(os.path.dirname(_HERE), "scripts", "lint_isa.py")
+        if os.path.exists(lint):
+            subprocess.check_call([sys.executable, lint, LIB_PATH])
     return LIB_PATH
 
 

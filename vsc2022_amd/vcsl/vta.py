@@ -2,10 +2,10 @@
 tests/test_localization.py:17): `build_vta_model(model_type, **kwargs)` returning an object with
 `forward_sim([(name, sims), ...]) -> [(name, [[q_lo, r_lo, q_hi, r_hi], ...]), ...]`.
 
-Only the Temporal-Network aligner ("TN") is provided -- it is the only model the reference ever
-requests (sscd_baseline.py:121,131; dns_baseline.py:202).  The alignment itself runs on the GPU
-(libvscmi vsc_tn_forward_sim, one candidate pair per workgroup).  The third-party VCSL source is
-not part of the reference checkout; see DESIGN.md ("TN: parity unpinned").
+"TN" -- the only model the reference ever requests (sscd_baseline.py:121,131; dns_baseline.py:202) -- runs on the GPU
+(libvscmi vsc_tn_forward_sim, one candidate pair per workgroup).  "DTW" and "DP" (vsc2022_amd/vcsl/aligners.py) are host
+code over the similarity matrices, as VCSL's own are: the reference's route, off the hot path.  The third-party VCSL
+source is not part of the reference checkout; see DESIGN.md ("TN: parity unpinned" -- the same holds for DTW / DP).
 """
 import ctypes
 from typing import List, Optional, Sequence, Tuple
@@ -82,10 +82,14 @@ def build_vta_model(method="TN", concurrency: int = 1, **config):
         return method  # a ready-made aligner
     if method == "TN":
         return TN(concurrency=concurrency, **config)
+    if method in ("DTW", "DP") and method not in _REGISTRY:
+        from vsc2022_amd.vcsl import aligners
+
+        return getattr(aligners, method)(concurrency=concurrency, **config)
     if method in _REGISTRY:
         return _REGISTRY[method](concurrency=concurrency, **config)
     raise NotImplementedError(
-        f"alignment model {method!r}: only the Temporal Network ('TN') ships with this package (the only model the "
-        "reference requests; the VCSL source of DTW / DP / HV / SPD is not part of the reference checkout) -- "
-        "register another aligner with vsc2022_amd.vcsl.vta.register_vta_model"
+        f"alignment model {method!r}: 'TN' (GPU), 'DTW' and 'DP' (host) ship with this package; VCSL's 'HV' and 'SPD' (a "
+        "trained detector network) do not -- the VCSL source is not part of the reference checkout and the reference "
+        "never requests them; register another aligner with vsc2022_amd.vcsl.vta.register_vta_model"
     )
