@@ -650,6 +650,24 @@ int main(int argc, char** argv) {
                 run("V10 16x16x64 P256 8w  256x32  PF2 AW4 slice 32768", k16<256, 8, 1, 8, 1, 2, 0, 0, 4>, a, 256, 8, 256, 32768, R);
             }
     }
+    if (mode == 5) {
+        // round 5: the ceiling of a hand-written 256-accumulator kernel -- 256 x 64 wave tiles at one
+        // wave per SIMD with the block-max epilogue only once per work item (the K loop a hand-written kernel would have;
+        // its interleaved epilogue can only cost more than none) against V10 under the same exemption
+        a.thr = (int)(9.f * sig);
+        const int R = 4;
+        for (int rep = 0; rep < 2; ++rep) {
+            run("V10 16x16x64 P256 8w 256x32 PF2 AW4", k16<256, 8, 1, 8, 1, 2, 0, 0, 4>, a, 256, 8, 256, slice_cols, R);
+            run("V10 same, epilogue per item only", k16<256, 8, 1, 8, 1, 2, 1, 0, 4>, a, 256, 8, 256, slice_cols, R);
+            run("V10 without the panel reads (A operands stay in registers)", k16<256, 8, 1, 8, 1, 2, 0, 2, 4>, a, 256, 8, 256, slice_cols, R);
+            run("V10 without the panel reads, epilogue per item only", k16<256, 8, 1, 8, 1, 2, 1, 2, 4>, a, 256, 8, 256, slice_cols, R);
+            run("V10 without the reference stream", k16<256, 8, 1, 8, 1, 2, 0, 1, 4>, a, 256, 8, 256, slice_cols, R);
+            run("V11 16x16x64 P256 4w 256x64 PF2 AW4, epilogue per item only", k16<256, 4, 1, 8, 2, 2, 1, 0, 4>, a, 256, 4, 256, slice_cols, R);
+            run("V11 same, PF4", k16<256, 4, 1, 8, 2, 4, 1, 0, 4>, a, 256, 4, 256, slice_cols, R);
+            run("V11 same, PF2 AW8", k16<256, 4, 1, 8, 2, 2, 1, 0, 8>, a, 256, 4, 256, slice_cols, R);
+            run("V12 16x16x64 P128 4w 128x128 PF2 AW4, epilogue per item only", k16<128, 4, 1, 4, 4, 2, 1, 0, 4>, a, 128, 4, 512, slice_cols, R);
+        }
+    }
     if (mode == 3) {
         a.thr = (int)(9.f * sig);
         const int R = 4;
