@@ -98,6 +98,7 @@ int vsc_device_count(void);
  *   VSC_KNN_LEVELS=1          pre-filtered k-NN with one refinement level; VSC_KNN_SUBSET=<factor> (default 300),
  *   VSC_KNN_S0DIV=<n> (28), VSC_KNN_S0MIN=<rows> (1024), VSC_KNN_RATIO=<r> (by k), VSC_KNN_NCHUNK=<n>: sizes of its exact subset pass / levels
  *   VSC_DEBUG_I8 / VSC_DEBUG_SCREEN: notes on stderr when a search falls back from int8 / per screen launch
+ *   VSC_TOPK_SHORTCUT=0|1|2   proven top-K route of vsc_index_global_topk (see there); VSC_TOPK_SAMPLE=<rows> (4096)
  * Process-wide (first use): VSC_SIM_GRID (persistent grid of the exact similarity kernel), VSC_POISON_ALLOC=1
  * (fresh device buffers filled with 0xFF). */
 int vsc_index_create(int dim, int metric, int device, vsc_index_t** out);
@@ -146,7 +147,21 @@ int vsc_index_range_search(vsc_index_t* idx, const float* q, int64_t nq, int q_m
  * max_results=2K, min_results=K) followed by the stable sort + truncate to K.  Reproduces the
  * reference's batch schedule (32, 64, ... rows) and strict re-thresholding, ties included.
  * Output: <= K hits ordered by (score desc, row asc, ref asc) [L2: dist asc].
- * out_* capacity `cap` (>= K suffices).  *final_radius receives the last radius. */
+ * out_* capacity `cap` (>= K suffices).  *final_radius receives the last radius.
+ *
+ * Optional proven route (option "topk_shortcut" / VSC_TOPK_SHORTCUT: 0 = never [default], 1 = inner-product query sets of
+ * >= 65536 rows and >= 4e10 pairs, 2 = wherever it is defined [tests]).  What the reference returns is the first K of
+ * {s > tau_final} in sorted order, and tau_final -- the (K+1)-th best score of the row PREFIX its last re-threshold event
+ * saw -- cannot exceed s_(K+1), the (K+1)-th best score of the whole matrix; so whenever s_K > s_(K+1) the reference's
+ * result IS the exact top-K, whatever its batch schedule did on the way.  The route computes that top-K without the
+ * doubling batches (the schedule over a strided sample of <= "topk_sample" = 4096 rows seeds a radius just below the cut;
+ * all rows then run as steady 32768-row batches from it with the budget K + 1), checks s_K > s_(K+1) on the result and
+ * returns it only then; with a tie on the cut, a seed that turned out too high or an overflow it replays the schedule as
+ * above.  Results are bit-identical either way (tests/test_gpu_topk_proven.py).  Off by default because the proof cannot
+ * succeed at BASELINE's sizes: with 2e12 scores and K = 48 M about 70 pairs share every fp32 value at the cut (4.6e9 pairs
+ * per unit of score x 1.5e-8 per ulp), a tie on the cut is certain and the schedule's own final radius decides (DESIGN.md
+ * section 8).  On the proven route *final_radius is the steady run's last radius (every returned hit lies above it).
+ * get_option("last_topk_route"): 0 schedule, 1 proven, 2 tried + replayed. */
 int vsc_index_global_topk(vsc_index_t* idx, const float* q, int64_t nq, int q_mem, int64_t K,
                           int32_t* out_i, int32_t* out_j, float* out_s, int64_t cap, int out_mem,
                           int64_t* n_out, float* final_radius);

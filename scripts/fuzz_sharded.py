@@ -51,7 +51,7 @@ def dataset(case):
 def worker(rank, world, port, out_dir, case):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), LOCAL_RANK="0")
     if case["seed_rows"]:
-        os.environ["VSC_SHARD_SEED_ROWS"] = str(case["seed_rows"])
+        os.environ["VSC_SHARD_SPEC_START"] = str(case["seed_rows"])
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from vsc2022_amd import dist as vdist

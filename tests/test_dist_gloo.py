@@ -523,6 +523,136 @@ def test_query_sharded_hits_are_the_references_with_ties_on_the_cut(tmp_path, wo
             assert len(s) < K
 
 
+def _emulate_worker(rank, world, port, Ks, out_path, by_cols=False):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        sys.path[:0] = [ROOT, os.path.join(ROOT, "oracle")]
+        import oracle as orc
+        from vsc2022_amd import dist as vdist
+
+        q, r = _tie_data()
+        lo, hi = vdist.shard_ranges(len(q), world)[rank]
+        Q = q[lo:hi]
+        rng = np.random.default_rng(11 + rank)
+        res = {}
+        for K in Ks:
+            # lists prepared "beforehand" for the batches behind row 96, at floors that are sometimes too high (the
+            # emulation must then search the batch at the schedule's own radius), sometimes far too low
+            prepared, stats = {}, dict(used=0, redone=0, demand=0)
+            S_all = np.sort(orc.scores(Q, r).ravel())[::-1] if len(Q) else np.zeros(0, np.float32)
+            for r0, r1 in vdist.exponential_batches(len(q)):
+                a, b = max(r0, lo) - lo, min(r1, hi) - lo
+                if r0 < 96 or b <= a:
+                    continue
+                dens = min(1.0, float(rng.choice([0.6, 2.3, 6.0])) * K / (r0 * len(r)))
+                floor = float(S_all[min(len(S_all) - 1, int(dens * len(S_all)))])
+                lims, D, I = orc.range_search(Q[a:b], r, floor)
+                rows = np.repeat(np.arange(a, b), np.diff(lims.astype(np.int64))).astype(np.int32)
+                prepared[(a, b)] = (floor, torch.from_numpy(rows), torch.from_numpy(I.astype(np.int32)), torch.from_numpy(D))
+
+            c0, c1 = vdist.shard_ranges(len(r), world)[rank]
+
+            def search_rows(r0, r1, radius):
+                if by_cols and r0 < 96:
+                    # the head of the query set split by reference COLUMNS: every rank searches all of the batch's rows
+                    # against its slice (GLOBAL row numbers until the hand-over)
+                    lims, D, I = orc.range_search(q[r0:r1], r[c0:c1], radius)
+                    rows = np.repeat(np.arange(r0, r1), np.diff(lims.astype(np.int64))).astype(np.int32)
+                    return torch.from_numpy(rows), torch.from_numpy((I + c0).astype(np.int32)), torch.from_numpy(D)
+                a, b = max(r0, lo) - lo, min(r1, hi) - lo
+                if b <= a:
+                    return torch.zeros(0, dtype=torch.int32), torch.zeros(0, dtype=torch.int32), torch.zeros(0)
+                got = prepared.get((a, b))
+                if got is not None and got[0] <= radius:
+                    stats["used"] += 1
+                    m = got[3] > radius
+                    return got[1][m], got[2][m], got[3][m]
+                stats["redone" if got is not None else "demand"] += 1
+                lims, D, I = orc.range_search(Q[a:b], r, radius)
+                rows = np.repeat(np.arange(a, b), np.diff(lims.astype(np.int64))).astype(np.int32)
+                return torch.from_numpy(rows), torch.from_numpy(I.astype(np.int32)), torch.from_numpy(D)
+
+            def to_row_owners(i, j, sc):
+                allh = vdist.all_gather_varlen(torch.stack([i.to(torch.int64), j.to(torch.int64),
+                                                            sc.view(torch.int32).to(torch.int64)], dim=1))
+                allh = allh[(allh[:, 0] >= lo) & (allh[:, 0] < hi)]
+                return (allh[:, 0] - lo).to(torch.int32), allh[:, 1].to(torch.int32), allh[:, 2].to(torch.int32).view(torch.float32)
+
+            trace = []
+            head_end = min([a for a, _ in vdist.exponential_batches(len(q)) if a >= 96] + [len(q)])
+            radius, hi_, hj_, hs_ = vdist.emulate_schedule(search_rows, len(q), K, trace=trace,
+                                                           handover=(head_end, to_row_owners) if by_cols else None)
+            order = np.lexsort((hj_.numpy(), hi_.numpy(), -hs_.numpy().astype(np.float64)))
+            hs_sorted = hs_[torch.from_numpy(order)]
+            n_take, tau, info = vdist.distributed_prefix_select(hs_sorted, K, ties="rank", return_info=True)
+            keep = order[:n_take]
+            res[f"i{K}"], res[f"j{K}"], res[f"s{K}"] = hi_.numpy()[keep] + lo, hj_.numpy()[keep], hs_.numpy()[keep]
+            res[f"r{K}"] = np.array([radius, sum(1 for t in trace if t[4])], dtype=np.float64)
+            res[f"u{K}"] = np.array([stats["used"], stats["redone"], stats["demand"]])
+        np.savez(f"{out_path}.{rank}.npz", **res)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,by_cols", [(2, False), (3, False), (2, True), (3, True)])
+def test_emulated_schedule_over_query_shards_is_the_references(tmp_path, world, by_cols):
+    """dist.emulate_schedule (round 5: what DeviceMatcher.match runs over query shards): the reference's batch schedule
+    walked over lists the ranks hold -- prepared at floors below, or (deliberately) above, the schedule's radius -- must
+    end on the reference's final radius and leave exactly the reference's hits, for K with no tie on the cut, with a tie
+    the reference keeps and with a tie it drops.  by_cols: the batches at the head of the query set are searched under
+    another partition (all of their rows against the rank's slice of the reference COLUMNS) and handed to the row owners
+    before the first batch behind them, as engine.DeviceMatcher does with the doubling phase."""
+    sys.path[:0] = [ROOT, os.path.join(ROOT, "oracle")]
+    import oracle as orc
+
+    q, r = _tie_data()
+    cls = _tie_classes(q, r)
+    Ks = sorted(set(sum(cls.values(), [])))
+    out = str(tmp_path / "em")
+    mp.spawn(_emulate_worker, args=(world, 29300 + os.getpid() % 600, Ks, out, by_cols), nprocs=world, join=True)
+    parts = [np.load(f"{out}.{k}.npz") for k in range(world)]
+    used = redone = 0
+    for K in Ks:
+        i, j, s, info = orc.global_threshold_search(q, r, K, return_info=True)
+        gi = np.concatenate([p[f"i{K}"] for p in parts])
+        gj = np.concatenate([p[f"j{K}"] for p in parts])
+        gs = np.concatenate([p[f"s{K}"] for p in parts])
+        order = np.lexsort((gj, gi, -gs.astype(np.float64)))
+        assert np.array_equal(gi[order], i) and np.array_equal(gj[order], j), K
+        assert np.array_equal(gs[order].view(np.uint32), s.view(np.uint32)), K
+        for p in parts:
+            assert np.float32(p[f"r{K}"][0]) == np.float32(info["radius"]), (K, p[f"r{K}"], info)
+            assert int(p[f"r{K}"][1]) == info["n_rethreshold"], (K, p[f"r{K}"], info)
+        used += sum(int(p[f"u{K}"][0]) for p in parts)
+        redone += sum(int(p[f"u{K}"][1]) for p in parts)
+        if K in cls["dropped"]:
+            assert len(s) < K
+    assert used > 0 and redone > 0, (used, redone)   # both ways of answering a batch were exercised
+
+
+def test_kth_best_unsorted_single_process():
+    sys.path[:0] = [ROOT]
+    from vsc2022_amd.dist import kth_best_unsorted
+
+    rng = np.random.default_rng(8)
+    for trial in range(200):
+        n = int(rng.integers(0, 400))
+        x = rng.normal(size=n).astype(np.float32)
+        if trial % 2:
+            x = np.round(x * 2) / 2
+        if trial % 5 == 0 and n:
+            x[rng.integers(0, n, 3)] = [0.0, -0.0, np.float32(1e-42)]
+        k = n if trial % 7 == 3 and n else int(rng.integers(1, 420))
+        tau, total = kth_best_unsorted(torch.from_numpy(x), k)
+        assert total == n
+        if k > n:
+            assert tau == float("-inf")
+        else:
+            assert np.float32(tau) == np.sort(x)[::-1][k - 1], (trial, n, k)
+
+
 class _OracleIndexRS(_OracleIndex):
     def range_scores(self, x, radius, k_hint, device_out=False):
         import oracle as orc

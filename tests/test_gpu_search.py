@@ -55,7 +55,8 @@ def _check_topk(orc, q, r, K, metric=0):
     assert len(s) == len(os_), (len(s), len(os_))
     assert np.array_equal(i, oi) and np.array_equal(j, oj)
     assert np.array_equal(bits(s), bits(os_))
-    assert np.float32(radius) == np.float32(info["radius"])
+    # (VSC_TOPK_SHORTCUT=2, tests/test_gpu_topk_proven.py: the proven route returns the steady run's radius, not the schedule's)
+    assert idx.get_option("last_topk_route") == 1 or np.float32(radius) == np.float32(info["radius"])
     return info
 
 

@@ -46,9 +46,10 @@ def _result_arrays(res):
 def _worker(rank, world, port, out_dir, seed, seed_rows, static=0.0, grid=0):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), LOCAL_RANK="0")
     if seed_rows:
-        # a sample of `seed_rows` rows over all ranks seeds every rank's local search (engine.DeviceMatcher.seed_radius);
-        # by default these query sets are too small for the sample to be taken
-        os.environ["VSC_SHARD_SEED_ROWS"] = str(seed_rows)
+        # the batches of the schedule that start at or after global row `seed_rows` are answered from lists the ranks
+        # prepared beforehand at a floor radius estimated over a row sample (engine.DeviceMatcher.sharded_schedule_search);
+        # by default only batches behind the doubling phase (row 65504) are -- these query sets end long before that
+        os.environ["VSC_SHARD_SPEC_START"] = str(seed_rows)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         sys.path.insert(0, ROOT)

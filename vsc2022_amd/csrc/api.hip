@@ -130,6 +130,7 @@ static const OptionName kOptions[] = {
     {"knn_levels", "VSC_KNN_LEVELS"}, {"knn_subset", "VSC_KNN_SUBSET"}, {"knn_s0div", "VSC_KNN_S0DIV"},
     {"knn_s0min", "VSC_KNN_S0MIN"}, {"knn_ratio", "VSC_KNN_RATIO"}, {"knn_nchunk", "VSC_KNN_NCHUNK"},
     {"cand_budget", "VSC_CAND_BUDGET"}, {"debug_i8", "VSC_DEBUG_I8"}, {"debug_screen", "VSC_DEBUG_SCREEN"},
+    {"topk_shortcut", "VSC_TOPK_SHORTCUT"}, {"topk_sample", "VSC_TOPK_SAMPLE"},
 };
 
 // Options that decide which images of the reference rows are kept can only change while the index is empty.
@@ -195,6 +196,8 @@ static int apply_option(vsc_index* idx, const char* name, double v) {
     if (is("cand_budget")) { if (!(v >= 1048576.0)) goto bad; idx->cand_budget = (int64_t)v; return VSC_OK; }
     if (is("debug_i8")) { idx->debug_i8 = v != 0.0; return VSC_OK; }
     if (is("debug_screen")) { idx->debug_screen = v != 0.0; return VSC_OK; }
+    if (is("topk_shortcut")) { const int m = (int)v; if (m < 0 || m > 2) goto bad; idx->topk_shortcut = m; return VSC_OK; }
+    if (is("topk_sample")) { if (!(v >= 2.0)) goto bad; idx->topk_sample_rows = (int64_t)v; return VSC_OK; }
     set_error("vsc_index_set_option: unknown option '%s'", name);
     return VSC_ERR_INVALID;
 bad:
@@ -231,6 +234,9 @@ static int read_option(const vsc_index* idx, const char* name, double* out) {
     else if (is("cand_budget")) *out = (double)idx->cand_budget;
     else if (is("debug_i8")) *out = idx->debug_i8;
     else if (is("debug_screen")) *out = idx->debug_screen;
+    else if (is("topk_shortcut")) *out = idx->topk_shortcut;
+    else if (is("topk_sample")) *out = (double)idx->topk_sample_rows;
+    else if (is("last_topk_route")) *out = idx->last_topk_route;  // (read-only: what the last vsc_index_global_topk did)
     else {
         set_error("vsc_index_get_option: unknown option '%s'", name);
         return VSC_ERR_INVALID;

@@ -35,8 +35,11 @@ struct Workspace {
     DevBuf rt8c;            // the rows' largest |x| (second sort key of launches with per-row thresholds)
     DevBuf rt8, rt8b;       // ... and its row thresholds in position order (rows sorted by threshold inside a launch);
                             // rt8b: thresholds lowered by the excluded coordinates' contribution, in row order
+    DevBuf sample, sk[3], tk[3];  // proven top-K route (api_search.hip): the row sample, its sorted hits, the K + 1 best of the steady run
     void release() {
-        stage.release(); qbuf.release();
+        stage.release(); qbuf.release(); sample.release();
+        for (auto& b : sk) b.release();
+        for (auto& b : tk) b.release();
         qh.release(); qn.release(); ci.release(); cj.release(); segcnt.release(); rowthr.release(); slices.release();
         q8.release(); pstat.release(); rt8.release(); rt8b.release(); rt8c.release(); tailfill.release();
         for (auto& b : cs) b.release();
@@ -122,6 +125,14 @@ struct vsc_index {
     double knn_ratio = 0.0;      // VSC_KNN_RATIO (0: by k)
     int knn_nchunk = 0;          // VSC_KNN_NCHUNK: reference chunks of the exact k-NN kernel (0: by size)
     bool debug_i8 = false, debug_screen = false;  // VSC_DEBUG_I8 / VSC_DEBUG_SCREEN: stderr notes
+    // vsc_index_global_topk, optional route (api_search.hip: global_topk_proven): the exact top-K from a sampled seed radius
+    // + steady batches, returned only when it is PROVEN to be the reference schedule's result (no tie on the K cut), else
+    // the schedule is replayed.  OFF by default: at BASELINE's sizes a tie on the cut is certain (configs[3]: ~70 pairs per
+    // fp32 value at the cut), the proof never succeeds there.  VSC_TOPK_SHORTCUT: 0 (default) the schedule, 1 large query
+    // sets, 2 wherever the route is defined (tests)
+    int topk_shortcut = 0;
+    int64_t topk_sample_rows = 4096;  // VSC_TOPK_SAMPLE: rows of the strided sample that seeds the radius
+    int last_topk_route = 0;          // get_option("last_topk_route"): 0 schedule, 1 proven route, 2 proven route tried, schedule replayed
     bool prefilter = false, prefilter_force = false;
     double prefilter_density = 0.05;  // expected hit density below which a batch goes through the pre-filter (r03: 0.02 -> 0.05 with the cheaper exact stage: -0.8 %)
     unsigned long long stat_candidates = 0, stat_hits = 0;  // last search (vsc_index_profile_read)

@@ -18,20 +18,20 @@ buckets are needed.  Everything here works on torch tensors of any device, so th
 under gloo on CPU tensors in the tests (with the per-rank search results supplied by the oracle)
 and under RCCL on HBM tensors in production.
 
-Result contract: the reference's own result (vsc/index.py:142-165), proven per query set.  The
-reference returns the top K of {s > t} under (score desc, query row asc, ref row asc), t = the final
-radius of range_search_max_results = the (K+1)-th best score of the row PREFIX that ended at the last
-re-threshold event, hence t <= s_(K+1) <= s_K.  The sharded search computes the exact global top-K
-under the same total order; the two differ only if {s > t} holds fewer than K hits, i.e. only if
-t == s_K == s_(K+1):
+Result contract: the reference's own result (vsc/index.py:142-165), ties included.  The reference returns the top K of
+{s > t} under (score desc, query row asc, ref row asc), t = the final radius of range_search_max_results = the (K+1)-th
+best score of the row PREFIX that ended at the last re-threshold event, hence t <= s_(K+1) <= s_K: its result is the exact
+global top-K unless t == s_K == s_(K+1), when every hit tied with the cut is dropped.  Round 4 computed the exact top-K and
+round 5 first decided the tie case by replaying the schedule on one rank -- until the numbers said that the tie case is not
+a case but the rule: at BASELINE configs[3] (2e12 scores, K = 48 M) about 70 pairs share EVERY fp32 value near the cut, a tie
+on the cut is certain, and a replay on one rank costs what the whole single-GPU search costs.  So the query-sharded search
+now emulates the schedule itself (`emulate_schedule`): the schedule's state is a radius and a list of kept hits, its batches
+are global row ranges, and its decisions need only counts and order statistics of lists -- which the ranks can prepare
+IN PARALLEL by searching their rows at a radius that is certain (and checked) to lie below the schedule's.
 
-  * s_K > s_(K+1) (or the whole matrix holds <= K scores): identical, no further work -- the
-    selection below reports this from the tie counts it gathers anyway (`SelectInfo.tie_on_cut`);
-  * s_K == s_(K+1) (a tie sits on the cut; duplicate frames of static videos make this a few percent
-    of the query sets): the final radius of the reference's schedule is computed -- query shards:
-    rank 0 replays the schedule on the gathered query rows (engine.DeviceMatcher); reference shards:
-    `emulate_schedule_radius` runs the schedule's batches on all shards at once -- and the hits tied
-    with the cut are dropped iff t == s_K, exactly as the reference drops them.
+  * query shards (engine.DeviceMatcher.match): `emulate_schedule` over lists searched beforehand; exact t, exact {s > t};
+  * reference shards (refshard.py): the exact top-K over column shards + `emulate_schedule_radius` (every batch runs on
+    all shards at once) when a tie sits on the cut.
 """
 from dataclasses import dataclass
 from typing import Callable, List, Optional, Tuple
@@ -219,6 +219,28 @@ def all_gather_varlen(t: torch.Tensor, group=None) -> torch.Tensor:
     return torch.cat([o[:n] for o, n in zip(outs, lens)], dim=0).to(t.device)
 
 
+def send_to_owners(rows: torch.Tensor, dest: torch.Tensor, group=None) -> torch.Tensor:
+    """Every row of the 2-D int32 tensor `rows` to the rank dest[row] names; returns what this rank received (any order).
+    RCCL: one all-to-all of the counts and one of the rows (each row crosses one link once); gloo has no all-to-all --
+    the debugging set-up gathers everything everywhere and filters."""
+    rank, world = _world(group)
+    if world == 1:
+        return rows
+    if dist.get_backend(group) == "nccl":
+        order = torch.argsort(dest, stable=True)
+        rows = rows[order].contiguous()
+        counts = torch.bincount(dest, minlength=world)[:world].to(torch.int64)
+        got = torch.empty_like(counts)
+        dist.all_to_all_single(got, counts, group=group)
+        send, recv = counts.cpu().tolist(), got.cpu().tolist()
+        out = torch.empty((sum(recv),) + tuple(rows.shape[1:]), dtype=rows.dtype, device=rows.device)
+        dist.all_to_all_single(out, rows, output_split_sizes=recv, input_split_sizes=send, group=group)
+        return out
+    tagged = torch.cat([rows, dest.to(rows.dtype).unsqueeze(1)], dim=1)
+    allr = all_gather_varlen(tagged, group)
+    return allr[allr[:, -1] == rank][:, :-1].contiguous()
+
+
 class ShardedCandidates:
     """Globally ordered candidate table (every rank holds the same copy)."""
 
@@ -375,6 +397,103 @@ def emulate_schedule_radius(range_scores: Callable[[int, int, float], torch.Tens
             allk = allk[allk > radius]
             kept, n_kept = ([allk] if allk.numel() else []), int(allk.numel())
     return float(radius)
+
+
+def predict_schedule_density(n_rows: int, k_global: int, n_refs: int) -> List[Tuple[int, int, float]]:
+    """(r0, r1, hits per query row above the radius in effect while the batch [r0, r1) is searched) for every batch of the
+    reference's schedule, PREDICTED for a query set whose rows are alike: after an event at row boundary n the radius sits
+    where the rows before n hold K + 1 hits -- (K + 1) / n per row --, and the next event comes at the first boundary where
+    that density times the rows so far exceeds 2K.  Only a prediction (real rows differ, the events of a real run can fall
+    one batch earlier or later): `engine.DeviceMatcher.sharded_schedule_search` lists its rows' hits a margin below it and
+    `emulate_schedule` checks every list against the radius the schedule really has."""
+    out, d = [], float(n_refs)  # radius -1e10: every pair is a hit
+    for r0, r1 in exponential_batches(n_rows):
+        out.append((r0, r1, d))
+        # an event the count predicts by less than 3 % may not happen in the real run (65504 x 2^k rows + the tail of a
+        # batch: the steady boundaries sit 0.03 % behind the doubling of the last event): the prediction keeps the LOWER
+        # radius (the larger list) until the count is clear
+        if r1 * d > 2.06 * k_global:
+            d = min(float(n_refs), (k_global + 1) / r1)
+    return out
+
+
+def kth_best_unsorted(scores: torch.Tensor, k: int, group=None) -> Tuple[float, int]:
+    """(k-th best score, total count) over all ranks' UNSORTED fp32 score tensors (k is 1-based; -inf when fewer than k
+    scores exist): a local sort of the scores alone (the lists themselves stay as they are and are filtered once the
+    radius is known) + the exact distributed selection.  (A histogram of the unsorted keys was tried first: the scores of
+    a kept list share their upper 16 key bits with a few hundred others, `bincount` serialises on those bins -- 0.4 s per
+    event on 1e8 scores against 25 ms for the sort.)"""
+    srt = torch.sort(scores, descending=True).values if scores.numel() else scores
+    _, tau, info = distributed_prefix_select(srt, int(k), group, return_info=True)
+    if info.total == k:  # (the selection answers -inf for "the whole union": the k-th best is then the smallest score)
+        t = torch.tensor([-float(srt[-1]) if srt.numel() else float("-inf")], dtype=torch.float64, device=scores.device)
+        rank, world = _world(group)
+        if world > 1:
+            h = t.cpu() if _via_host(t, group) else t
+            dist.all_reduce(h, op=dist.ReduceOp.MAX, group=group)
+            t = h
+        return -float(t.item()), int(info.total)
+    return (float("-inf") if info.total < k else float(tau)), int(info.total)
+
+
+def emulate_schedule(search_rows: Callable[[int, int, float], Tuple[torch.Tensor, torch.Tensor, torch.Tensor]], n_rows: int,
+                     k_global: int, group=None, device=None, trace: Optional[list] = None,
+                     handover: Optional[Tuple[int, Callable]] = None):
+    """range_search_max_results(max_results=2K, min_results=K) over the reference's batch schedule (vsc/index.py:147-154,
+    inner product), run over QUERY SHARDS: returns (final radius t, i, j, s) -- this rank's part of {s > t}, the set the
+    reference sorts and cuts at K.  Exact, ties included: nothing is decided by a proof about the cut.
+
+    search_rows(r0, r1, radius) -> (i, j, s): EVERY pair of this rank's rows inside the global row range [r0, r1) with
+    score > radius (STRICT); empty tensors for a batch the rank owns no row of.  Where the lists come from is the
+    caller's business: engine.DeviceMatcher answers the steady 32768-row batches from lists it searched BEFOREHAND at a
+    radius that lies below the schedule's (all ranks at once -- the emulation itself then only filters lists) and
+    searches a batch on demand when the schedule's radius turns out lower, or when the batch belongs to the doubling
+    phase.  Every rank walks the same batches: one all-reduce of the kept count per batch; at every event (more than 2K
+    kept) the (K+1)-th best kept score over all ranks (`kth_best_unsorted`) becomes the radius and everything at or below
+    it goes.  trace (optional list): (r0, r1, radius before the batch, kept after it, event) per batch, for the tests.
+
+    handover = (row, fn): how the kept hits are spread over the ranks does not matter to the schedule (counts and order
+    statistics are sums over ranks), so the batches before `row` may be searched under ANOTHER partition -- the engine
+    splits the doubling batches at the head of the query set by reference COLUMNS, every rank searching all of their rows
+    against its slice --; before the first batch that starts at or after `row`, fn(i, j, s) -> (i, j, s) hands every kept
+    hit to the rank that owns its query row (i: whatever search_rows returned for those batches in, local rows out)."""
+    radius = -1e10
+    kept_i: List[torch.Tensor] = []
+    kept_j: List[torch.Tensor] = []
+    kept_s: List[torch.Tensor] = []
+    n_kept = 0
+    dev = device
+    def cat(parts, dtype):
+        return torch.cat(parts) if parts else torch.zeros(0, dtype=dtype, device=dev if dev is not None else "cpu")
+
+    for r0, r1 in exponential_batches(n_rows):
+        if handover is not None and r0 >= handover[0]:
+            i, j, s = handover[1](cat(kept_i, torch.int32), cat(kept_j, torch.int32), cat(kept_s, torch.float32))
+            kept_i, kept_j, kept_s = ([i], [j], [s]) if s.numel() else ([], [], [])
+            n_kept = int(s.numel())
+            handover = None
+        i, j, s = search_rows(r0, r1, radius)
+        if dev is None:
+            dev = s.device
+        if s.numel():
+            kept_i.append(i); kept_j.append(j); kept_s.append(s)
+            n_kept += int(s.numel())
+        total = all_reduce_sum_int(n_kept, dev, group)
+        event = total > 2 * k_global
+        if event:
+            alls = torch.cat(kept_s) if kept_s else torch.zeros(0, dtype=torch.float32, device=dev)
+            tau, _ = kth_best_unsorted(alls, k_global + 1, group)
+            radius = float(tau)
+            if kept_s:
+                m = alls > radius
+                kept_i, kept_j, kept_s = [torch.cat(kept_i)[m]], [torch.cat(kept_j)[m]], [alls[m]]
+                n_kept = int(kept_s[0].numel())
+        if trace is not None:
+            trace.append((r0, r1, radius, total, event))
+    if handover is not None:  # (the whole query set lies before `row`)
+        i, j, s = handover[1](cat(kept_i, torch.int32), cat(kept_j, torch.int32), cat(kept_s, torch.float32))
+        kept_i, kept_j, kept_s = [i], [j], [s]
+    return float(radius), cat(kept_i, torch.int32), cat(kept_j, torch.int32), cat(kept_s, torch.float32)
 
 
 def merge_candidates(q_vid: torch.Tensor, r_vid: torch.Tensor, score: torch.Tensor, first_i: torch.Tensor,

@@ -41,10 +41,9 @@ class MatchResult:
     boxes: torch.Tensor       # [n_localized_here, 16, 4] int32
     box_score: torch.Tensor   # [n_localized_here, 16] fp32 (MaxSim - bias)
     radius: float
-    # Sharded runs (vsc2022_amd/dist.py, module docstring): the exact global top-K IS the reference's result unless a tie
-    # sits on the K cut; then the reference's final radius decides whether the tied hits are dropped.
-    matches_reference: bool = True   # proven identical to vsc/index.py:142-165 on this query set (False only when a tie
-    #                                  sits on the cut and VSC_SHARD_TIE_RESOLVE=0 switched the resolution off)
+    # Sharded runs (vsc2022_amd/dist.py, module docstring) emulate the reference's schedule itself: the result is the
+    # reference's by construction, `radius` the schedule's final radius.
+    matches_reference: bool = True
     tie_on_cut: bool = False         # s_K == s_(K+1) over the whole score matrix
     ties_dropped: bool = False       # ... and the reference's schedule ends on that very score: hits tied with it dropped
 
@@ -224,60 +223,46 @@ class DeviceMatcher:
             self._tn = None
 
     # ---- stages (all tensors stay in HBM)
-    def search(self, K: int, seed_radius: Optional[float] = None, rows: Optional[torch.Tensor] = None):
+    def search(self, K: int, seed_radius: Optional[float] = None, rows: Optional[torch.Tensor] = None,
+               schedule: bool = False, index: Optional[FlatIndex] = None):
         """vsc/index.py:142-165 over the resident queries: (i, j, s) sorted hits + final radius.
 
-        seed_radius: a radius known to lie below the K-th best score (sharded pipeline): the rows run as steady
-        batches from there (`vsc_index_global_topk_seeded`) instead of replaying the doubling schedule.
-        rows: search these query rows instead (an [n, dim] tensor in HBM; row numbers are relative to it)."""
+        seed_radius: the rows run as steady batches from this radius (`vsc_index_global_topk_seeded`) instead of
+        replaying the doubling schedule: every hit beyond it, cut at K (the sharded pipeline's row lists).
+        rows: search these query rows instead (an [n, dim] tensor in HBM; row numbers are relative to it).
+        schedule: replay the reference's batch schedule even where the library would take its proven top-K route
+        (include/vscmi.h, "topk_shortcut"): the returned radius is then the SCHEDULE's final radius."""
+        index = self.index if index is None else index
+        if schedule and seed_radius is None and index.get_option("topk_shortcut") != 0:
+            keep = index.get_option("topk_shortcut")
+            index.set_option("topk_shortcut", 0)
+            try:
+                return self.search(K, None, rows, index=index)
+            finally:
+                index.set_option("topk_shortcut", keep)
         q = self.q_feats if rows is None else rows.to(self.tdev, torch.float32).contiguous()
         nq = int(q.shape[0])
-        cap = int(max(1, min(K, nq * max(self.index.ntotal, 1))))
+        cap = int(max(1, min(K, nq * max(index.ntotal, 1))))
         tag = "hit" if rows is None else "seed_hit"
         oi = self._buf(tag + "_i", cap, torch.int32)
         oj = self._buf(tag + "_j", cap, torch.int32)
         os_ = self._buf(tag + "_s", cap, torch.float32)
         n_out, radius = ctypes.c_int64(0), ctypes.c_float(0.0)
         self._order()
+        if index is not self.index and self.torch_stream:
+            index.use_stream(torch.cuda.current_stream(self.tdev).cuda_stream)
         if seed_radius is None:
             _lib.check(_lib.lib().vsc_index_global_topk(
-                self.index.handle, _dev_ptr(q), nq, _lib.MEM_DEVICE, int(K),
+                index.handle, _dev_ptr(q), nq, _lib.MEM_DEVICE, int(K),
                 _dev_ptr(oi), _dev_ptr(oj), _dev_ptr(os_), cap, _lib.MEM_DEVICE, ctypes.byref(n_out),
                 ctypes.byref(radius)))
         else:
             _lib.check(_lib.lib().vsc_index_global_topk_seeded(
-                self.index.handle, _dev_ptr(q), nq, _lib.MEM_DEVICE, int(K), float(seed_radius),
+                index.handle, _dev_ptr(q), nq, _lib.MEM_DEVICE, int(K), float(seed_radius),
                 _dev_ptr(oi), _dev_ptr(oj), _dev_ptr(os_), cap, _lib.MEM_DEVICE, ctypes.byref(n_out),
                 ctypes.byref(radius)))
         m = n_out.value
         return oi[:m], oj[:m], os_[:m], radius.value
-
-    def seed_radius(self, K: int, group=None) -> Optional[float]:
-        """A radius just below the K-th best score of the GLOBAL score matrix, estimated over a strided sample of every
-        rank's query rows (same stride everywhere): each rank searches its sample with the reference's schedule, the
-        1.25 * K * (sample share)-th best score over all ranks' sample hits is found with the exact distributed
-        selection (two histogram all-reduces + one all-gather of tie counts).  None when the query set is too small for
-        a sample to pay (then the ranks replay the schedule as before).  An estimate, never trusted: the caller checks
-        the seeded result with the same exactness test as any other local search and falls back when it fails."""
-        nq_loc = int(self.q_feats.shape[0])
-        tot_rows = vdist.all_reduce_sum_int(nq_loc, self.tdev, group)
-        target = int(os.environ.get("VSC_SHARD_SEED_ROWS", "4096"))  # sample rows over all ranks
-        stride = tot_rows // max(target, 1)
-        if stride < 4 or self.index.ntotal == 0:
-            return None
-        pick = torch.arange(0, nq_loc, stride, device=self.tdev)
-        s_loc = int(pick.numel())
-        s_tot = vdist.all_reduce_sum_int(s_loc, self.tdev, group)
-        k_tot = int(np.ceil(1.25 * K * s_tot / tot_rows))
-        if s_loc:
-            k_s = int(min(s_loc * self.index.ntotal, np.ceil(2.0 * K * s_loc / tot_rows) + 1024))
-            _, _, sc, _ = self.search(k_s, rows=self.q_feats.index_select(0, pick))
-        else:
-            sc = torch.zeros(0, dtype=torch.float32, device=self.tdev)
-        _, tau = vdist.distributed_prefix_select(sc, k_tot, group)
-        if not np.isfinite(tau):
-            return None
-        return float(np.nextafter(np.float32(tau), np.float32(-np.inf)))
 
     def pair_max(self, hi, hj, hs):
         """vsc/index.py:121-140 + vsc/candidates.py:24-40 on device hits."""
@@ -338,44 +323,13 @@ class DeviceMatcher:
             return MatchResult(int(hs.numel()), int(ps.numel()), n_cand, n_loc, int(nbox.sum().item()),
                                pq[:n_cand], pr[:n_cand], ps[:n_cand],
                                torch.arange(n_loc, device=self.tdev), nbox, boxes, bmax, radius)
-        radius_box = [float("nan")]
-        # The sharded search computes the exact global top-K (vsc2022_amd/dist.py) -- which is the reference's result
-        # unless a tie sits on the K cut (resolved below) --, so a rank need not replay the 32, 64, ... doubling batches on
-        # its own rows: a radius agreed over a row sample seeds every rank's FIRST local search; a retry (seed too high,
-        # skewed shard) takes the unseeded search.  Budgets go up to K + 1: the selection must see whether the (K+1)-th
-        # best ties with the K-th.
-        seed = [self.seed_radius(K, group) if os.environ.get("VSC_SHARD_SEED", "1") != "0" else None]
-
-        def local_search(k_local):
-            if seed[0] is not None:
-                try:
-                    i, j, sc, rad = self.search(K + 1, seed_radius=seed[0])  # (full budget: see dist.sharded_hits)
-                except _lib.VscError as e:
-                    # a seed far too low (unrepresentative sample) can overflow the kept-hit buffer: the unseeded
-                    # schedule bounds its own buffers
-                    if e.code not in (_lib.VSC_ERR_OVERFLOW, _lib.VSC_ERR_CAPACITY, _lib.VSC_ERR_NOMEM):
-                        raise
-                    seed[0] = None
-                    i, j, sc, rad = self.search(k_local)
-                    radius_box[0] = rad
-                    return i, j, sc, rad
-                seed[0] = None
-                radius_box[0] = rad
-                return i, j, sc, rad, True
-            i, j, sc, rad = self.search(k_local)
-            radius_box[0] = rad
-            return i, j, sc, rad
-
-        hi, hj, hs, tau, info = vdist.sharded_hits(local_search, int(self.q_feats.shape[0]) * self.index.ntotal, K,
-                                                   group, self.tdev, return_info=True)
-        # s_K == s_(K+1): the reference drops every hit tied with the cut iff its schedule's final radius is that score
-        # (dist.py module docstring).  Rare (duplicate frames of static videos put a few percent of the query sets here)
-        # and decided exactly: rank 0 replays the reference's schedule on the gathered query rows.
-        keep, proven, dropped = vdist.resolve_tie_on_cut(hs, tau, info, lambda: self.reference_radius(K, group),
-                                                         os.environ.get("VSC_SHARD_TIE_RESOLVE", "1") != "0")
-        if dropped:
-            hi, hj, hs = hi[keep], hj[keep], hs[keep]
-        radius = radius_box[0]
+        # The reference's schedule itself, over query shards (vsc2022_amd/dist.py, module docstring + emulate_schedule): a
+        # proof about the K cut cannot replace it -- at BASELINE's sizes a tie on the cut is certain.
+        hi, hj, hs, radius, info = self.sharded_schedule_search(K, nq_glob_rows=None, row_base=row_base, group=group)
+        # (a list shorter than K although the matrix holds more: the schedule ended ON the K-th best score and dropped
+        # everything tied with it, as the reference does)
+        dropped = info.total < min(K, self.last_shard_stats["n_rows"] * self.index.ntotal)
+        proven, tie = True, bool(info.tie_on_cut or dropped)
         n_take = int(hs.numel())
         pq, pr, ps, pf = self.pair_max(hi, hj, hs)
         first_i = hi[pf].to(torch.int64) + row_base if pf.numel() else pf
@@ -390,21 +344,163 @@ class DeviceMatcher:
         n_hits = vdist.all_reduce_sum_int(n_take, self.tdev, group)
         return MatchResult(n_hits, int(ps.numel()), n_cand, n_loc, n_matches,
                            cands.q_vid, cands.r_vid, cands.score, loc_index, nbox, boxes, bmax, radius,
-                           matches_reference=proven, tie_on_cut=info.tie_on_cut, ties_dropped=dropped)
+                           matches_reference=proven, tie_on_cut=tie, ties_dropped=dropped)
 
-    def reference_radius(self, K: int, group=None) -> float:
-        """The final radius of the reference's schedule (vsc/index.py:147-154) over ALL ranks' query rows: the query
-        rows are gathered (rank order = query order) and rank 0 runs the single-GPU search on them -- the code whose
-        parity with the oracle the single-process suites pin --, then tells everybody.  Only the sharded pipeline's
-        tie-on-the-cut case calls this."""
-        allq = vdist.all_gather_varlen(self.q_feats, group)
+    # ---- the query-sharded search
+    def _rows_above(self, rows: torch.Tensor, radius: float, budget: int, index: Optional[FlatIndex] = None):
+        """EVERY pair of the query rows `rows` with score > radius (strict): (i relative to rows, j, s), sorted by (score
+        desc, row asc, ref asc).  Steady batches from `radius` (`vsc_index_global_topk_seeded`: pre-filters + exact stage)
+        with a budget the list must stay below -- a full list may be a truncated one: the budget doubles and the rows run
+        again.  index: another index than the matcher's (the rank's column slice of the references)."""
+        idx = self.index if index is None else index
+        cap_all = int(rows.shape[0]) * max(idx.ntotal, 1)
+        budget = max(1024, min(int(budget), cap_all))
+        while True:
+            i, j, s, rad = self.search(budget, seed_radius=float(radius), rows=rows, index=idx)
+            if int(s.numel()) < budget or budget >= cap_all:
+                break
+            budget = min(cap_all, budget * 2)
+        return i.clone(), j.clone(), s.clone()
+
+    def sharded_schedule_search(self, K: int, nq_glob_rows: Optional[int], row_base: int, group=None):
+        """vsc/index.py:142-165 over query shards: this rank's share of the reference's K hits (sorted; rows LOCAL), the
+        schedule's final radius and the selection's report.  Identical to what one process returns for the whole query
+        set, ties included.
+
+        The schedule (range_search_max_results over exponential_query_iterator) is a radius, a list of kept hits and
+        global row batches; every decision it takes is a count or an order statistic of that list.  So:
+          1. in parallel, every rank lists the hits of its rows of each steady 32768-row batch above a FLOOR that should lie
+             below the radius the schedule will have there: `dist.predict_schedule_density` says how many hits per row that
+             radius leaves if all rows are alike, the floor is the score below which a quarter more pairs of an m-row sample
+             of the rank's rows lie (1.25 x; at most 2.3 K m / n: the radius at row n never falls below the (2K+1)-th best score of
+             the rows before n) -- int8 batches + exact stage, what the single-process search spends on the same rows;
+          2. `dist.emulate_schedule` walks the batches: a batch's hits come out of the prepared list (filtered at the
+             schedule's radius) -- or, where the floor turns out too high and for the doubling batches 32 ... 32768 at the head
+             of the query set, from a search at exactly that radius by the rank that owns the rows;
+          3. the exact distributed selection cuts {s > final radius} at K.
+        VSC_SHARD_SPEC_START=<row> (default 65504, the end of the doubling phase): batches from there on are prepared."""
+        dev = self.tdev
+        nq_loc = int(self.q_feats.shape[0])
+        nr = self.index.ntotal
+        n_rows = vdist.all_reduce_sum_int(nq_loc, dev, group) if nq_glob_rows is None else int(nq_glob_rows)
+        spec_start = max(32, int(os.environ.get("VSC_SHARD_SPEC_START", "65504")))
+        spec_factor = float(os.environ.get("VSC_SHARD_SPEC_FACTOR", "1.25"))
+        stats = dict(n_rows=n_rows, prepared=0, prepared_hits=0, on_demand=0, floor_too_high=0)
+        debug = os.environ.get("VSC_SHARD_DEBUG") == "1"
+        import sys
+        import time as _time
+
+        def clock():
+            if debug:
+                torch.cuda.synchronize()
+            return _time.perf_counter()
+
+        t_start = clock()
+
+        def local(r0, r1):
+            return max(r0, row_base) - row_base, min(r1, row_base + nq_loc) - row_base
+
+        # (batch start, local rows, predicted hits per row above the schedule's radius there)
+        pieces = [(r0,) + local(r0, r1) + (d,) for r0, r1, d in vdist.predict_schedule_density(n_rows, K, nr) if r0 >= spec_start]
+        pieces = [(r0, a, b, d) for r0, a, b, d in pieces if a < b]
+        lists = {}
+        m = min(int(os.environ.get("VSC_SHARD_SAMPLE", "4096")), nq_loc // 4)
+        if pieces and m >= 16 and nr > 0:
+            stride = nq_loc // m
+            sample = self.q_feats[::stride][:m]
+            m = int(sample.shape[0])
+            # the floor of a batch: the score below which `spec_factor` x the predicted hits of the sample's rows lie, never
+            # more than 2.3 K m / r0 of them (the radius at row r0 is never below the (2K+1)-th best of the rows before it)
+            need = [int(np.ceil(min(spec_factor * d, 2.3 * K / r0) * m)) for r0, _, _, d in pieces]
+            k_s = int(min(m * nr, max(need) + max(need) // 16 + 1024))
+            _, _, ss, _ = self.search(k_s, rows=sample, schedule=True)
+            ss = ss.clone()
+            stats["t_sample"] = clock() - t_start
+            for (r0, a, b, _), c in zip(pieces, need):
+                if c > int(ss.numel()):
+                    continue  # (the sample does not reach that deep: the batch is searched when the schedule gets there)
+                floor = float(np.nextafter(np.float32(ss[c - 1].item()), np.float32(-np.inf)))
+                i, j, sc = self._rows_above(self.q_feats[a:b], floor, int(1.3 * (b - a) * c / m) + (1 << 16))
+                lists[(a, b)] = (floor, i + a, j, sc)
+                stats["prepared"] += 1
+                stats["prepared_hits"] += int(sc.numel())
+        empty = (torch.zeros(0, dtype=torch.int32, device=dev), torch.zeros(0, dtype=torch.int32, device=dev),
+                 torch.zeros(0, dtype=torch.float32, device=dev))
+
+        # The head of the query set (the doubling batches: every one of them hands ~K hits to the exact stage whatever its
+        # size, none of it shrinks with the number of ranks if the rank that owns the rows searches them alone) is split by
+        # reference COLUMNS instead: every rank gets the head's rows and searches them against its slice of the references.
         rank, world = vdist._world(group)
-        rad = 0.0
-        if rank == 0:
-            _, _, _, rad = self.search(K, rows=allq)
-        t = torch.tensor([float(rad) if rank == 0 else 0.0], dtype=torch.float64, device=self.tdev)
-        vdist._all_reduce_sum(t, group)
-        return float(t.item())
+        head_end = min([r0 for r0, _ in vdist.exponential_batches(n_rows) if r0 >= spec_start] + [n_rows])
+        by_cols = world > 1 and head_end > 0 and nr >= 64 * world and os.environ.get("VSC_SHARD_HEAD_COLS", "1") != "0"
+        if by_cols:
+            ha, hb = local(0, head_end)
+            head_q = vdist.all_gather_varlen(self.q_feats[ha:max(ha, hb)], group)   # rank order = row order
+            c0, c1 = [(x // 64) * 64 for x in vdist.shard_ranges(nr, world)[rank]]
+            if rank == world - 1:
+                c1 = nr
+            col_index = getattr(self, "_col_index", None)
+            if col_index is None or self._col_range != (c0, c1):
+                col_index = FlatIndex(self.dim, _lib.METRIC_INNER_PRODUCT, self.device)
+                if self.torch_stream:
+                    col_index.use_torch_stream()
+                col_index.add(self.ref_feats[c0:c1])
+                self._col_index, self._col_range = col_index, (c0, c1)
+
+        def head_budget(r0, n_here, share):
+            return int(min(2.5 * K, 4.0 * K * n_here / max(r0, n_here)) * share) + (1 << 20)
+
+        def search_rows(r0, r1, radius):
+            if by_cols and r0 < head_end:
+                t0 = clock()
+                i, j, sc = self._rows_above(head_q[r0:r1], radius, head_budget(r0, r1 - r0, 1.3 / world), index=col_index)
+                stats["on_demand"] += 1
+                stats["t_on_demand"] = stats.get("t_on_demand", 0.0) + clock() - t0
+                return i + r0, j + c0, sc          # GLOBAL rows until the hand-over
+            a, b = local(r0, r1)
+            if a >= b:
+                return empty
+            got = lists.get((a, b))
+            if got is not None and got[0] <= radius:
+                n = int((got[3] > radius).sum().item())   # (sorted by score: a prefix)
+                return got[1][:n], got[2][:n], got[3][:n]
+            stats["floor_too_high" if got is not None else "on_demand"] += 1
+            if debug and got is not None:
+                print(f"[shard {row_base}] batch at row {r0}: floor {got[0]:.6f} > radius {radius:.6f} ({int(got[3].numel())} listed)",
+                      file=sys.stderr, flush=True)
+            t0 = clock()
+            i, j, sc = self._rows_above(self.q_feats[a:b], radius, head_budget(r0, b - a, 1.0))
+            stats["t_on_demand"] = stats.get("t_on_demand", 0.0) + clock() - t0
+            return i + a, j, sc
+
+        def to_row_owners(i, j, sc):
+            """the kept hits of the column-split head -> the ranks that own their query rows (local row numbers)"""
+            t0 = clock()
+            bases = torch.tensor(vdist._all_gather_scalar(row_base, dev, group), dtype=torch.int64, device=dev)
+            owner = torch.searchsorted(bases, i.to(torch.int64), right=True) - 1
+            got = vdist.send_to_owners(torch.stack([i, j, sc.view(torch.int32)], dim=1), owner, group)
+            stats["t_handover"] = clock() - t0
+            return got[:, 0] - row_base, got[:, 1].contiguous(), got[:, 2].contiguous().view(torch.float32)
+
+        stats["t_prepare"] = clock() - t_start
+        t0 = clock()
+        radius, hi, hj, hs = vdist.emulate_schedule(search_rows, n_rows, K, group, dev,
+                                                    handover=(head_end, to_row_owners) if by_cols else None)
+        stats["t_emulate"] = clock() - t0
+        t0 = clock()
+        # (score desc, row asc, ref asc): the order the reference's stable sort leaves, then the global cut at K
+        if hs.numel():
+            o1 = torch.sort(hi.to(torch.int64) * max(nr, 1) + hj.to(torch.int64), stable=True).indices
+            o2 = torch.sort(hs[o1], descending=True, stable=True).indices
+            order = o1[o2]
+            hi, hj, hs = hi[order], hj[order], hs[order]
+        n_take, tau, info = vdist.distributed_prefix_select(hs, K, group, ties="rank", return_info=True)
+        stats["t_final"] = clock() - t0
+        self.last_shard_stats = stats
+        if debug:
+            print(f"[shard {row_base}] " + " ".join(f"{k}={v:.3f}" if isinstance(v, float) else f"{k}={v}" for k, v in stats.items()),
+                  file=sys.stderr, flush=True)
+        return hi[:n_take], hj[:n_take], hs[:n_take], radius, info
 
     def gather_boxes(self, res: MatchResult, group=None) -> torch.Tensor:
         """Every rank's localisation results in one table (the hand-over of vsc/baseline/sscd_baseline.py:139-152 when

@@ -144,8 +144,6 @@ def match_sharded(queries: List[VideoFeature], refs: List[VideoFeature], score_n
     m.set_queries(q_rows, q_off, tn_q_feats=tn_q)
     res = m.match(n_qvid_global=len(queries), qvid_base=lo, row_base=row_base, bias=bias if score_normalization else 0.0,
                   localize=localize)
-    if not res.matches_reference:
-        raise RuntimeError("sharded search: a tie sits on the K cut and its resolution was switched off (VSC_SHARD_TIE_RESOLVE=0)")
     cq, cr = res.cand_q.cpu().numpy(), res.cand_r.cpu().numpy()
     cs = res.cand_score.cpu().numpy()
     pairs = CandidateList(cq.astype(np.int32), cr.astype(np.int32), cs, q_layout_all.video_ids, r_layout.video_ids)
