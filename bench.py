@@ -785,6 +785,15 @@ def main():
             },
             "kernels": kernels,
         }
+        if world > 1:
+            # what the sharded search did in the last step on rank 0 (engine.DeviceMatcher.sharded_schedule_search): batches
+            # searched, and -- with VSC_SHARD_DEBUG=1, which synchronises around every phase -- the seconds per phase.  In the
+            # share-GPU debugging set-up t_gather / t_handover are host-staged gloo transfers and the GPU phases are the work
+            # of ALL ranks interleaved on one device
+            st = getattr(matcher, "last_shard_stats", None)
+            if st:
+                out["sharded_search"] = dict(mode=os.environ.get("VSC_SHARD_MODE", "cols"), share_gpu=share_gpu,
+                                             **{k: (round(v, 4) if isinstance(v, float) else v) for k, v in st.items()})
         if world == 1:
             # the untimed legs must never cost the headline line: a failure in one of them is reported, not raised
             if not args.no_extra:

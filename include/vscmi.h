@@ -99,6 +99,10 @@ int vsc_device_count(void);
  *   VSC_KNN_S0DIV=<n> (28), VSC_KNN_S0MIN=<rows> (1024), VSC_KNN_RATIO=<r> (by k), VSC_KNN_NCHUNK=<n>: sizes of its exact subset pass / levels
  *   VSC_DEBUG_I8 / VSC_DEBUG_SCREEN: notes on stderr when a search falls back from int8 / per screen launch
  *   VSC_TOPK_SHORTCUT=0|1|2   proven top-K route of vsc_index_global_topk (see there); VSC_TOPK_SAMPLE=<rows> (4096)
+ *   VSC_SORT_HITS=0           vsc_index_global_topk / _seeded (inner product) return their hits as a SET, in the kept
+ *                             list's order, instead of (score desc, row asc, ref asc): the column-sharded schedule joins
+ *                             a batch's hits to a list that is sorted once at the end.  min(n, K) entries come back; K
+ *                             of them may be a truncated list
  * Process-wide (first use): VSC_SIM_GRID (persistent grid of the exact similarity kernel), VSC_POISON_ALLOC=1
  * (fresh device buffers filled with 0xFF). */
 int vsc_index_create(int dim, int metric, int device, vsc_index_t** out);

@@ -36,12 +36,23 @@ __device__ inline uint32_t hash32(uint32_t x) {
     return x;
 }
 // bytes ~ round(N(0, 40^2)) clipped to int8 (the toggling statistics of quantised descriptors)
-__global__ void gen_bytes(int8_t* x, int64_t n, uint32_t seed) {
+__global__ void gen_bytes(int8_t* x, int64_t n, uint32_t seed, int dist) {
+    // dist (round 5, data-dependent power): 0 Gaussian sigma 40 (what the product's quantised unit rows look like),
+    // 1 zeros, 2 Gaussian sigma 10, 3 |Gaussian sigma 40| (no sign bits), 4 Gaussian sigma 20 + 64 (7-bit offset form),
+    // 5 uniform random bytes
     for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) {
         uint32_t h = hash32((uint32_t)e * 2654435761u + seed);
+        const uint32_t h0 = h;
         float s = 0;
         for (int t = 0; t < 4; ++t) { h = hash32(h + t); s += (h >> 8) * (1.0f / 16777216.0f); }
-        x[e] = (int8_t)fminf(127.f, fmaxf(-127.f, rintf((s - 2.0f) * 1.7320508f * 40.f)));
+        const float g = (s - 2.0f) * 1.7320508f;
+        float v = g * 40.f;
+        if (dist == 1) v = 0.f;
+        if (dist == 2) v = g * 10.f;
+        if (dist == 3) v = fabsf(g * 40.f);
+        if (dist == 4) v = g * 20.f + 64.f;
+        if (dist == 5) v = (float)(int8_t)(h0 & 255);
+        x[e] = (int8_t)fminf(127.f, fmaxf(-127.f, rintf(v)));
     }
 }
 
@@ -575,8 +586,10 @@ int main(int argc, char** argv) {
     char *Q, *Rf;
     CK(hipMalloc(&Q, (size_t)nq_pad * ROWB));
     CK(hipMalloc(&Rf, (size_t)nr_pad * ROWB + (1 << 20)));
-    hipLaunchKernelGGL(gen_bytes, dim3(4096), dim3(256), 0, 0, (int8_t*)Q, (int64_t)nq_pad * ROWB, 1u);
-    hipLaunchKernelGGL(gen_bytes, dim3(4096), dim3(256), 0, 0, (int8_t*)Rf, nr_pad * ROWB, 77u);
+    const int dq = getenv("I8_DATA_Q") ? atoi(getenv("I8_DATA_Q")) : 0, dr = getenv("I8_DATA_R") ? atoi(getenv("I8_DATA_R")) : 0;
+    printf("operand distributions: panel %d, references %d\n", dq, dr);
+    hipLaunchKernelGGL(gen_bytes, dim3(4096), dim3(256), 0, 0, (int8_t*)Q, (int64_t)nq_pad * ROWB, 1u, dq);
+    hipLaunchKernelGGL(gen_bytes, dim3(4096), dim3(256), 0, 0, (int8_t*)Rf, nr_pad * ROWB, 77u, dr);
     CK(hipDeviceSynchronize());
     {
         int* out;
@@ -667,6 +680,12 @@ int main(int argc, char** argv) {
             run("V11 same, PF2 AW8", k16<256, 4, 1, 8, 2, 2, 1, 0, 8>, a, 256, 4, 256, slice_cols, R);
             run("V12 16x16x64 P128 4w 128x128 PF2 AW4, epilogue per item only", k16<128, 4, 1, 4, 4, 2, 1, 0, 4>, a, 128, 4, 512, slice_cols, R);
         }
+    }
+    if (mode == 6) {
+        // round 5: data-dependent power -- the shipped shape only, operand distributions from I8_DATA_Q / I8_DATA_R
+        a.thr = 0x7fffffff;
+        for (int rep = 0; rep < 3; ++rep)
+            run("V10 16x16x64 P256 8w 256x32 PF2 AW4", k16<256, 8, 1, 8, 1, 2, 0, 0, 4>, a, 256, 8, 256, slice_cols, 4);
     }
     if (mode == 3) {
         a.thr = (int)(9.f * sig);

@@ -460,9 +460,21 @@ static int global_topk_impl(vsc_index_t* idx, const float* q, int64_t nq, int q_
     int64_t mm = 0;
     hipEvent_t sort_stop;
     VSC_TRY(prof_begin(idx, &sort_stop, 4));
-    VSC_TRY(sort_hits_topk(idx->ws.hA[0].as<int32_t>(), idx->ws.hA[1].as<int32_t>(), idx->ws.hA[2].as<float>(),
-                           n, K, nq, idx->ws.w0, idx->ws.w1, idx->ws.w2, idx->ws.w3, idx->ws.tmp, di, dj, ds,
-                           ip ? 0 : 1, &mm, idx->stream));
+    if (idx->sort_hits || !ip) {
+        VSC_TRY(sort_hits_topk(idx->ws.hA[0].as<int32_t>(), idx->ws.hA[1].as<int32_t>(), idx->ws.hA[2].as<float>(),
+                               n, K, nq, idx->ws.w0, idx->ws.w1, idx->ws.w2, idx->ws.w3, idx->ws.tmp, di, dj, ds,
+                               ip ? 0 : 1, &mm, idx->stream));
+    } else {
+        // option "sort_hits" = 0 (the column-sharded schedule, vsc2022_amd/dist.py: a batch's hits only join a list that
+        // is counted, filtered and sorted ONCE at the end; inner product only): the kept hits as they lie; a
+        // list of K entries may be a truncated one (n > K) -- the caller then asks again with a larger budget
+        mm = m;
+        if (mm > 0) {
+            VSC_HIP(hipMemcpyAsync(di, idx->ws.hA[0].p, (size_t)mm * 4, hipMemcpyDeviceToDevice, idx->stream));
+            VSC_HIP(hipMemcpyAsync(dj, idx->ws.hA[1].p, (size_t)mm * 4, hipMemcpyDeviceToDevice, idx->stream));
+            VSC_HIP(hipMemcpyAsync(ds, idx->ws.hA[2].p, (size_t)mm * 4, hipMemcpyDeviceToDevice, idx->stream));
+        }
+    }
     VSC_TRY(prof_end(idx, sort_stop, 12.0 * (double)n, 4));  // (row, ref, score) of every kept hit in
     if (out_mem == VSC_MEM_HOST && mm > 0) {
         VSC_HIP(hipMemcpyAsync(out_i, di, (size_t)mm * 4, hipMemcpyDeviceToHost, idx->stream));

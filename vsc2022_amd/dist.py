@@ -26,10 +26,14 @@ round 5 first decided the tie case by replaying the schedule on one rank -- unti
 a case but the rule: at BASELINE configs[3] (2e12 scores, K = 48 M) about 70 pairs share EVERY fp32 value near the cut, a tie
 on the cut is certain, and a replay on one rank costs what the whole single-GPU search costs.  So the query-sharded search
 now emulates the schedule itself (`emulate_schedule`): the schedule's state is a radius and a list of kept hits, its batches
-are global row ranges, and its decisions need only counts and order statistics of lists -- which the ranks can prepare
-IN PARALLEL by searching their rows at a radius that is certain (and checked) to lie below the schedule's.
+are global row ranges, and its decisions need only counts and order statistics of that list -- sums over ANY partition of it.
+The batches must be walked in order (a batch's radius is decided by the batches before it), so the parallel axis inside a
+batch is the reference side: every rank searches all rows of the batch against its slice of the reference columns.
 
-  * query shards (engine.DeviceMatcher.match): `emulate_schedule` over lists searched beforehand; exact t, exact {s > t};
+  * query shards (engine.DeviceMatcher.match): queries all-gathered once, `emulate_schedule` in lockstep over column slices
+    (engine.DeviceMatcher.sharded_schedule_search), kept hits handed to the ranks that own their query rows; exact t, exact
+    {s > t}.  Everything around the search -- score normalisation, candidate generation, localisation -- stays sharded by
+    query video;
   * reference shards (refshard.py): the exact top-K over column shards + `emulate_schedule_radius` (every batch runs on
     all shards at once) when a tie sits on the cut.
 """
@@ -438,7 +442,7 @@ def kth_best_unsorted(scores: torch.Tensor, k: int, group=None) -> Tuple[float, 
 
 def emulate_schedule(search_rows: Callable[[int, int, float], Tuple[torch.Tensor, torch.Tensor, torch.Tensor]], n_rows: int,
                      k_global: int, group=None, device=None, trace: Optional[list] = None,
-                     handover: Optional[Tuple[int, Callable]] = None):
+                     handover: Optional[Tuple[int, Callable]] = None, timing: Optional[Tuple[Callable, dict]] = None):
     """range_search_max_results(max_results=2K, min_results=K) over the reference's batch schedule (vsc/index.py:147-154,
     inner product), run over QUERY SHARDS: returns (final radius t, i, j, s) -- this rank's part of {s > t}, the set the
     reference sorts and cuts at K.  Exact, ties included: nothing is decided by a proof about the cut.
@@ -478,9 +482,13 @@ def emulate_schedule(search_rows: Callable[[int, int, float], Tuple[torch.Tensor
         if s.numel():
             kept_i.append(i); kept_j.append(j); kept_s.append(s)
             n_kept += int(s.numel())
+        t0 = timing[0]() if timing else 0.0
         total = all_reduce_sum_int(n_kept, dev, group)
+        if timing:
+            timing[1]["t_count"] = timing[1].get("t_count", 0.0) + timing[0]() - t0
         event = total > 2 * k_global
         if event:
+            t0 = timing[0]() if timing else 0.0
             alls = torch.cat(kept_s) if kept_s else torch.zeros(0, dtype=torch.float32, device=dev)
             tau, _ = kth_best_unsorted(alls, k_global + 1, group)
             radius = float(tau)
@@ -488,6 +496,9 @@ def emulate_schedule(search_rows: Callable[[int, int, float], Tuple[torch.Tensor
                 m = alls > radius
                 kept_i, kept_j, kept_s = [torch.cat(kept_i)[m]], [torch.cat(kept_j)[m]], [alls[m]]
                 n_kept = int(kept_s[0].numel())
+            if timing:
+                timing[1]["t_events"] = timing[1].get("t_events", 0.0) + timing[0]() - t0
+                timing[1]["events"] = timing[1].get("events", 0) + 1
         if trace is not None:
             trace.append((r0, r1, radius, total, event))
     if handover is not None:  # (the whole query set lies before `row`)

@@ -363,27 +363,39 @@ class DeviceMatcher:
         return i.clone(), j.clone(), s.clone()
 
     def sharded_schedule_search(self, K: int, nq_glob_rows: Optional[int], row_base: int, group=None):
-        """vsc/index.py:142-165 over query shards: this rank's share of the reference's K hits (sorted; rows LOCAL), the
-        schedule's final radius and the selection's report.  Identical to what one process returns for the whole query
-        set, ties included.
+        """vsc/index.py:142-165 for a query set that is sharded over ranks: this rank's share of the reference's K hits
+        (sorted; rows LOCAL), the schedule's final radius and the selection's report.  Identical to what one process
+        returns for the whole query set, ties included.
 
         The schedule (range_search_max_results over exponential_query_iterator) is a radius, a list of kept hits and
-        global row batches; every decision it takes is a count or an order statistic of that list.  So:
-          1. in parallel, every rank lists the hits of its rows of each steady 32768-row batch above a FLOOR that should lie
-             below the radius the schedule will have there: `dist.predict_schedule_density` says how many hits per row that
-             radius leaves if all rows are alike, the floor is the score below which a quarter more pairs of an m-row sample
-             of the rank's rows lie (1.25 x; at most 2.3 K m / n: the radius at row n never falls below the (2K+1)-th best score of
-             the rows before n) -- int8 batches + exact stage, what the single-process search spends on the same rows;
-          2. `dist.emulate_schedule` walks the batches: a batch's hits come out of the prepared list (filtered at the
-             schedule's radius) -- or, where the floor turns out too high and for the doubling batches 32 ... 32768 at the head
-             of the query set, from a search at exactly that radius by the rank that owns the rows;
-          3. the exact distributed selection cuts {s > final radius} at K.
-        VSC_SHARD_SPEC_START=<row> (default 65504, the end of the doubling phase): batches from there on are prepared."""
+        GLOBAL row batches that must be walked in order -- the radius a batch is searched at is decided by the batches
+        before it --; every decision it takes is a count or an order statistic of the kept list, i.e. a sum over any
+        partition of that list.  The score matrix of a batch is split by reference COLUMNS (VSC_SHARD_MODE=cols, default):
+          1. the (score-normalised) query rows are all-gathered once (2 GB at configs[3]) and every rank keeps an index of
+             its 1/world slice of the reference rows next to the full set the localisation needs;
+          2. `dist.emulate_schedule` walks the batches in lockstep: every rank searches ALL rows of the batch against its
+             slice at exactly the schedule's radius (the library's steady-batch entry, hits unsorted), one all-reduce of the
+             kept count per batch, the exact distributed (K+1)-th best at every event;
+          3. the kept hits go to the ranks that own their query rows (one all-to-all), where the exact distributed
+             selection cuts {s > final radius} at K and candidate generation / localisation carry on per query video.
+        Every rank does 1/world of every launch of the single-process search -- the same candidates, the same exact-stage
+        work, no prediction and nothing searched twice; measured on ranks sharing one GPU the searches of all ranks
+        together take 1.30 s (2 ranks) / 1.38 s (4 ranks) against 1.26 s in one process.
+
+        VSC_SHARD_MODE=rows is this round's first design, kept for comparison: only the doubling batches at the head are
+        split by columns; for the steady batches every rank lists its OWN rows' hits beforehand above a floor predicted
+        from a row sample (`dist.predict_schedule_density`) and the schedule filters those lists, searching a batch on
+        demand where the floor was too high.  It needs no all-gather of the queries, but the rank that owns the first rows
+        (low radii: three times the hits of the others) carries most of the exact-stage work, and every list is 1.25 x what
+        the schedule needs.  VSC_SHARD_SPEC_START=<row> (default 65504): where its prepared batches begin."""
         dev = self.tdev
         nq_loc = int(self.q_feats.shape[0])
         nr = self.index.ntotal
         n_rows = vdist.all_reduce_sum_int(nq_loc, dev, group) if nq_glob_rows is None else int(nq_glob_rows)
-        spec_start = max(32, int(os.environ.get("VSC_SHARD_SPEC_START", "65504")))
+        # VSC_SHARD_MODE=cols (default): EVERY batch of the schedule is split by reference columns (below); =rows: only the
+        # doubling batches are, the steady ones come from lists the row owners prepared (steps 1-2 above)
+        by_rows = os.environ.get("VSC_SHARD_MODE", "cols") == "rows"
+        spec_start = max(32, int(os.environ.get("VSC_SHARD_SPEC_START", "65504"))) if by_rows else n_rows + 1
         spec_factor = float(os.environ.get("VSC_SHARD_SPEC_FACTOR", "1.25"))
         stats = dict(n_rows=n_rows, prepared=0, prepared_hits=0, on_demand=0, floor_too_high=0)
         debug = os.environ.get("VSC_SHARD_DEBUG") == "1"
@@ -435,7 +447,9 @@ class DeviceMatcher:
         by_cols = world > 1 and head_end > 0 and nr >= 64 * world and os.environ.get("VSC_SHARD_HEAD_COLS", "1") != "0"
         if by_cols:
             ha, hb = local(0, head_end)
+            t0 = clock()
             head_q = vdist.all_gather_varlen(self.q_feats[ha:max(ha, hb)], group)   # rank order = row order
+            stats["t_gather"] = clock() - t0
             c0, c1 = [(x // 64) * 64 for x in vdist.shard_ranges(nr, world)[rank]]
             if rank == world - 1:
                 c1 = nr
@@ -444,6 +458,7 @@ class DeviceMatcher:
                 col_index = FlatIndex(self.dim, _lib.METRIC_INNER_PRODUCT, self.device)
                 if self.torch_stream:
                     col_index.use_torch_stream()
+                col_index.set_option("sort_hits", 0)   # (a batch's hits join a list that is sorted once, at the end)
                 col_index.add(self.ref_feats[c0:c1])
                 self._col_index, self._col_range = col_index, (c0, c1)
 
@@ -485,7 +500,8 @@ class DeviceMatcher:
         stats["t_prepare"] = clock() - t_start
         t0 = clock()
         radius, hi, hj, hs = vdist.emulate_schedule(search_rows, n_rows, K, group, dev,
-                                                    handover=(head_end, to_row_owners) if by_cols else None)
+                                                    handover=(head_end, to_row_owners) if by_cols else None,
+                                                    timing=(clock, stats) if debug else None)
         stats["t_emulate"] = clock() - t0
         t0 = clock()
         # (score desc, row asc, ref asc): the order the reference's stable sort leaves, then the global cut at K
