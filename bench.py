@@ -680,15 +680,23 @@ def main():
         peak = classes[dom][1]
         achieved = (k_flops / 1e12) / (k_ms / 1e3) if k_ms > 0 else 0.0
         # HBM-side bytes per launch of the dominant kernel come from the committed PMC passes of the SAME kernel
-        # (FETCH_SIZE / WRITE_SIZE cannot be sampled from inside the process): profiles/r04_roofline.json names the
-        # kernel, the commit it was measured at and the rocprofv3 files
+        # (FETCH_SIZE / WRITE_SIZE cannot be sampled from inside the process): the newest profiles/r*_roofline.json names
+        # the kernel, the commit it was measured at, the rocprofv3 files and the hash of the kernel's source file then --
+        # compared with the file as it is now, so the line says whether the figure belongs to this very kernel
         traffic, traffic_src = None, None
         try:
-            with open(os.path.join(ROOT, "profiles", "r04_roofline.json")) as fh:
+            import glob
+            import hashlib
+            rpath = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_roofline.json")))[-1]
+            with open(rpath) as fh:
                 rj = json.load(fh)
             if rj.get("kernel_class") == dom:
                 traffic = float(rj["hbm_bytes_per_launch"])
-                traffic_src = f"profiles/r04_roofline.json, measured at commit {rj.get('commit', '?')}"
+                traffic_src = f"profiles/{os.path.basename(rpath)}, measured at commit {rj.get('commit', '?')}"
+                if rj.get("kernel_source"):
+                    with open(os.path.join(ROOT, rj["kernel_source"]), "rb") as fh:
+                        same = hashlib.sha256(fh.read()).hexdigest()[:16] == rj.get("kernel_source_sha256_16")
+                    traffic_src += f"; {rj['kernel_source']} {'unchanged' if same else 'CHANGED'} since"
         except Exception:
             pass
         dpad_bytes = 8 * ((dim + 63) // 64 * 64)  # two packed fp32 rows per re-scored candidate
