@@ -97,6 +97,8 @@ int vsc_device_count(void);
  *                             sorted by reference row)
  *   VSC_KNN_LEVELS=1          pre-filtered k-NN with one refinement level; VSC_KNN_SUBSET=<factor> (default 300),
  *   VSC_KNN_S0DIV=<n> (28), VSC_KNN_S0MIN=<rows> (1024), VSC_KNN_RATIO=<r> (by k), VSC_KNN_NCHUNK=<n>: sizes of its exact subset pass / levels
+ *   VSC_KNN_FIRST_TILE=0      exact k-NN kernel, k > 1: insert every score of a run's first tile (default: only those that reach
+ *                             a per-wave lower bound of the row's k-th largest score of that tile; A/B)
  *   VSC_DEBUG_I8 / VSC_DEBUG_SCREEN: notes on stderr when a search falls back from int8 / per screen launch
  *   VSC_TOPK_SHORTCUT=0|1|2   proven top-K route of vsc_index_global_topk (see there); VSC_TOPK_SAMPLE=<rows> (4096)
  *   VSC_SORT_HITS=0           vsc_index_global_topk / _seeded (inner product) return their hits as a SET, in the kept

@@ -128,7 +128,7 @@ static const OptionName kOptions[] = {
     {"i8p_pair", "VSC_I8P_PAIR"}, {"i8_screen", "VSC_I8_SCREEN"}, {"i8_knn", "VSC_I8_KNN"}, {"knn_step", "VSC_KNN_STEP"},
     {"knn_step_max", "VSC_KNN_STEP_MAX"}, {"knn_step_work", "VSC_KNN_STEP_WORK"}, {"rescore_sort", "VSC_RESCORE_SORT"},
     {"knn_levels", "VSC_KNN_LEVELS"}, {"knn_subset", "VSC_KNN_SUBSET"}, {"knn_s0div", "VSC_KNN_S0DIV"},
-    {"knn_s0min", "VSC_KNN_S0MIN"}, {"knn_ratio", "VSC_KNN_RATIO"}, {"knn_nchunk", "VSC_KNN_NCHUNK"},
+    {"knn_s0min", "VSC_KNN_S0MIN"}, {"knn_ratio", "VSC_KNN_RATIO"}, {"knn_nchunk", "VSC_KNN_NCHUNK"}, {"knn_first_tile", "VSC_KNN_FIRST_TILE"},
     {"cand_budget", "VSC_CAND_BUDGET"}, {"debug_i8", "VSC_DEBUG_I8"}, {"debug_screen", "VSC_DEBUG_SCREEN"},
     {"topk_shortcut", "VSC_TOPK_SHORTCUT"}, {"topk_sample", "VSC_TOPK_SAMPLE"}, {"sort_hits", "VSC_SORT_HITS"},
 };
@@ -193,6 +193,7 @@ static int apply_option(vsc_index* idx, const char* name, double v) {
     if (is("knn_s0min")) { idx->knn_s0_min = v >= 64.0 ? (int)v : 1024; return VSC_OK; }
     if (is("knn_ratio")) { idx->knn_ratio = v; return VSC_OK; }
     if (is("knn_nchunk")) { idx->knn_nchunk = (int)v; return VSC_OK; }
+    if (is("knn_first_tile")) { idx->knn_first_tile = v != 0.0; return VSC_OK; }
     if (is("cand_budget")) { if (!(v >= 1048576.0)) goto bad; idx->cand_budget = (int64_t)v; return VSC_OK; }
     if (is("debug_i8")) { idx->debug_i8 = v != 0.0; return VSC_OK; }
     if (is("debug_screen")) { idx->debug_screen = v != 0.0; return VSC_OK; }
@@ -232,6 +233,7 @@ static int read_option(const vsc_index* idx, const char* name, double* out) {
     else if (is("knn_s0min")) *out = idx->knn_s0_min;
     else if (is("knn_ratio")) *out = idx->knn_ratio;
     else if (is("knn_nchunk")) *out = idx->knn_nchunk;
+    else if (is("knn_first_tile")) *out = idx->knn_first_tile;
     else if (is("cand_budget")) *out = (double)idx->cand_budget;
     else if (is("debug_i8")) *out = idx->debug_i8;
     else if (is("debug_screen")) *out = idx->debug_screen;

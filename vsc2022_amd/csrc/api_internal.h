@@ -123,6 +123,7 @@ struct vsc_index {
     int knn_s0_div = 28;         // VSC_KNN_S0DIV
     int knn_s0_min = 1024;       // VSC_KNN_S0MIN: smallest exact subset
     double knn_ratio = 0.0;      // VSC_KNN_RATIO (0: by k)
+    bool knn_first_tile = true;  // VSC_KNN_FIRST_TILE=0: no per-wave k-th-largest threshold on a run's first tile (k > 1)
     int knn_nchunk = 0;          // VSC_KNN_NCHUNK: reference chunks of the exact k-NN kernel (0: by size)
     bool debug_i8 = false, debug_screen = false;  // VSC_DEBUG_I8 / VSC_DEBUG_SCREEN: stderr notes
     // vsc_index_global_topk, optional route (api_search.hip: global_topk_proven): the exact top-K from a sampled seed radius

@@ -28,7 +28,7 @@ static int knn_exact_ip(vsc_index* idx, const float* qp, int64_t nq, int64_t nr,
     VSC_TRY(idx->ws.parts.reserve((size_t)nq_pad * nchunk * k * 4));
     VSC_TRY(idx->ws.partj.reserve((size_t)nq_pad * nchunk * k * 4));
     SimKnnArgs a{qp, idx->ref.as<float>(), idx->dpad, (int)nq, (int)nr, tq, tr, nchunk, k,
-                 idx->ws.parts.as<float>(), idx->ws.partj.as<int32_t>()};
+                 idx->ws.parts.as<float>(), idx->ws.partj.as<int32_t>(), idx->knn_first_tile ? 0 : 1};
     hipEvent_t stop;
     VSC_TRY(prof_begin(idx, &stop));
     VSC_TRY(launch_sim_knn(a, idx->stream));

@@ -107,6 +107,7 @@ struct ScreenArgs {
 struct SimKnnArgs {
     const float* Q; const float* R; int dpad; int nq; int nr; int tq; int tr; int nchunk; int k;
     float* part_s; int32_t* part_j;
+    int no_first_tile_select;  // option knn_first_tile = 0: k > 1 inserts every score of a run's first tile (A/B)
 };
 struct KnnMergeArgs {
     const float* part_s; const int32_t* part_j; int nq; int nchunk; int k; float* out_s; int64_t* out_j; int l2;

@@ -353,6 +353,15 @@ __device__ __forceinline__ bool knn_better(float s, int j, float s2, int j2) {
     return (s > s2) || (s == s2 && j < j2);
 }
 
+// order-preserving fp32 <-> unsigned key (larger score, larger key; -0.0 sorts just below +0.0)
+__device__ __forceinline__ unsigned ordered_key(float v) {
+    const unsigned b = __float_as_uint(v);
+    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+__device__ __forceinline__ float key_to_float(unsigned key) {
+    return __uint_as_float((key & 0x80000000u) ? (key & 0x7fffffffu) : ~key);
+}
+
 __global__ __launch_bounds__(256, 1) void sim_knn_kernel(SimKnnArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -430,6 +439,40 @@ __global__ __launch_bounds__(256, 1) void sim_knn_kernel(SimKnnArgs a) {
                     if ((lane & 31) == 0 && v > -INFINITY) {
                         const int rl = rl_base + m * 32 + (r & 3) + 8 * (r >> 2);
                         // float maximum on the bits: non-negative floats order like ints, negative ones like reversed unsigneds
+                        if (v >= 0.0f) atomicMax(&thr_bits[rl], __float_as_int(v));
+                        else atomicMin(reinterpret_cast<unsigned int*>(&thr_bits[rl]), __float_as_uint(v));
+                    }
+                }
+            __syncthreads();
+        } else if (tri == t_begin && k <= 32 && !a.no_first_tile_select) {
+            // k > 1, first tile of the run: the same storm, 128 insertions per row for k survivors.  Any
+            // lower bound of a row's k-th largest score of the tile is a valid threshold; each of the two waves that share
+            // a row takes the k-th largest of ITS 64 scores of that row (k <= 64) -- a bitwise search on the order-preserving
+            // key, two ballots per bit, the two rows of a register (lanes 0-31 / 32-63) side by side -- and the larger of
+            // the two bounds gates the insertions: between k and 2k entries per row get through instead of 128.  The search
+            // stops 8 bits early (the prefix with zero low bits is still a lower bound).  200 k x 2 M subset pass: k = 5 11.5 ->
+            // 6.5 ms, k = 20 21.5 -> 16.5 ms; k = 64 gains nothing (the 64-th of a wave's 64 scores is their minimum): k <= 32.
+            int* thr_bits = reinterpret_cast<int*>(thr);
+            const int half_shift = lane & 32;
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float v0 = col_base < a.nr ? acc[m][0][r] : -INFINITY;
+                    const float v1 = col_base + 32 < a.nr ? acc[m][1][r] : -INFINITY;
+                    const unsigned k0 = v0 == v0 ? ordered_key(v0) : 0u;      // (NaN scores are never inserted: lowest key)
+                    const unsigned k1 = v1 == v1 ? ordered_key(v1) : 0u;
+                    unsigned prefix = 0;
+#pragma unroll 1
+                    for (int bit = 31; bit >= 8; --bit) {
+                        const unsigned cand = prefix | (1u << bit);
+                        const unsigned long long b0 = __ballot(k0 >= cand), b1 = __ballot(k1 >= cand);
+                        const int cnt = __popc((unsigned)(b0 >> half_shift)) + __popc((unsigned)(b1 >> half_shift));
+                        if (cnt >= k) prefix = cand;
+                    }
+                    const float v = key_to_float(prefix);
+                    if ((lane & 31) == 0 && prefix > ordered_key(-INFINITY)) {
+                        const int rl = rl_base + m * 32 + (r & 3) + 8 * (r >> 2);
                         if (v >= 0.0f) atomicMax(&thr_bits[rl], __float_as_int(v));
                         else atomicMin(reinterpret_cast<unsigned int*>(&thr_bits[rl]), __float_as_uint(v));
                     }
