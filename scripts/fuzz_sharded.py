@@ -1,10 +1,12 @@
 #!/usr/bin/env python3
-"""Soak test of the query-sharded engine: random datasets, 2-4 ranks sharing the one GPU of the box (gloo), the ranks'
-local searches seeded from a row sample of random size (`DeviceMatcher.seed_radius`, incl. samples so small that the
-seed is often too high and the fallback runs) -- the global candidate table and the localisation results must equal
-the single-process engine's bit for bit.  Round 5: static videos and descriptors on a coarse grid are part of the draw --
-exact score ties, also ON the K cut, where the sharded pipeline has to find out what the reference's schedule does with
-the tied hits (vsc2022_amd/dist.py, module docstring); every run must report `matches_reference`.
+"""Soak test of the query-sharded engine: random datasets, 2-4 ranks sharing the one GPU of the box (gloo) -- the global
+candidate table and the localisation results must equal the single-process engine's bit for bit.  Both designs of the
+sharded search are drawn (engine.DeviceMatcher.sharded_schedule_search): the default column mode (every batch of the
+reference's schedule split by reference columns) and, for cases with `seed_rows`, the row-list mode with lists prepared
+from a row sample of random size (VSC_SHARD_SPEC_START: incl. samples so small that the predicted floor is often too
+high and batches are searched on demand).  Static videos and descriptors on a coarse grid are part of the draw -- exact
+score ties, also ON the K cut, where the result depends on what the reference's schedule does with the tied hits
+(vsc2022_amd/dist.py, module docstring); every run must report `matches_reference`.
 
     python scripts/fuzz_sharded.py --seconds 120 --seed 0
 """
@@ -52,6 +54,7 @@ def worker(rank, world, port, out_dir, case):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), LOCAL_RANK="0")
     if case["seed_rows"]:
         os.environ["VSC_SHARD_SPEC_START"] = str(case["seed_rows"])
+        os.environ["VSC_SHARD_MODE"] = "rows"   # cases with prepared row lists; the others run the default column mode
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from vsc2022_amd import dist as vdist
@@ -122,7 +125,7 @@ def main():
         n_seeded += 1 if case["seed_rows"] else 0
         n_tie += int(parts[0]["flags"][1])
         n_drop += int(parts[0]["flags"][2])
-    print(f"fuzz ok: {n_cases} random datasets ({n_seeded} with seeded local searches; {n_tie} with a tie on the K cut, "
+    print(f"fuzz ok: {n_cases} random datasets ({n_seeded} in row-list mode with prepared lists, the others in column mode; {n_tie} with a tie on the K cut, "
           f"{n_drop} of them with the tied hits dropped as the reference drops them), 2-4 ranks on one GPU, candidate "
           f"tables and localisation equal to the single-process engine")
 

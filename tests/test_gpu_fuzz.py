@@ -13,7 +13,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 @pytest.mark.gpu
 @pytest.mark.parametrize("seed", [11, 12])
 def test_fuzz_prefilter_vs_fp32_route(seed):
-    r = subprocess.run([sys.executable, "scripts/fuzz_prefilter.py", "--seconds", "15", "--seed", str(seed)], cwd=ROOT,
+    r = subprocess.run([sys.executable, "scripts/fuzz_prefilter.py", "--seconds", "8", "--seed", str(seed)], cwd=ROOT,
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
     assert "fuzz ok" in r.stdout
@@ -24,7 +24,7 @@ def test_fuzz_prefilter_vs_fp32_route(seed):
 def test_fuzz_int8_prefilter_vs_fp32_route(seed):
     """The same soak with the int8 kernel on every pre-filtered batch (VSC_I8=2): dims up to 1000, rows of wildly
     different norms, exact ties, coordinates on which all references agree."""
-    r = subprocess.run([sys.executable, "scripts/fuzz_prefilter.py", "--seconds", "20", "--seed", str(seed)], cwd=ROOT,
+    r = subprocess.run([sys.executable, "scripts/fuzz_prefilter.py", "--seconds", "10", "--seed", str(seed)], cwd=ROOT,
                        env=dict(os.environ, VSC_I8="2"), capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
     assert "fuzz ok" in r.stdout
@@ -33,7 +33,7 @@ def test_fuzz_int8_prefilter_vs_fp32_route(seed):
 @pytest.mark.gpu
 def test_fuzz_pipeline_vs_oracle():
     """Random small datasets through candidates + TN localisation, every output equal to the CPU oracle."""
-    r = subprocess.run([sys.executable, "scripts/fuzz_pipeline.py", "--seconds", "15", "--seed", "21"], cwd=ROOT,
+    r = subprocess.run([sys.executable, "scripts/fuzz_pipeline.py", "--seconds", "8", "--seed", "21"], cwd=ROOT,
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
     assert "fuzz ok" in r.stdout

@@ -303,7 +303,7 @@ def test_int8_is_chosen_for_score_normalised_descriptors(gpu):
 def test_parity_suites_with_forced_int8():
     """The search / candidate / golden / sharded / pre-filter parity suites again with the int8 kernel on every
     pre-filtered batch."""
-    e = dict(os.environ, VSC_PREFILTER="2", VSC_I8="2")
+    e = dict(os.environ, VSC_PREFILTER="2", VSC_TEST_QUICK="1", VSC_I8="2")
     r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", "tests/test_gpu_search.py",
                         "tests/test_gpu_edge_cases.py", "tests/test_gpu_golden.py", "tests/test_gpu_sharded.py",
                         "tests/test_gpu_prefilter.py", "-k", "not forced_prefilter and not fp32_path_at_scale "

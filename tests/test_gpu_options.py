@@ -116,3 +116,60 @@ def test_handles_on_torch_streams(gpu, orc):
     res2 = m2.match()
     assert torch.equal(res.cand_q, res2.cand_q) and torch.equal(res.cand_r, res2.cand_r)
     assert torch.equal(res.cand_score, res2.cand_score) and torch.equal(res.boxes, res2.boxes) and torch.equal(res.nbox, res2.nbox)
+
+
+def test_unsorted_hits_are_the_same_set(gpu, orc):
+    """option sort_hits = 0 (the column-sharded schedule's batches): the kept hits as they lie -- the same set, the same
+    radius; a list of K entries may be a truncated one"""
+    from vsc2022_amd import _lib
+    from vsc2022_amd.vsc.index import FlatIndex
+
+    q, r = _data(seed=4)
+    for opts in ({"prefilter": 0}, {"prefilter": 2, "i8": 2}):
+        idx = FlatIndex(q.shape[1], _lib.METRIC_INNER_PRODUCT, 0)
+        for k, v in opts.items():
+            idx.set_option(k, v)
+        idx.add(r)
+        for K in (300000, 20000):
+            i, j, s, rad = idx.global_topk(q, K)
+            idx.set_option("sort_hits", 0)
+            assert idx.get_option("sort_hits") == 0
+            ui, uj, us, urad = idx.global_topk(q, K)
+            idx.set_option("sort_hits", 1)
+            assert urad == rad and len(us) <= K
+            if len(s) < K:      # nothing was cut: the unsorted list is the whole set
+                a = np.lexsort((j, i, -s.astype(np.float64)))
+                b = np.lexsort((uj, ui, -us.astype(np.float64)))
+                assert np.array_equal(i[a], ui[b]) and np.array_equal(j[a], uj[b])
+                assert np.array_equal(s[a].view(np.uint32), us[b].view(np.uint32))
+            else:               # K of more than K kept hits: every one of them lies above the radius
+                assert len(us) == K and (us > rad).all()
+        # seeded steady batches (what the sharded schedule calls): every pair above the radius, as a set
+        rad0 = float(np.sort((q @ r.T).ravel())[-5000])
+        i, j, s, _ = idx.global_topk(q, 10 ** 7, seed_radius=rad0)
+        idx.set_option("sort_hits", 0)
+        ui, uj, us, _ = idx.global_topk(q, 10 ** 7, seed_radius=rad0)
+        a, b = np.lexsort((j, i)), np.lexsort((uj, ui))
+        assert len(s) == len(us) > 0
+        assert np.array_equal(i[a], ui[b]) and np.array_equal(j[a], uj[b]) and np.array_equal(s[a].view(np.uint32), us[b].view(np.uint32))
+
+
+@pytest.mark.parametrize("k", [2, 7, 20, 32, 33])
+def test_knn_first_tile_threshold_matches_the_oracle(gpu, orc, k):
+    """exact k-NN kernel, k > 1: the per-wave k-th-largest threshold of a run's first tile (option knn_first_tile) changes
+    nothing but the number of insertions -- oracle parity with it and without, ties and short reference sets included"""
+    from vsc2022_amd import _lib
+    from vsc2022_amd.vsc.index import FlatIndex
+
+    q, r = _data(seed=10 + k, nq=300, nr=1500, d=96)
+    r[200:260] = r[7]          # more exact ties than k in one tile
+    for nr in (1500, 130, max(k, 40)):
+        oD, oI = orc.knn(q, r[:nr], k)
+        for ft in (1, 0):
+            idx = FlatIndex(q.shape[1], _lib.METRIC_INNER_PRODUCT, 0)
+            idx.set_option("prefilter", 0)
+            idx.set_option("knn_first_tile", ft)
+            idx.add(r[:nr])
+            D, I = idx.search(q, k)
+            assert np.array_equal(I, oI), (k, nr, ft)
+            assert np.array_equal(D.view(np.uint32), oD.view(np.uint32)), (k, nr, ft)

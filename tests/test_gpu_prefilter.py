@@ -192,7 +192,7 @@ def test_knn_prefilter_chosen_by_size_matches_oracle(gpu, orc):
 
 def test_parity_suites_with_forced_prefilter():
     """All search/candidate parity suites again with the pre-filter on every batch."""
-    env = dict(os.environ, VSC_PREFILTER="2")
+    env = dict(os.environ, VSC_PREFILTER="2", VSC_TEST_QUICK="1")
     r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", "tests/test_gpu_search.py",
                         "tests/test_gpu_edge_cases.py", "tests/test_gpu_golden.py", "tests/test_gpu_sharded.py"],
                        cwd=ROOT, env=env, capture_output=True, text=True, timeout=1200)
