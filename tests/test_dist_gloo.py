@@ -718,3 +718,44 @@ def test_emulated_schedule_radius_equals_the_oracles_single_process():
             t = vdist.emulate_schedule_radius(
                 lambda r0, r1, rad: torch.from_numpy(orc.range_search(q[r0:r1], r, rad)[1]), len(q), K)
             assert np.float32(t) == np.float32(info["radius"]), (seed, K, t, info)
+
+
+def _owners_worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        sys.path.insert(0, ROOT)
+        from vsc2022_amd import dist as vdist
+
+        g = torch.Generator().manual_seed(100 + rank)
+        n = [0, 1000, 37][rank % 3]                      # one rank has nothing to send
+        rows = torch.randint(0, 1 << 20, (n, 3), generator=g, dtype=torch.int32)
+        rows[:, 0] = rank                                 # (sender, payload, payload)
+        dest = torch.randint(0, world, (n,), generator=g, dtype=torch.int64)
+        if rank == 1:
+            dest[dest == 2] = 0                           # ... and one link carries nothing
+        got = vdist.send_to_owners(rows, dest, None)
+        np.savez(os.path.join(out_dir, f"o{rank}.npz"), rows=rows.numpy(), dest=dest.numpy(), got=got.numpy())
+        # rows of unequal length from every rank, rank order
+        allv = vdist.all_gather_varlen(rows[:, 1].contiguous(), None)
+        np.save(os.path.join(out_dir, f"g{rank}.npy"), allv.numpy())
+    finally:
+        dist.destroy_process_group()
+
+
+def test_send_to_owners_and_varlen_gather_world3(tmp_path):
+    """the two transfers of the column-sharded schedule (queries gathered once, kept hits to the ranks that own their rows):
+    the same all-to-all / all-gather calls the RCCL run makes, here over gloo on CPU tensors"""
+    world = 3
+    mp.spawn(_owners_worker, args=(world, 29800 + os.getpid() % 150, str(tmp_path)), nprocs=world, join=True)
+    parts = [np.load(tmp_path / f"o{r}.npz") for r in range(world)]
+    for r in range(world):
+        exp = np.concatenate([p["rows"][p["dest"] == r] for p in parts])
+        got = parts[r]["got"]
+        assert got.shape == exp.shape
+        # any order between senders is fine; inside a sender the stable sort keeps the rows' order
+        for sender in range(world):
+            assert np.array_equal(got[got[:, 0] == sender], exp[exp[:, 0] == sender])
+    allv = np.concatenate([p["rows"][:, 1] for p in parts])
+    for r in range(world):
+        assert np.array_equal(np.load(tmp_path / f"g{r}.npy"), allv)

@@ -225,24 +225,24 @@ def all_gather_varlen(t: torch.Tensor, group=None) -> torch.Tensor:
 
 def send_to_owners(rows: torch.Tensor, dest: torch.Tensor, group=None) -> torch.Tensor:
     """Every row of the 2-D int32 tensor `rows` to the rank dest[row] names; returns what this rank received (any order).
-    RCCL: one all-to-all of the counts and one of the rows (each row crosses one link once); gloo has no all-to-all --
-    the debugging set-up gathers everything everywhere and filters."""
+    One all-to-all of the counts and one of the rows (each row crosses one link once) -- the same two collectives under
+    RCCL (device tensors) and under gloo (CPU tensors; device tensors staged through the host), so the CPU tests walk the
+    code the multi-GPU run walks."""
     rank, world = _world(group)
     if world == 1:
         return rows
-    if dist.get_backend(group) == "nccl":
-        order = torch.argsort(dest, stable=True)
-        rows = rows[order].contiguous()
-        counts = torch.bincount(dest, minlength=world)[:world].to(torch.int64)
-        got = torch.empty_like(counts)
-        dist.all_to_all_single(got, counts, group=group)
-        send, recv = counts.cpu().tolist(), got.cpu().tolist()
-        out = torch.empty((sum(recv),) + tuple(rows.shape[1:]), dtype=rows.dtype, device=rows.device)
-        dist.all_to_all_single(out, rows, output_split_sizes=recv, input_split_sizes=send, group=group)
-        return out
-    tagged = torch.cat([rows, dest.to(rows.dtype).unsqueeze(1)], dim=1)
-    allr = all_gather_varlen(tagged, group)
-    return allr[allr[:, -1] == rank][:, :-1].contiguous()
+    order = torch.argsort(dest, stable=True)
+    rows = rows[order].contiguous()
+    counts = torch.bincount(dest, minlength=world)[:world].to(torch.int64)
+    host = _via_host(rows, group)
+    c = counts.cpu() if host else counts
+    got = torch.empty_like(c)
+    dist.all_to_all_single(got, c, group=group)
+    send, recv = c.cpu().tolist(), got.cpu().tolist()
+    src = rows.cpu() if host else rows
+    out = torch.empty((sum(recv),) + tuple(rows.shape[1:]), dtype=rows.dtype, device=src.device)
+    dist.all_to_all_single(out, src, output_split_sizes=recv, input_split_sizes=send, group=group)
+    return out.to(rows.device)
 
 
 class ShardedCandidates:
