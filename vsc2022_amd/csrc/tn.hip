@@ -70,18 +70,39 @@ __device__ __forceinline__ int tn_edge_bit(const TnStateT<IDX>& g, int qi, int a
     return (((qi + d) * g.top + b) * g.ms + d) * g.top + a;
 }
 
-// (value, order) wave arg-max: larger value wins, ties go to the smaller order index
-__device__ __forceinline__ void wave_first_max(float& v, int& o) {
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) {
-        const float ov = __shfl_xor(v, off);
-        const int oo = __shfl_xor(o, off);
-        if (oo >= 0 && (o < 0 || ov > v || (ov == v && oo < o))) {
-            v = ov;
-            o = oo;
-        }
-    }
+// (value, order) first-maximum reductions: larger value wins, ties go to the smaller order index, order < 0 = no entry.
+// Round 5: the pair is folded into ONE 64-bit key whose unsigned maximum is that first maximum -- the order-preserving
+// image of the float above (2^31 - 1 - order) -- so a butterfly step is two ds_bpermute, one 64-bit compare and two
+// selects.  The compare-and-branch form it replaces cost ~7 VALU + ~12 SALU / branches per step (the compiler turns the
+// short-circuit conditions into exec-mask surgery), and the kernel is instruction-issue-bound.
+// -0.0 is folded onto +0.0 (they compare equal); a NaN ranks below every number and above "no entry".
+__device__ __forceinline__ unsigned long long first_max_key(float v, int o) {
+    const float vz = v + 0.0f;
+    const unsigned b = __float_as_uint(vz);
+    unsigned hi = (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+    hi = (vz != vz) ? 1u : hi;
+    const unsigned long long k = ((unsigned long long)hi << 32) | (unsigned)(0x7fffffff - o);
+    return o < 0 ? 0ull : k;
 }
+__device__ __forceinline__ void first_max_unkey(unsigned long long k, float& v, int& o) {
+    const unsigned hi = (unsigned)(k >> 32);
+    const float kv = __uint_as_float((hi & 0x80000000u) ? (hi & 0x7fffffffu) : ~hi);  // (hi == 1 decodes to a NaN again)
+    v = k ? kv : 0.0f;
+    o = k ? 0x7fffffff - (int)(unsigned)k : -1;
+}
+template <int FIRST_OFF>
+__device__ __forceinline__ void first_max_reduce(float& v, int& o) {
+    unsigned long long k = first_max_key(v, o);
+#pragma unroll
+    for (int off = FIRST_OFF; off >= 1; off >>= 1) {
+        const unsigned long long ok = __shfl_xor(k, off);
+        k = ok > k ? ok : k;
+    }
+    first_max_unkey(k, v, o);
+}
+// over the whole wave / inside each half wave (xor offsets <= 16 stay inside a half)
+__device__ __forceinline__ void wave_first_max(float& v, int& o) { first_max_reduce<32>(v, o); }
+__device__ __forceinline__ void half_first_max(float& v, int& o) { first_max_reduce<16>(v, o); }
 
 
 #ifdef VSC_TN_PROFILE  // experiment builds only: shader cycles per phase, summed over all pairs (scripts/experiments)
@@ -329,6 +350,13 @@ __global__ __launch_bounds__(64) void tn_pair_kernel(TnPairArgs a) {
     const int P = (ms - 1) * top;  // regular predecessor slots of a node, insertion order
     int nbox = 0;
     bool have_order = false;
+    // lane constants of the half-wave passes (P <= 32): predecessor slot o = (row distance d, top-k entry aa) of the lane, and
+    // the lane's share of the index arithmetic -- what is left per pass is wave-uniform and runs on the scalar unit (round 5:
+    // the divisions by `top` and two 64-bit multiply-adds per pass were a fifth of the kernel's vector instructions)
+    const int hw_half = lane >> 5, hw_o = lane & 31;
+    const int hw_d = ms - 1 - hw_o / top, hw_aa = hw_o % top;
+    const int hw_bit_off = hw_d * top + hw_aa + hw_half * ms * top;
+    const int hw_pred_off = 1 + hw_aa - hw_d * top;
     for (int it = 0; it <= a.prm.max_path; ++it) {
         // DP by query row (a valid topological order; dist does not depend on which one)
         if (lane == 0) {
@@ -342,15 +370,15 @@ __global__ __launch_bounds__(64) void tn_pair_kernel(TnPairArgs a) {
             // (xor shuffles with offsets <= 16 stay inside a half); the sink keeps the whole-wave path below.
             int b_first = 0;
             if (P <= 32) {
-                const int half = lane >> 5, o = lane & 31;
+                const int half = hw_half, o = hw_o, d = hw_d, aa = hw_aa;
+                const int qi = qj - d;
+                const int pred = qj * top + hw_pred_off;  // node id of this lane's predecessor slot: 1 + qi * top + aa
                 for (int b0 = 0; b0 < top; b0 += 2) {
                     const int b = b0 + half;
                     const int v = 1 + qj * top + b;
                     const bool mine = b < top && v != g.sink;
                     float c = 0.0f;
                     int oo = -1;
-                    const int d = ms - 1 - o / top, aa = o % top;
-                    const int qi = qj - d;
                     const int mslot = qj * ((top + 1) / 2) + (b0 >> 1);
                     bool ok;
                     if (it == 0) {
@@ -361,28 +389,21 @@ __global__ __launch_bounds__(64) void tn_pair_kernel(TnPairArgs a) {
                         ok = (okmask[mslot] >> lane) & 1ull;
                     }
                     if (ok) {
-                        const int bit = tn_edge_bit(g, qi, aa, d, b);
+                        const int bit = (qj * top + b0) * ms * top + hw_bit_off;  // = tn_edge_bit(g, qi, aa, d, b)
                         const bool z = (zero[bit >> 5] >> (bit & 31)) & 1u;
                         const float w = z ? 0.0f : tsim[qj * top + b];
-                        c = dist[1 + qi * top + aa] + w;
+                        c = dist[pred] + w;
                         oo = o;
                     }
-#pragma unroll
-                    for (int off = 16; off >= 1; off >>= 1) {  // (value, slot) first-max inside the half wave
-                        const float ov = __shfl_xor(c, off);
-                        const int o2 = __shfl_xor(oo, off);
-                        if (o2 >= 0 && (oo < 0 || ov > c || (ov == c && o2 < oo))) {
-                            c = ov;
-                            oo = o2;
-                        }
-                    }
+                    half_first_max(c, oo);  // (value, slot) first-max inside the half wave
+                    const int pw = __shfl(pred, (lane & 32) | (oo < 0 ? 0 : oo));  // the winning slot's node id
                     if (mine && o == 0) {
                         if (oo < 0 || !(c >= 0.0f)) {
                             dist[v] = 0.0f;
                             par[v] = (IDX)v;
                         } else {
                             dist[v] = c;
-                            par[v] = (IDX)(1 + (qj - (ms - 1 - oo / top)) * top + oo % top);
+                            par[v] = (IDX)pw;
                         }
                     }
                 }
