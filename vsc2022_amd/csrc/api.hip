@@ -593,8 +593,8 @@ int pack_queries(vsc_index* idx, const float* q, int64_t nq, int q_mem, float** 
 int ensure_hit_buffers(vsc_index* idx, int64_t cap, int64_t ccap, bool need_b) {
     if (ccap < 0) ccap = cap;
     for (int c = 0; c < 3; ++c) {
-        VSC_TRY(idx->ws.hA[c].reserve((size_t)cap * 4));
-        if (need_b) VSC_TRY(idx->ws.hB[c].reserve((size_t)cap * 4));
+        VSC_TRY(idx->ws.hA[c].reserve((size_t)cap * 4 + 16));  // (+ 16: select_hist_kernel reads whole 16-byte pieces)
+        if (need_b) VSC_TRY(idx->ws.hB[c].reserve((size_t)cap * 4 + 16));
     }
     if (idx->prefilter) {
         // candidate list: `ccap` entries in per-wave segments + a shared tail.  The tail is handed out in chunks

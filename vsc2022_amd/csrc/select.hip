@@ -30,6 +30,10 @@ __global__ void select_begin_kernel(SelectCtl* c, unsigned long long max_results
     }
 }
 
+// One digit histogram of the kept scores that match the prefix found so far.  Round 5: 16-byte loads, and the FIRST pass
+// (shift 24: every kept score of a search shares its sign and exponent byte, so 64 lanes used to queue on one LDS counter)
+// counts equal digits inside the wave with ballots and adds once per distinct digit; the later passes see digits that are
+// spread (or few matching elements) and keep the plain LDS atomics.
 __global__ __launch_bounds__(256) void select_hist_kernel(SelectCtl* c, const float* s, int shift) {
     if (!c->active) return;
     __shared__ unsigned int lh[256];
@@ -37,10 +41,33 @@ __global__ __launch_bounds__(256) void select_hist_kernel(SelectCtl* c, const fl
     __syncthreads();
     const unsigned long long n = c->n;
     const unsigned int prefix = c->prefix, pmask = c->prefix_mask;
-    for (unsigned long long x = (unsigned long long)blockIdx.x * 256 + threadIdx.x; x < n;
-         x += (unsigned long long)gridDim.x * 256) {
-        const unsigned int key = f2key(s[x]);
-        if ((key & pmask) == prefix) atomicAdd(&lh[(key >> shift) & 255u], 1u);
+    const int lane = threadIdx.x & 63;
+    const unsigned long long n4 = (n + 3) / 4;  // (the buffer is 16-byte aligned and padded: see ensure_hit_buffers)
+    for (unsigned long long q = (unsigned long long)blockIdx.x * 256 + threadIdx.x; q < ((n4 + 255) & ~255ull);
+         q += (unsigned long long)gridDim.x * 256) {
+        float v[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+        if (q < n4) {
+            const float4 t = *reinterpret_cast<const float4*>(s + q * 4);
+            v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const unsigned int key = f2key(v[e]);
+            const bool valid = q * 4 + e < n && (key & pmask) == prefix;
+            const unsigned int bin = (key >> shift) & 255u;
+            if (shift == 24) {
+                unsigned long long todo = __ballot(valid);
+                while (todo) {
+                    const int leader = __ffsll((long long)todo) - 1;
+                    const unsigned int lb = __shfl(bin, leader);
+                    const unsigned long long same = __ballot(valid && bin == lb);
+                    if (lane == leader) atomicAdd(&lh[lb], (unsigned int)__popcll(same));
+                    todo &= ~same;
+                }
+            } else if (valid) {
+                atomicAdd(&lh[bin], 1u);
+            }
+        }
     }
     __syncthreads();
     if (lh[threadIdx.x]) atomicAdd(&c->hist[threadIdx.x], lh[threadIdx.x]);
@@ -91,31 +118,36 @@ __global__ __launch_bounds__(256) void select_compact_kernel(SelectCtl* c, const
             s[e] = x < n ? as[x] : 0.0f;
             keep_bits |= (unsigned int)((x < n) && (s[e] > radius)) << e;
         }
-        // order inside the chunk: element-slot major, then thread -- any order is fine (sorted later)
-        unsigned int mine = __popc(keep_bits), incl = mine;
+        // order inside the chunk: wave, element slot, lane -- any order is fine (sorted later).  The survivors of one
+        // element slot of a wave go to CONSECUTIVE positions (ballot ranks), so the three stores of a slot are
+        // contiguous runs (round 5; a thread's survivors used to sit next to each other, the wave's stores strided)
+        unsigned long long bal[PER_THREAD];
+        unsigned int wave_total = 0;
 #pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            const unsigned int v = __shfl_up(incl, off);
-            if (lane >= off) incl += v;
+        for (int e = 0; e < PER_THREAD; ++e) {
+            bal[e] = __ballot((keep_bits >> e) & 1u);
+            wave_total += (unsigned int)__popcll(bal[e]);
         }
-        if (lane == 63) wave_cnt[wave] = incl;
+        if (lane == 0) wave_cnt[wave] = wave_total;
         __syncthreads();
         if (threadIdx.x == 0) {
             const unsigned int tot = wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
             chunk_base = tot ? atomicAdd(&c->n_tmp, (unsigned long long)tot) : 0ull;
         }
         __syncthreads();
-        unsigned long long pos = chunk_base + (incl - mine);
+        unsigned long long pos = chunk_base;
         for (int w = 0; w < wave; ++w) pos += wave_cnt[w];
+        const unsigned long long below = (1ull << lane) - 1ull;
 #pragma unroll
         for (int e = 0; e < PER_THREAD; ++e) {
             if ((keep_bits >> e) & 1u) {
                 const unsigned long long x = x0 + (unsigned long long)e * 256;
-                bi[pos] = ai[x];
-                bj[pos] = aj[x];
-                bs[pos] = s[e];
-                ++pos;
+                const unsigned long long p = pos + (unsigned int)__popcll(bal[e] & below);
+                bi[p] = ai[x];
+                bj[p] = aj[x];
+                bs[p] = s[e];
             }
+            pos += (unsigned int)__popcll(bal[e]);
         }
         __syncthreads();  // wave_cnt / chunk_base are reused by the next chunk
     }
