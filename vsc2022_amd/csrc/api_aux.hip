@@ -98,7 +98,7 @@ int vsc_pair_max(const int32_t* hit_i, const int32_t* hit_j, const float* hit_s,
     AuxTimer tm;
     tm.begin(0, c->stream);
     VSC_TRY(pair_max_device((const int32_t*)di, (const int32_t*)dj, (const float*)ds, n, (const int32_t*)dq,
-                            (const int32_t*)dr, 0, ws.w0, ws.w1, ws.w2, ws.w3, ws.tmp, ws.cnt, oq, orr, os, of,
+                            (const int32_t*)dr, nq_rows, nr_rows, ws.w0, ws.w1, ws.w2, ws.w3, ws.tmp, ws.cnt, oq, orr, os, of,
                             ocap, &np, c->stream));
     tm.end(12.0 * (double)n + 20.0 * (double)np, c->stream);  // hits in, (q, r, score, first hit) per pair out
     *n_pairs = np;

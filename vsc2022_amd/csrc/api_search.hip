@@ -462,7 +462,7 @@ static int global_topk_impl(vsc_index_t* idx, const float* q, int64_t nq, int q_
     VSC_TRY(prof_begin(idx, &sort_stop, 4));
     if (idx->sort_hits || !ip) {
         VSC_TRY(sort_hits_topk(idx->ws.hA[0].as<int32_t>(), idx->ws.hA[1].as<int32_t>(), idx->ws.hA[2].as<float>(),
-                               n, K, nq, idx->ws.w0, idx->ws.w1, idx->ws.w2, idx->ws.w3, idx->ws.tmp, di, dj, ds,
+                               n, K, nq, idx->ntotal, idx->ws.w0, idx->ws.w1, idx->ws.w2, idx->ws.w3, idx->ws.tmp, di, dj, ds,
                                ip ? 0 : 1, &mm, idx->stream));
     } else {
         // option "sort_hits" = 0 (the column-sharded schedule, vsc2022_amd/dist.py: a batch's hits only join a list that
@@ -642,7 +642,7 @@ int vsc_index_candidates(vsc_index_t* idx, const float* q, int64_t nq, int q_mem
     VSC_TRY(ws.out[3].reserve((size_t)n * 8));
     int64_t np = 0;
     VSC_TRY(pair_max_device(idx->cand[0].as<int32_t>(), idx->cand[1].as<int32_t>(), idx->cand[2].as<float>(), n,
-                            ws.maps0.as<int32_t>(), ws.maps1.as<int32_t>(), 0, ws.w0, ws.w1, ws.w2, ws.w3, ws.tmp,
+                            ws.maps0.as<int32_t>(), ws.maps1.as<int32_t>(), nq, idx->ntotal, ws.w0, ws.w1, ws.w2, ws.w3, ws.tmp,
                             ws.cnt, ws.out[0].as<int32_t>(), ws.out[1].as<int32_t>(), ws.out[2].as<float>(),
                             ws.out[3].as<int64_t>(), n, &np, idx->stream));
     *n_pairs = np;

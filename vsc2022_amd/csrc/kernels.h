@@ -175,11 +175,11 @@ int launch_matrix_thresh(const MatThreshArgs&, hipStream_t);
 int launch_matrix_knn(const MatKnnArgs&, hipStream_t);
 int set_thresh_kernel_attrs();
 int enqueue_rethreshold(SelectCtl*, int32_t*, int32_t*, float*, int32_t*, int32_t*, float*, unsigned long long, hipStream_t);
-int sort_hits_topk(const int32_t*, const int32_t*, const float*, int64_t, int64_t, int64_t, DevBuf&, DevBuf&,
+int sort_hits_topk(const int32_t*, const int32_t*, const float*, int64_t, int64_t, int64_t, int64_t, DevBuf&, DevBuf&,
                    DevBuf&, DevBuf&, DevBuf&, int32_t*, int32_t*, float*, int, int64_t*, hipStream_t);
 int sort_hits_rowcol(const int32_t*, const int32_t*, const float*, int64_t, DevBuf&, DevBuf&, DevBuf&, DevBuf&,
                      DevBuf&, int32_t*, int32_t*, float*, int, hipStream_t);
-int pair_max_device(const int32_t*, const int32_t*, const float*, int64_t, const int32_t*, const int32_t*, int64_t,
+int pair_max_device(const int32_t*, const int32_t*, const float*, int64_t, const int32_t*, const int32_t*, int64_t, int64_t,
                     DevBuf&, DevBuf&, DevBuf&, DevBuf&, DevBuf&, DevBuf&, int32_t*, int32_t*, float*, int64_t*,
                     int64_t, int64_t*, hipStream_t);
 int launch_pack_rows(const float*, int64_t, int, float*, int64_t, int, hipStream_t);

@@ -187,9 +187,12 @@ inline size_t radix_tmp_bytes(int64_t n) {
 // Stable sort of n pairs by key bits [begin_bit, end_bit), ascending (or descending).  The buffers ping-pong; the
 // result is left in (keys_b, vals_b) when the number of passes is odd, else in (keys_a, vals_a): the return
 // value tells (0 = a, 1 = b), < 0 = error.  `tmp` holds radix_tmp_bytes(n).  n < 2^32.
+// (begin2, end2): a second bit range sorted after the first -- keys made of two fields with unused bits between them
+// (row << 32 | ref, query video << 32 | ref video) skip the passes over the gap (round 5: the pair-max sorted 64 bits for
+// two 16-bit fields, 8 passes instead of 4)
 template <class K, class V>
 int radix_sort_pairs(K* keys_a, K* keys_b, V* vals_a, V* vals_b, int64_t n, int begin_bit, int end_bit, bool desc,
-                     void* tmp, hipStream_t stream) {
+                     void* tmp, hipStream_t stream, int begin2 = 0, int end2 = 0) {
     if (n <= 0) return 0;
     if (n > 0xffffffffLL) {  // histograms, totals and scatter offsets are 32-bit
         set_error("radix_sort_pairs: %lld entries exceed the 2^32 limit of the sort", (long long)n);
@@ -199,7 +202,10 @@ int radix_sort_pairs(K* keys_a, K* keys_b, V* vals_a, V* vals_b, int64_t n, int 
     unsigned* hist = reinterpret_cast<unsigned*>(tmp);
     unsigned* totals = hist + (size_t)256 * ntiles;
     int where = 0;
-    for (int shift = begin_bit; shift < end_bit; shift += 8) {
+    for (int pass = 0;; ++pass) {
+        const int n1 = (end_bit - begin_bit + 7) / 8;
+        const int shift = pass < n1 ? begin_bit + 8 * pass : begin2 + 8 * (pass - n1);
+        if (pass >= n1 && shift >= end2) break;
         const K* ki = where ? keys_b : keys_a;
         const V* vi = where ? vals_b : vals_a;
         K* ko = where ? keys_a : keys_b;

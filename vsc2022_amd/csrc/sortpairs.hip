@@ -49,7 +49,7 @@ static int bits_for(uint64_t maxval) {
 // Orders hits (device arrays, arbitrary order) by (score desc, i asc, j asc) and writes the first
 // min(n, K) to out_* (device).  `negate`: stored scores are negated distances (L2).
 int sort_hits_topk(const int32_t* hi, const int32_t* hj, const float* hs, int64_t n, int64_t K,
-                   int64_t max_i, DevBuf& w0, DevBuf& w1, DevBuf& w2, DevBuf& w3, DevBuf& tmp,
+                   int64_t max_i, int64_t max_j, DevBuf& w0, DevBuf& w1, DevBuf& w2, DevBuf& w3, DevBuf& tmp,
                    int32_t* out_i, int32_t* out_j, float* out_s, int negate, int64_t* n_out,
                    hipStream_t stream) {
     const int64_t m = n < K ? n : K;
@@ -68,7 +68,9 @@ int sort_hits_topk(const int32_t* hi, const int32_t* hj, const float* hs, int64_
     const int end_bit = 32 + bits_for((uint64_t)(max_i > 0 ? max_i : 1));
     VSC_TRY(tmp.reserve(radix_tmp_bytes(n)));
     // (row, ref) ascending, then -- stably -- score descending
-    int w = radix_sort_pairs<uint64_t, uint32_t>(k64a, k64b, k32a, k32b, n, 0, end_bit, false, tmp.p, stream);
+    // (the reference rows occupy `max_j` bits of the low word: the passes over the zero bits above them are skipped)
+    int w = radix_sort_pairs<uint64_t, uint32_t>(k64a, k64b, k32a, k32b, n, 0, max_j > 0 ? bits_for((uint64_t)max_j) : 32, false,
+                                                 tmp.p, stream, 32, end_bit);
     if (w < 0) { set_error("radix sort launch failed"); return VSC_ERR_HIP; }
     if (w) { std::swap(k64a, k64b); std::swap(k32a, k32b); }  // sorted pairs now in (k64a, k32a)
     w = radix_sort_pairs<uint32_t, uint64_t>(k32a, k32b, k64a, k64b, n, 0, 32, true, tmp.p, stream);
@@ -161,6 +163,16 @@ int sort_candidates_by_ref(uint32_t* ka, uint32_t* kb, uint32_t* va, uint32_t* v
 
 // ----------------------------------------------------------------------------- pair max
 
+// maximum of the video ordinals of the rows, taken as the unsigned words the pair key holds: how many key bits the
+// pair sort has to look at
+__global__ __launch_bounds__(256) void max_u32_kernel(const int32_t* x, int64_t n, unsigned* out) {
+    unsigned m = 0;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (int64_t)gridDim.x * 256) m = max(m, (unsigned)x[e]);
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, off));
+    if ((threadIdx.x & 63) == 0 && m > 0) atomicMax(out, m);
+}
+
 __global__ __launch_bounds__(256) void pair_key_kernel(const int32_t* hi, const int32_t* hj, int64_t n,
                                                        const int32_t* row2q, const int32_t* row2r,
                                                        uint64_t* key, uint32_t* rank) {
@@ -209,11 +221,10 @@ __global__ __launch_bounds__(256) void pair_out_kernel(const uint32_t* head_rank
 // All pointers device.  hits are in search order (score-descending).  Synchronises the stream once
 // (the pair count sizes the second sort).
 int pair_max_device(const int32_t* hi, const int32_t* hj, const float* hs, int64_t n,
-                    const int32_t* row2q, const int32_t* row2r, int64_t n_qvid_hint, DevBuf& w0,
+                    const int32_t* row2q, const int32_t* row2r, int64_t nq_rows, int64_t nr_rows, DevBuf& w0,
                     DevBuf& w1, DevBuf& w2, DevBuf& w3, DevBuf& tmp, DevBuf& cnt, int32_t* out_q,
                     int32_t* out_r, float* out_s, int64_t* out_first, int64_t cap, int64_t* n_pairs,
                     hipStream_t stream) {
-    (void)n_qvid_hint;
     *n_pairs = 0;
     if (n <= 0) return VSC_OK;
     if (n > 0xffffffffLL) {
@@ -232,7 +243,19 @@ int pair_max_device(const int32_t* hi, const int32_t* hj, const float* hs, int64
     hipLaunchKernelGGL(pair_key_kernel, dim3(grid_for(n)), dim3(256), 0, stream, hi, hj, n, row2q, row2r, ka, ra);
     VSC_HIP(hipGetLastError());
     VSC_TRY(tmp.reserve(radix_tmp_bytes(n)));
-    int w = radix_sort_pairs<uint64_t, uint32_t>(ka, kb, ra, rb, n, 0, 64, false, tmp.p, stream);
+    // the key is (query video << 32 | ref video): only the bits the largest ordinals occupy are sorted (40 000 videos a
+    // side: 2 + 2 passes instead of 8)
+    VSC_TRY(cnt.reserve(sizeof(unsigned long long)));
+    VSC_HIP(hipMemsetAsync(cnt.p, 0, sizeof(unsigned long long), stream));
+    unsigned* mx = reinterpret_cast<unsigned*>(cnt.p);
+    hipLaunchKernelGGL(max_u32_kernel, dim3(256), dim3(256), 0, stream, row2q, nq_rows, mx);
+    hipLaunchKernelGGL(max_u32_kernel, dim3(256), dim3(256), 0, stream, row2r, nr_rows, mx + 1);
+    VSC_HIP(hipGetLastError());
+    unsigned mxh[2] = {0, 0};
+    VSC_HIP(hipMemcpyAsync(mxh, mx, sizeof(mxh), hipMemcpyDeviceToHost, stream));
+    VSC_HIP(hipStreamSynchronize(stream));
+    const int bits_q = bits_for((uint64_t)std::max(mxh[0], 1u)), bits_r = bits_for((uint64_t)std::max(mxh[1], 1u));
+    int w = radix_sort_pairs<uint64_t, uint32_t>(ka, kb, ra, rb, n, 0, bits_r, false, tmp.p, stream, 32, 32 + bits_q);
     if (w < 0) { set_error("radix sort launch failed"); return VSC_ERR_HIP; }
     if (!w) { std::swap(ka, kb); std::swap(ra, rb); }  // sorted pairs in (kb, rb); (ka, ra) are free
     VSC_HIP(hipMemsetAsync(cnt.p, 0, sizeof(unsigned long long), stream));
