@@ -206,7 +206,17 @@ int vsc_pair_max(const int32_t* hit_i, const int32_t* hit_j, const float* hit_s,
                  int64_t nr_rows, int maps_mem, int32_t* out_q, int32_t* out_r, float* out_s,
                  int64_t* out_first, int64_t cap, int out_mem, int64_t* n_pairs, int device);
 
-/* The stream of the entry points that own no handle on `device` (vsc_pair_max, vsc_row_normalize, vsc_tn_forward_sim):
+/* The final ordering of a hit list on its own: (score desc, query row asc, reference row asc), the order in which
+ * VideoIndex._global_threshold_knn_search flattens and stably sorts its hits (vsc/index.py:158-165) -- for callers that
+ * assemble a hit list themselves (the sharded schedule, vsc2022_amd/engine.py: the kept hits of the column slices arrive at
+ * the rank that owns their query rows in no particular order).  Arrays of n entries, host or device; out_* may not alias the
+ * inputs.  max_row / max_ref: exclusive upper bounds of the row / reference numbers (<= 0: unknown, all 31 bits are
+ * sorted); they only save sort passes. */
+int vsc_sort_hits(const int32_t* hit_i, const int32_t* hit_j, const float* hit_s, int64_t n, int hits_mem,
+                  int64_t max_row, int64_t max_ref, int32_t* out_i, int32_t* out_j, float* out_s, int out_mem,
+                  int device);
+
+/* The stream of the entry points that own no handle on `device` (vsc_pair_max, vsc_sort_hits, vsc_row_normalize, vsc_tn_forward_sim):
  * as vsc_index_set_stream. */
 int vsc_set_aux_stream(int device, void* hip_stream, int own);
 

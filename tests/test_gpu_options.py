@@ -173,3 +173,29 @@ def test_knn_first_tile_threshold_matches_the_oracle(gpu, orc, k):
             D, I = idx.search(q, k)
             assert np.array_equal(I, oI), (k, nr, ft)
             assert np.array_equal(D.view(np.uint32), oD.view(np.uint32)), (k, nr, ft)
+
+
+def test_sort_hits_entry_point(gpu):
+    """vsc_sort_hits: (score desc, row asc, ref asc) of a hit list on its own -- host and device arrays, exact ties, with and
+    without the bounds that save sort passes"""
+    import ctypes
+    import torch
+    from vsc2022_amd import _lib
+    from vsc2022_amd.engine import sort_hits_device
+
+    rng = np.random.default_rng(5)
+    for n, nrow, nref in ((1, 1, 1), (1000, 17, 40), (300000, 70000, 2100000), (5000, 3, 3)):
+        i = rng.integers(0, nrow, n).astype(np.int32)
+        j = rng.integers(0, nref, n).astype(np.int32)
+        s = rng.choice(np.float32([-1.5, 0.0, 0.25, 0.25000003, 3.0]), n) if n % 2 == 0 else rng.standard_normal(n).astype(np.float32)
+        order = np.lexsort((j, i, -s.astype(np.float64)))
+        for bounds in ((nrow, nref), (0, 0)):
+            oi, oj, os_ = np.empty_like(i), np.empty_like(j), np.empty_like(s)
+            _lib.check(_lib.lib().vsc_sort_hits(i.ctypes.data, j.ctypes.data, s.ctypes.data, n, _lib.MEM_HOST, bounds[0], bounds[1],
+                                                oi.ctypes.data, oj.ctypes.data, os_.ctypes.data, _lib.MEM_HOST, 0))
+            assert np.array_equal(oi, i[order]) and np.array_equal(oj, j[order])
+            assert np.array_equal(os_.view(np.uint32), s[order].view(np.uint32))
+        dev = torch.device("cuda", 0)
+        di, dj, ds = sort_hits_device(torch.from_numpy(i).to(dev), torch.from_numpy(j).to(dev), torch.from_numpy(s).to(dev), nrow, nref)
+        assert np.array_equal(di.cpu().numpy(), i[order]) and np.array_equal(dj.cpu().numpy(), j[order])
+        assert np.array_equal(ds.cpu().numpy(), s[order])

@@ -117,6 +117,47 @@ int vsc_pair_max(const int32_t* hit_i, const int32_t* hit_j, const float* hit_s,
     return VSC_OK;
 }
 
+int vsc_sort_hits(const int32_t* hit_i, const int32_t* hit_j, const float* hit_s, int64_t n, int hits_mem, int64_t max_row,
+                  int64_t max_ref, int32_t* out_i, int32_t* out_j, float* out_s, int out_mem, int device) {
+    if (n < 0 || (n > 0 && (!hit_i || !hit_j || !hit_s || !out_i || !out_j || !out_s))) {
+        set_error("vsc_sort_hits: invalid argument");
+        return VSC_ERR_INVALID;
+    }
+    if (n == 0) return VSC_OK;
+    VSC_TRY(check_device(device));
+    VSC_HIP(hipSetDevice(device));
+    DeviceCtx* c = device_ctx(device);
+    if (!c) {
+        set_error("vsc_sort_hits: cannot create device context");
+        return VSC_ERR_HIP;
+    }
+    std::lock_guard<std::mutex> lk(c->mu);
+    Workspace& ws = c->ws;
+    const void *di, *dj, *ds;
+    VSC_TRY(to_device(hit_i, (size_t)n * 4, hits_mem, ws.hA[0], &di, c->stream));
+    VSC_TRY(to_device(hit_j, (size_t)n * 4, hits_mem, ws.hA[1], &dj, c->stream));
+    VSC_TRY(to_device(hit_s, (size_t)n * 4, hits_mem, ws.hA[2], &ds, c->stream));
+    int32_t *oi = out_i, *oj = out_j;
+    float* os = out_s;
+    if (out_mem == VSC_MEM_HOST) {
+        for (int k = 0; k < 3; ++k) VSC_TRY(ws.out[k].reserve((size_t)n * 4));
+        oi = ws.out[0].as<int32_t>();
+        oj = ws.out[1].as<int32_t>();
+        os = ws.out[2].as<float>();
+    }
+    const int64_t all = (int64_t)1 << 31;
+    int64_t m = 0;
+    VSC_TRY(sort_hits_topk((const int32_t*)di, (const int32_t*)dj, (const float*)ds, n, n, max_row > 0 ? max_row : all,
+                           max_ref > 0 ? max_ref : all, ws.w0, ws.w1, ws.w2, ws.w3, ws.tmp, oi, oj, os, 0, &m, c->stream));
+    if (out_mem == VSC_MEM_HOST) {
+        VSC_HIP(hipMemcpyAsync(out_i, oi, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
+        VSC_HIP(hipMemcpyAsync(out_j, oj, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
+        VSC_HIP(hipMemcpyAsync(out_s, os, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
+    }
+    VSC_HIP(hipStreamSynchronize(c->stream));
+    return VSC_OK;
+}
+
 int vsc_row_normalize(const float* x, int64_t n, int dim, int x_mem, float* out, int out_mem, int device) {
     if (n < 0 || dim <= 0 || (n > 0 && (!x || !out))) {
         set_error("vsc_row_normalize: invalid argument");

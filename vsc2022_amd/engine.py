@@ -83,6 +83,20 @@ def row_normalize_device(x: torch.Tensor) -> torch.Tensor:
     return out
 
 
+def sort_hits_device(hi: torch.Tensor, hj: torch.Tensor, hs: torch.Tensor, max_row: int = 0, max_ref: int = 0):
+    """A hit list in HBM ordered by (score desc, row asc, ref asc) -- vsc/index.py:158-165 -- by libvscmi's radix sorts
+    (`vsc_sort_hits`); max_row / max_ref: exclusive bounds of the row / reference numbers (they save sort passes)."""
+    n = int(hs.numel())
+    hi, hj, hs = hi.to(torch.int32).contiguous(), hj.to(torch.int32).contiguous(), hs.to(torch.float32).contiguous()
+    oi, oj, os_ = torch.empty_like(hi), torch.empty_like(hj), torch.empty_like(hs)
+    if n:
+        _after_torch(hs.device)
+        _lib.check(_lib.lib().vsc_sort_hits(_dev_ptr(hi), _dev_ptr(hj), _dev_ptr(hs), n, _lib.MEM_DEVICE, int(max_row),
+                                            int(max_ref), _dev_ptr(oi), _dev_ptr(oj), _dev_ptr(os_), _lib.MEM_DEVICE,
+                                            hs.device.index))
+    return oi, oj, os_
+
+
 class DeviceScoreNormalizer:
     """`score_normalize` (vsc/baseline/score_normalization.py:31-105) on frame-row tensors that stay in HBM,
     with the noise set resident: built once, then applied to any number of query / reference batches.
@@ -506,10 +520,7 @@ class DeviceMatcher:
         t0 = clock()
         # (score desc, row asc, ref asc): the order the reference's stable sort leaves, then the global cut at K
         if hs.numel():
-            o1 = torch.sort(hi.to(torch.int64) * max(nr, 1) + hj.to(torch.int64), stable=True).indices
-            o2 = torch.sort(hs[o1], descending=True, stable=True).indices
-            order = o1[o2]
-            hi, hj, hs = hi[order], hj[order], hs[order]
+            hi, hj, hs = sort_hits_device(hi, hj, hs, max_row=nq_loc, max_ref=nr)
         n_take, tau, info = vdist.distributed_prefix_select(hs, K, group, ties="rank", return_info=True)
         stats["t_final"] = clock() - t0
         self.last_shard_stats = stats
