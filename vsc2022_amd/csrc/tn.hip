@@ -33,6 +33,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 template <class IDX>
 struct TnStateT {
     int lq, lr, top, ms, n_nodes, sink, sink_q, sink_r;
+    unsigned top_magic;  // ceil(2^32 / top): (x * top_magic) >> 32 == x / top for x < 2^28 (top <= 16) -- node ids are far below
     float min_sim;
     const IDX* tidx;
     const float* tsim;
@@ -41,9 +42,13 @@ struct TnStateT {
 };
 
 template <class IDX>
-__device__ __forceinline__ int tn_node_q(const TnStateT<IDX>& g, int v) { return v == 0 ? -1 : (v - 1) / g.top; }
+__device__ __forceinline__ int tn_div_top(const TnStateT<IDX>& g, int x) {
+    return g.top == 1 ? x : (int)__umulhi((unsigned)x, g.top_magic);  // (2^32 / 1 does not fit the magic word)
+}
 template <class IDX>
-__device__ __forceinline__ int tn_node_k(const TnStateT<IDX>& g, int v) { return (v - 1) % g.top; }
+__device__ __forceinline__ int tn_node_q(const TnStateT<IDX>& g, int v) { return v == 0 ? -1 : tn_div_top(g, v - 1); }
+template <class IDX>
+__device__ __forceinline__ int tn_node_k(const TnStateT<IDX>& g, int v) { return (v - 1) - tn_div_top(g, v - 1) * g.top; }
 template <class IDX>
 __device__ __forceinline__ int tn_node_r(const TnStateT<IDX>& g, int v) { return v == 0 ? -1 : g.tidx[v - 1]; }
 
@@ -317,6 +322,7 @@ __global__ __launch_bounds__(64) void tn_pair_kernel(TnPairArgs a) {
     g.sink_q = lq - 1;
     g.sink_r = tidx[(lq - 1) * top + top - 1];
     g.min_sim = a.prm.min_sim;
+    g.top_magic = (unsigned)((0x100000000ull + (unsigned)top - 1u) / (unsigned)top);
     g.tidx = tidx; g.tsim = tsim; g.ilo = ilo; g.ihi = ihi;
 
     // ---- 3. intermediate ranges: one lane per source row q_i, steps d are sequential ----
@@ -657,9 +663,12 @@ __global__ __launch_bounds__(64) void tn_pair_kernel(TnPairArgs a) {
             // MaxSim box score: max of sims[q_lo:q_hi, r_lo:r_hi] (half-open, localization.py:91) - bias
             float m = -INFINITY;
             const int w = br1 - br0, h = bq1 - bq0;
-            for (int64_t x = lane; x < (int64_t)w * h; x += 64) {
-                const float s = sims[(int64_t)(bq0 + x / w) * lr + br0 + x % w];
-                m = s > m ? s : m;
+            for (int y = 0; y < h; ++y) {  // (row by row: no 64-bit divisions per element)
+                const float* srow = sims + (int64_t)(bq0 + y) * lr + br0;
+                for (int x = lane; x < w; x += 64) {
+                    const float s = srow[x];
+                    m = s > m ? s : m;
+                }
             }
 #pragma unroll
             for (int off2 = 32; off2 >= 1; off2 >>= 1) {
