@@ -101,6 +101,9 @@ int vsc_device_count(void);
  *                             a per-wave lower bound of the row's k-th largest score of that tile; A/B)
  *   VSC_DEBUG_I8 / VSC_DEBUG_SCREEN: notes on stderr when a search falls back from int8 / per screen launch
  *   VSC_TOPK_SHORTCUT=0|1|2   proven top-K route of vsc_index_global_topk (see there); VSC_TOPK_SAMPLE=<rows> (4096)
+ *   density_hint=<d>          (option only) expected hit density of the batches of the next thresholded searches; > 0: the
+ *                             exact / fp16 / int8 rule uses it instead of K / (rows x references) -- the sharded schedule calls the
+ *                             seeded search once per batch with a generous budget K and knows the density the batch will have
  *   VSC_SORT_HITS=0           vsc_index_global_topk / _seeded (inner product) return their hits as a SET, in the kept
  *                             list's order, instead of (score desc, row asc, ref asc): the column-sharded schedule joins
  *                             a batch's hits to a list that is sorted once at the end.  min(n, K) entries come back; K

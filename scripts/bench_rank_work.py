@@ -97,6 +97,7 @@ for W in args.worlds:
     def search_rows(r0, r1, radius):
         parts = []
         for r, (c0, c1, idx) in enumerate(slices):
+            idx.set_option("density_hint", min(1.0, K / (float(r0) * nr)) if r0 > 0 else 1.0)   # (as the engine does)
             t0 = sync()
             i, j, s = matcher._rows_above(qn[r0:r1], radius, head_budget(r0, r1 - r0, 1.3 / W), index=idx)
             t_slice[r] += sync() - t0

@@ -130,7 +130,7 @@ static const OptionName kOptions[] = {
     {"knn_levels", "VSC_KNN_LEVELS"}, {"knn_subset", "VSC_KNN_SUBSET"}, {"knn_s0div", "VSC_KNN_S0DIV"},
     {"knn_s0min", "VSC_KNN_S0MIN"}, {"knn_ratio", "VSC_KNN_RATIO"}, {"knn_nchunk", "VSC_KNN_NCHUNK"}, {"knn_first_tile", "VSC_KNN_FIRST_TILE"},
     {"cand_budget", "VSC_CAND_BUDGET"}, {"debug_i8", "VSC_DEBUG_I8"}, {"debug_screen", "VSC_DEBUG_SCREEN"},
-    {"topk_shortcut", "VSC_TOPK_SHORTCUT"}, {"topk_sample", "VSC_TOPK_SAMPLE"}, {"sort_hits", "VSC_SORT_HITS"},
+    {"topk_shortcut", "VSC_TOPK_SHORTCUT"}, {"topk_sample", "VSC_TOPK_SAMPLE"}, {"sort_hits", "VSC_SORT_HITS"}, {"density_hint", "VSC_DENSITY_HINT"},
 };
 
 // Options that decide which images of the reference rows are kept can only change while the index is empty.
@@ -200,6 +200,7 @@ static int apply_option(vsc_index* idx, const char* name, double v) {
     if (is("topk_shortcut")) { const int m = (int)v; if (m < 0 || m > 2) goto bad; idx->topk_shortcut = m; return VSC_OK; }
     if (is("topk_sample")) { if (!(v >= 2.0)) goto bad; idx->topk_sample_rows = (int64_t)v; return VSC_OK; }
     if (is("sort_hits")) { idx->sort_hits = v != 0.0; return VSC_OK; }
+    if (is("density_hint")) { if (!(v >= 0.0)) goto bad; idx->density_hint = v; return VSC_OK; }
     set_error("vsc_index_set_option: unknown option '%s'", name);
     return VSC_ERR_INVALID;
 bad:
@@ -240,6 +241,7 @@ static int read_option(const vsc_index* idx, const char* name, double* out) {
     else if (is("topk_shortcut")) *out = idx->topk_shortcut;
     else if (is("topk_sample")) *out = (double)idx->topk_sample_rows;
     else if (is("sort_hits")) *out = idx->sort_hits;
+    else if (is("density_hint")) *out = idx->density_hint;
     else if (is("last_topk_route")) *out = idx->last_topk_route;  // (read-only: what the last vsc_index_global_topk did)
     else {
         set_error("vsc_index_get_option: unknown option '%s'", name);

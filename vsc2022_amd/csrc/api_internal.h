@@ -132,6 +132,7 @@ struct vsc_index {
     // fp32 value at the cut), the proof never succeeds there.  VSC_TOPK_SHORTCUT: 0 (default) the schedule, 1 large query
     // sets, 2 wherever the route is defined (tests)
     int topk_shortcut = 0;
+    double density_hint = 0.0;        // option density_hint: expected hit density of the next thresholded searches (0: from K)
     bool sort_hits = true;            // VSC_SORT_HITS=0: thresholded searches return their kept hits in list order (a SET)
     int64_t topk_sample_rows = 4096;  // VSC_TOPK_SAMPLE: rows of the strided sample that seeds the radius
     int last_topk_route = 0;          // get_option("last_topk_route"): 0 schedule, 1 proven route, 2 proven route tried, schedule replayed

@@ -396,12 +396,14 @@ static int global_topk_impl(vsc_index_t* idx, const float* q, int64_t nq, int q_
             // K / (i0 * ntotal) of this batch's pairs are hits.  While that density is high the
             // exact kernel is cheaper than pre-filtering and re-scoring nearly everything
             // (exact: ~7.5 ps per pair; re-scoring: ~0.5 ns per candidate; measured optimum near 2 % with the segment-wise exact stage, 5 % with the sorted one).
-            const bool f16 = idx->prefilter_force ||
-                             (idx->prefilter && seen > 0 && (double)K < idx->prefilter_density * seen * (double)idx->ntotal);
+            // (option "density_hint": the caller knows the batch's expected hit density better than K / (rows x refs) says --
+            // the sharded schedule's budgets K are several times the hits it expects, which sent int8 batches to fp16)
+            const double dens = idx->density_hint > 0.0 ? idx->density_hint
+                                                         : (seen > 0 ? (double)K / (seen * (double)idx->ntotal) : 1.0);
+            const bool f16 = idx->prefilter_force || (idx->prefilter && (seen > 0 || idx->density_hint > 0.0) && dens < idx->prefilter_density);
             // ... and once it is low enough that the int8 kernel's 4-5x candidates cost less than the fp16 kernel's
             // second half (the bound of 8-bit rows is ~16x looser), the batch runs on int8
-            const bool i8 = f16 && allow_i8 &&
-                            (idx->i8_mode == 2 || (seen > 0 && (double)K < idx->i8_density * seen * (double)idx->ntotal));
+            const bool i8 = f16 && allow_i8 && (idx->i8_mode == 2 || dens < idx->i8_density);
             used_i8 |= i8;
             VSC_TRY(enqueue_batch(idx, qp, i0, i1, cap, f16, i8));
             hipEvent_t stop;

@@ -482,6 +482,9 @@ class DeviceMatcher:
         def search_rows(r0, r1, radius):
             if by_cols and r0 < head_end:
                 t0 = clock()
+                # the exact / fp16 / int8 rule of the single-process schedule for this batch (K / (rows so far x references));
+                # the budget below is several times the hits expected and would send int8 batches to the fp16 kernel
+                col_index.set_option("density_hint", min(1.0, K / (float(r0) * nr)) if r0 > 0 else 1.0)
                 i, j, sc = self._rows_above(head_q[r0:r1], radius, head_budget(r0, r1 - r0, 1.3 / world), index=col_index)
                 stats["on_demand"] += 1
                 stats["t_on_demand"] = stats.get("t_on_demand", 0.0) + clock() - t0
