@@ -89,6 +89,7 @@ for W in args.worlds:
         idx.add(matcher.ref_feats[c0:c1])
         slices.append((c0, c1, idx))
     t_slice = [0.0] * W
+    per_batch = {}
     t_misc = {"events_and_counts": 0.0}
 
     def head_budget(r0, n_here, share):
@@ -100,7 +101,10 @@ for W in args.worlds:
             idx.set_option("density_hint", min(1.0, K / (float(r0) * nr)) if r0 > 0 else 1.0)   # (as the engine does)
             t0 = sync()
             i, j, s = matcher._rows_above(qn[r0:r1], radius, head_budget(r0, r1 - r0, 1.3 / W), index=idx)
-            t_slice[r] += sync() - t0
+            dt = sync() - t0
+            t_slice[r] += dt
+            if r == 0:
+                per_batch[(r0, r1)] = dt
             parts.append((i + r0, j + c0, s))
         return (torch.cat([p[0] for p in parts]), torch.cat([p[1] for p in parts]), torch.cat([p[2] for p in parts]))
 
@@ -135,6 +139,8 @@ for W in args.worlds:
     rec["rank_gpu_work_ms"] = round(rec["score_norm_ms"] + rec["search_slice_max_ms"] + (rec["events_and_counts_all_lists_ms"]
                                     + rec["final_sort_all_hits_ms"]) / W + rec["pair_max_ms"] + rec["tn_ms"], 1)
     out["worlds"][str(W)] = rec
+    if os.environ.get("VSC_RANK_WORK_BATCHES") == "1":   # slice 0's time per batch of the schedule (second walk)
+        print(W, "batches", " ".join(f"{a}:{dt * 1e3:.2f}" for (a, b), dt in sorted(per_batch.items())), flush=True)
     print(W, json.dumps(rec), flush=True)
     del slices
     torch.cuda.empty_cache()
