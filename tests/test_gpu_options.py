@@ -52,7 +52,10 @@ def test_options_round_trip_and_validation(gpu):
 
 @pytest.mark.parametrize("opts", [{"prefilter": 0}, {"prefilter": 2}, {"prefilter": 2, "i8": 2}, {"prefilter": 2, "i8": 0},
                                   {"prefilter": 2, "i8": 2, "i8p_pair": 2}, {"prefilter": 2, "f16_kernel": 1, "i8": 0},
-                                  {"prefilter": 2, "i8": 2, "i8_sort": 0, "rescore_sort": 0}])
+                                  {"prefilter": 2, "i8": 2, "i8_sort": 0, "rescore_sort": 0},
+                                  # density_hint: the caller's expected hit density picks the route of every batch
+                                  # (1: exact kernel, 1e-3: fp16 pre-filter, 1e-9: int8 pre-filter)
+                                  {"density_hint": 1.0}, {"density_hint": 1e-3}, {"density_hint": 1e-9}])
 def test_every_route_chosen_by_option_matches_the_oracle(gpu, orc, opts):
     """the routes the test-suite forces through the environment, forced through vsc_index_set_option instead"""
     from vsc2022_amd import _lib
