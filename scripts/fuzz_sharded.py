@@ -89,7 +89,7 @@ def main():
                     rf=(lo_f, lo_f + int(rng.integers(0, 40))), planted=float(rng.uniform(0.0, 0.5)),
                     static=float(rng.choice([0.0, 0.05, 0.3])), grid=int(rng.choice([0, 0, 2, 4, 8])),
                     bias=float(rng.choice([0.0, 0.0, 0.5])),
-                    seed_rows=int(rng.choice([0, 8, 40, 150, 600])))
+                    seed_rows=int(rng.choice([0, 0, 0, 8, 40, 150, 600])))
         world = int(rng.integers(2, 5))
         q, r = dataset(case)
         if len(q) < world:
