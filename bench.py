@@ -734,7 +734,7 @@ def main():
                 "unit": "GB/s", "bound": "hbm"},
             "tn_pair_kernel (Temporal Network, one pair per wavefront)": {
                 "ms_per_step": tn_ms / steps, "achieved": _rate(tn_bytes, tn_ms, 1e9), "peak": HBM_PEAK_GBS,
-                "unit": "GB/s", "bound": "hbm (latency-bound in practice)",
+                "unit": "GB/s", "bound": "hbm by its bytes (instruction-issue-bound in practice: DESIGN.md 8.6)",
                 "note": "algorithmic bytes = 4 * dim * (Lq + Lr) per pair + boxes"},
         }
         if nprof is not None:

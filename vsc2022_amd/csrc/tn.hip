@@ -17,7 +17,7 @@
 // identical results.
 //
 // Bound: HBM/L2 (algorithmic bytes per pair = 4*dim*(Lq+Lr) read + 16 B/box written); in practice
-// latency/occupancy-bound -- see DESIGN.md.
+// instruction-issue-bound (78 k vector + 62 k scalar instructions per pair at the reference's parameters) -- DESIGN.md 8.6.
 #include <cfloat>
 
 #include "kernels.h"
