@@ -65,6 +65,9 @@ def parse():
                          "GPUs with score normalisation in the timed step (configs[3])")
     ap.add_argument("--total-query-videos", type=int, default=40000, help="--scaling strong: query videos of the whole job")
     ap.add_argument("--noise-rows", type=int, default=0, help="score-normalisation noise rows (default: as many as references)")
+    ap.add_argument("--data", default="gaussian",
+                    choices=("gaussian", "clusters", "powerlaw", "offset", "temporal", "neardup"),
+                    help="distribution class of the synthetic descriptors (vsc2022_amd/synth.py); the headline is gaussian")
     ap.add_argument("--launch-check", action="store_true",
                     help="only launch the ranks, form the process group (gloo, no GPU needed) and report it")
     return ap.parse_args()
@@ -101,17 +104,13 @@ def process_group_check(torch, dist, world, rank, local_rank, dev, share_gpu):
             "launcher": "bench.py self-launch" if os.environ.get("VSC_BENCH_SELF_LAUNCHED") == "1" else "external"}
 
 
-def synth_on_device(torch, dev, seed, n_vid, frames, dim, static_frac=0.01):
-    g = torch.Generator(device=dev)
-    g.manual_seed(seed)
-    x = torch.randn((n_vid * frames, dim), generator=g, device=dev, dtype=torch.float32)
-    x /= x.norm(dim=1, keepdim=True)
-    n_static = int(round(static_frac * n_vid))
-    if n_static:
-        vids = torch.randperm(n_vid, generator=g, device=dev)[:n_static]
-        xv = x.view(n_vid, frames, dim)
-        xv[vids] = xv[vids, :1].expand(-1, frames, -1).clone()
-    return x
+def synth_on_device(torch, dev, seed, n_vid, frames, dim, static_frac=0.01, dist="gaussian", geometry=None,
+                    duplicates=False):
+    """[n_vid * frames, dim] unit rows in HBM (vsc2022_amd/synth.py:device_rows): a function of the seed and the shape
+    alone.  dist: the distribution class (--data); "gaussian" is the generator every earlier round measured."""
+    from vsc2022_amd import synth
+
+    return synth.device_rows(torch, dev, seed, n_vid, frames, dim, static_frac, dist, geometry, duplicates)
 
 
 def plant_copies(torch, dev, seed, q, n_qvid, qf, r, n_rvid, rf, frac=0.2, noise=0.05):
@@ -135,6 +134,30 @@ def plant_copies(torch, dev, seed, q, n_qvid, qf, r, n_rvid, rf, frac=0.2, noise
         q[qs : qs + L] = seg / seg.norm(dim=1, keepdim=True)
         gt.append((int(qv[k]), int(rv[k])))
     return gt
+
+
+def result_digest(torch, matcher, res):
+    """What the job computed, as hashes that do not depend on the number of ranks: sha256 over the schedule's final
+    radius, the candidate table (query video, reference video, score bits -- vsc/baseline/sscd_baseline.py:98-115) and
+    the gathered table of localised segments (candidate, box, MaxSim bits -- :139-152), in the single-process order.
+    `--gpus 1` and `--gpus N` runs of the same command line must print the same `result_digest`."""
+    import hashlib
+
+    boxes = matcher.gather_boxes(res)
+    parts = {
+        "radius": np.array([res.radius], dtype=np.float32).tobytes(),
+        "candidates": b"".join(t.contiguous().cpu().numpy().tobytes() for t in
+                               (res.cand_q.to(torch.int32), res.cand_r.to(torch.int32),
+                                res.cand_score.contiguous().view(torch.int32))),
+        "boxes": boxes.contiguous().cpu().numpy().tobytes(),
+    }
+    whole = hashlib.sha256()
+    out = {}
+    for k, v in parts.items():
+        whole.update(v)
+        out[k] = hashlib.sha256(v).hexdigest()[:16]
+    return {"result_digest": whole.hexdigest()[:32], "parts": out, "n_boxes": int(boxes.shape[0]),
+            "tie_on_cut": bool(res.tie_on_cut), "ties_dropped": bool(res.ties_dropped)}
 
 
 def host_cores() -> int:
@@ -443,16 +466,8 @@ def extra_legs(args, torch, dev, matcher, queries, n_qv, qf, n_rv, rf, dim):
                                    "(pre-filtered exact k-NN), beta 1.2; noise index resident")
     del qn, norm
     torch.cuda.empty_cache()
-    # ---- the all-fp32 route (VSC_PREFILTER=0): one search of the same shape on the exact fp32 MFMA kernel alone
-    old = os.environ.get("VSC_PREFILTER")
-    os.environ["VSC_PREFILTER"] = "0"
-    try:
-        exact = FlatIndex(dim, _lib.METRIC_INNER_PRODUCT, dev.index)
-    finally:
-        if old is None:
-            os.environ.pop("VSC_PREFILTER", None)
-        else:
-            os.environ["VSC_PREFILTER"] = old
+    # ---- the all-fp32 route (option "prefilter" = 0): one search of the same shape on the exact fp32 MFMA kernel alone
+    exact = FlatIndex(dim, _lib.METRIC_INNER_PRODUCT, dev.index, options={"prefilter": 0})
     exact.add(matcher.ref_feats)
     exact.profile(True)
     exact.profile_read(reset=True)
@@ -531,6 +546,92 @@ def config2_shape_leg(args, torch, dev, dim):
     return out
 
 
+def distribution_leg(args, torch, dev, dim, dist, score_norm=False, exhaustive=True, steps=2):
+    """BASELINE configs[1]'s shape (8000 query videos x 25 frames vs 2 M reference frames) on descriptors of another
+    distribution class (vsc2022_amd/synth.py): what the pre-filters' bounds, the density rules and
+    the 1-NN ranges -- all tuned on isotropic rows -- do on clustered / anisotropic / shifted data.  Reports ms per
+    step, candidates handed to the exact stage per emitted hit, launches and ms per route, int8 -> fp16 fall-backs, and
+    (exhaustive) whether the default route returns the all-fp32 route's K hits bit for bit."""
+    import time as _t
+
+    from vsc2022_amd import _lib, synth
+    from vsc2022_amd.engine import DeviceMatcher, DeviceScoreNormalizer
+    from vsc2022_amd.vsc.index import FlatIndex
+
+    n_qv, qf, n_rv, rf = args.query_videos, args.query_frames, args.ref_videos, args.ref_frames
+    geo = None if dist == "gaussian" else synth.Geometry(dist, dim, args.seed)
+    refs = synth_on_device(torch, dev, args.seed, n_rv, rf, dim, dist=dist, geometry=geo, duplicates=True)
+    queries = synth_on_device(torch, dev, args.seed + 1000, n_qv, qf, dim, dist=dist, geometry=geo)
+    gt = plant_copies(torch, dev, args.seed + 2000, queries, n_qv, qf, refs, n_rv, rf)
+    out = {"data": dist, "score_normalised": bool(score_norm)}
+    bias = 0.0
+    if score_norm:
+        noise = synth_on_device(torch, dev, args.seed + 77, n_rv * rf, 1, dim, static_frac=0.0, dist=dist, geometry=geo)
+        norm = DeviceScoreNormalizer(noise, beta=1.2)
+        del noise
+        norm.noise_index.profile(True)
+        norm.queries(queries[:4096])
+        norm.noise_index.profile_read(reset=True)
+        torch.cuda.synchronize()
+        t0 = _t.perf_counter()
+        queries_n = norm.queries(queries)
+        torch.cuda.synchronize()
+        out["score_normalize_queries_ms"] = 1e3 * (_t.perf_counter() - t0)
+        np_ = norm.noise_index.profile_read(reset=True)
+        out["score_normalize_candidates_per_row"] = np_["candidates"] / float(n_qv * qf)
+        out["score_normalize_i8_fallbacks"] = int(norm.noise_index.get_option("i8_fallbacks"))
+        refs, queries, bias = norm.refs(refs), queries_n, 0.5
+        del norm
+        torch.cuda.empty_cache()
+    m = DeviceMatcher(refs, np.arange(n_rv + 1, dtype=np.int64) * rf, dev.index)
+    m.set_queries(queries, np.arange(n_qv + 1, dtype=np.int64) * qf)
+    res = m.match(bias=bias)
+    m.index.profile(True)
+    m.index.profile_read(reset=True)
+    _aux(0), _aux(1)
+    torch.cuda.synchronize()
+    t0 = _t.perf_counter()
+    for _ in range(steps):
+        res = m.match(bias=bias)
+    torch.cuda.synchronize()
+    dt = (_t.perf_counter() - t0) / steps
+    p = m.index.profile_read(reset=True)
+    K = 1200 * n_qv
+    planted = set(gt)
+    cq, cr = res.cand_q.cpu().numpy(), res.cand_r.cpu().numpy()
+    nbox = res.nbox.cpu().numpy()
+    loc = set(zip(cq[: res.n_localized][nbox > 0].tolist(), cr[: res.n_localized][nbox > 0].tolist()))
+    out.update({
+        "ms_per_step": 1e3 * dt, "query_videos_per_s": n_qv / dt, "hits": res.n_hits, "matches": res.n_matches,
+        "radius": res.radius, "candidates_per_hit": p["candidates"] / float(max(res.n_hits, 1)),
+        "planted_in_candidates": len(planted & set(zip(cq.tolist(), cr.tolist()))) / float(max(len(planted), 1)),
+        "planted_localised": len(planted & loc) / float(max(len(planted), 1)),
+        "launches_per_step": {"int8": p["i8_launches"] / steps, "fp16": p["f16_launches"] / steps, "exact_fp32": p["sim_launches"] / steps},
+        "kernel_ms_per_step": {"int8_prefilter": p["i8_ms"] / steps, "int8_preamble": p.get("i8_prep_ms", 0.0) / steps,
+                               "fp16_prefilter": p["f16_ms"] / steps, "exact_fp32": p["sim_ms"] / steps,
+                               "exact_rescore": p["rescore_ms"] / steps, "select": p["select_ms"] / steps,
+                               "final_sort": p["sort_ms"] / steps, "tn": _aux(1)[0] / steps},
+        "int8_prefilter_tops": _rate(p["i8_flops"], p["i8_ms"], 1e12),
+        "i8_fallbacks": int(m.index.get_option("i8_fallbacks")),
+        "i8_enabled": int(m.index.get_option("i8")),
+    })
+    if exhaustive:
+        exact = FlatIndex(int(refs.shape[1]), _lib.METRIC_INNER_PRODUCT, dev.index, options={"prefilter": 0})
+        exact.add(m.ref_feats)
+        torch.cuda.synchronize()
+        t0 = _t.perf_counter()
+        ei, ej, es, erad = exact.global_topk(m.q_feats, K, device_out=True)
+        torch.cuda.synchronize()
+        out["all_fp32_search_ms"] = 1e3 * (_t.perf_counter() - t0)
+        di, dj, ds, drad = m.search(K)
+        out["routes_identical"] = bool(drad == erad and ds.numel() == es.numel() and torch.equal(di, ei) and torch.equal(dj, ej)
+                                       and torch.equal(ds.view(torch.int32), es.view(torch.int32)))
+        del exact, ei, ej, es
+    del m, refs, queries
+    torch.cuda.empty_cache()
+    return out
+
+
 def main():
     args = parse()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -588,16 +689,25 @@ def main():
     else:
         n_qv, qv_base = args.query_videos, rank * args.query_videos
         n_qv_total = n_qv * world
-    refs = synth_on_device(torch, dev, args.seed, n_rv, rf, dim)
-    queries = synth_on_device(torch, dev, args.seed + 1000 + rank, n_qv, qf, dim)
-    plant_copies(torch, dev, args.seed + 2000 + rank, queries, n_qv, qf, refs, n_rv, rf)
+    # The WHOLE job's inputs are a function of the seed alone: every rank generates the global query set and keeps its
+    # slice, so `--gpus 1` and `--gpus N` see the same data and `result_digest` below can be compared across world sizes
+    # ("1-GPU vs 2/4/8-GPU outputs identical")
+    from vsc2022_amd import synth
+
+    geo = None if args.data == "gaussian" else synth.Geometry(args.data, dim, args.seed)
+    refs = synth_on_device(torch, dev, args.seed, n_rv, rf, dim, dist=args.data, geometry=geo, duplicates=True)
+    queries_all = synth_on_device(torch, dev, args.seed + 1000, n_qv_total, qf, dim, dist=args.data, geometry=geo)
+    plant_copies(torch, dev, args.seed + 2000, queries_all, n_qv_total, qf, refs, n_rv, rf)
+    queries = queries_all[qv_base * qf : (qv_base + n_qv) * qf].clone()
+    del queries_all
     r_off = np.arange(n_rv + 1, dtype=np.int64) * rf
     q_off = np.arange(n_qv + 1, dtype=np.int64) * qf
     norm = None
     if strong:
         # configs[3]: both sides score-normalised against the noise set (resident state, like the reference index);
         # the QUERY side of it belongs to every query set and is timed
-        noise = synth_on_device(torch, dev, args.seed + 77, args.noise_rows or n_rv * rf, 1, dim, static_frac=0.0)
+        noise = synth_on_device(torch, dev, args.seed + 77, args.noise_rows or n_rv * rf, 1, dim, static_frac=0.0,
+                                dist=args.data, geometry=geo)
         norm = DeviceScoreNormalizer(noise, beta=1.2)
         del noise
         matcher = DeviceMatcher(norm.refs(refs), r_off, local_rank)
@@ -641,6 +751,7 @@ def main():
     nprof = norm.noise_index.profile_read(reset=True) if norm is not None else None
     pm_ms, pm_calls, pm_bytes = _aux(0)
     tn_ms, tn_calls, tn_bytes = _aux(1)
+    digest = result_digest(torch, matcher, res)   # (collective at N > 1: every rank takes part, all hold the same tables)
     if use_dist:
         t = torch.tensor([dt], dtype=torch.float64, device="cpu" if share_gpu else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -768,7 +879,12 @@ def main():
             "dtype": "fp32 results; int8 / fp16 MFMA pre-filters",
             "dtype_note": "every reported score is the exact fp32 fma chain (bit-identical to the all-fp32 "
                           "path); int8 and fp16 MFMA only pre-filter pairs, each with a rigorous error bound",
-            "data": "synthetic",
+            "data": "synthetic" if args.data == "gaussian" else f"synthetic ({args.data})",
+            "result_digest": digest["result_digest"],
+            "result_digest_parts": dict(digest["parts"], n_boxes=digest["n_boxes"], tie_on_cut=digest["tie_on_cut"],
+                                        ties_dropped=digest["ties_dropped"],
+                                        note="sha256 of (final radius | candidate table | localised segments): identical for "
+                                             "--gpus 1 and --gpus N runs of the same command line"),
             "process_group": pg,
             "config": {
                 "workload": workload,
@@ -810,6 +926,8 @@ def main():
                         del matcher, norm
                         torch.cuda.empty_cache()
                         out["extra"] = {"config2_shape": config2_shape_leg(args, torch, dev, dim)}
+                        # non-Gaussian descriptors: the same shape on a cluster mixture
+                        out["extra"]["clustered"] = distribution_leg(args, torch, dev, dim, "clusters")
                     else:
                         out["extra"] = extra_legs(args, torch, dev, matcher, queries, n_qv, qf, n_rv, rf, dim)
                         ms_fresh = out["ms_per_step"] + out["extra"]["set_queries_ms"]

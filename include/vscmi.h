@@ -123,7 +123,10 @@ int vsc_index_get_option(const vsc_index_t* idx, const char* name, double* value
  * of the handle's own non-blocking stream: work the caller queued on that stream before a call -- the kernel that
  * produced the query rows -- is then ordered before the library's reads without a device-wide synchronisation.
  * hip_stream = NULL is HIP's default stream (torch's default); own != 0 goes back to the handle's own stream (hip_stream
- * is ignored then).  Calls still return only when their results are complete. */
+ * is ignored then).  Calls still return only when their results are complete.
+ * Lifetime: a bound stream must stay alive while a call of this handle runs on it; between calls nothing of the handle
+ * is pending on it.  When the handle leaves a caller's stream (another vsc_index_set_stream, vsc_index_destroy) the
+ * library does NOT touch that stream again -- it may already be destroyed -- and drains the device instead. */
 int vsc_index_set_stream(vsc_index_t* idx, void* hip_stream, int own);
 int vsc_index_add(vsc_index_t* idx, const float* x, int64_t n, int x_mem);
 int64_t vsc_index_ntotal(const vsc_index_t* idx);

@@ -35,7 +35,9 @@ while time.time() < t_end:
     q_frames, r_frames = (qlo, qlo + int(rng.integers(0, 60))), (rlo, rlo + int(rng.integers(0, 80)))
     case = dict(seed=int(rng.integers(1 << 30)), n_query=n_query, n_ref=n_ref, dim=dim, q_frames=q_frames,
                 r_frames=r_frames, planted_frac=float(rng.uniform(0, 0.8)), static_frac=float(rng.uniform(0, 0.3)),
-                noise=float(rng.choice([0.0, 0.02, 0.05, 0.2])))
+                noise=float(rng.choice([0.0, 0.02, 0.05, 0.2])),
+                # the distribution class of the rows (vsc2022_amd/synth.py): half of the cases are not isotropic
+                dist=str(rng.choice(["gaussian"] * 5 + list(synth.DISTRIBUTIONS[1:]))))
     queries, refs, _ = synth.make_dataset(**case)
     qf, rf = synth.to_video_features(queries, VideoFeature), synth.to_video_features(refs, VideoFeature)
     K = int(rng.choice([1, 7, 100 * len(qf), 1200 * len(qf)]))

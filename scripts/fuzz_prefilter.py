@@ -25,15 +25,7 @@ rng = np.random.default_rng(args.seed)
 
 
 def make(mode, d):
-    old = os.environ.get("VSC_PREFILTER")
-    os.environ["VSC_PREFILTER"] = mode
-    try:
-        return FlatIndex(d)
-    finally:
-        if old is None:
-            os.environ.pop("VSC_PREFILTER", None)
-        else:
-            os.environ["VSC_PREFILTER"] = old
+    return FlatIndex(d, options={"prefilter": int(mode)})
 
 
 def bits(x):
@@ -50,10 +42,25 @@ while time.time() < t_end:
         d = int(rng.choice([32, 64, 128, 256]))
         nq = int(rng.integers(2000, 70000))
         nr = int(rng.integers(20000, 150000))
-    style = int(rng.integers(0, 5))
+    style = int(rng.integers(0, 9))
     q = rng.standard_normal((nq, d)).astype(np.float32)
     r = rng.standard_normal((nr, d)).astype(np.float32)
-    if style != 1:  # unit rows (descriptor-like); style 1 keeps raw gaussian rows (norm ~ sqrt(d))
+    if style >= 5 and d >= 8:
+        # styles 5-8: the non-isotropic classes of vsc2022_amd/synth.py (cluster mixture, power-law spectrum, non-zero mean +
+        # dominant coordinates, AR(1) runs) -- what the int8 / fp16 bounds and the density rules were NOT tuned on
+        from vsc2022_amd import synth
+
+        geo = synth.Geometry(("clusters", "powerlaw", "offset", "temporal")[style - 5], d, int(rng.integers(1 << 30)),
+                             n_centres=int(rng.integers(2, 200)))
+        def rows(n):
+            out, done = np.empty((n, d), dtype=np.float32), 0
+            while done < n:
+                m = int(min(n - done, rng.integers(1, 80)))
+                out[done : done + m] = geo.video_rows(rng, m)
+                done += m
+            return out
+        q, r = rows(nq), rows(nr)
+    elif style != 1:  # unit rows (descriptor-like); style 1 keeps raw gaussian rows (norm ~ sqrt(d))
         q /= np.linalg.norm(q, axis=1, keepdims=True)
         r /= np.linalg.norm(r, axis=1, keepdims=True)
     if style == 2 and nr > 20:  # duplicates -> exact ties

@@ -43,7 +43,7 @@ def dataset(case):
 
     q, r = synth.make_dataset(seed=case["seed"], n_query=case["n_query"], n_ref=case["n_ref"], dim=case["dim"],
                               q_frames=case["qf"], r_frames=case["rf"], planted_frac=case["planted"],
-                              static_frac=case["static"])[:2]
+                              static_frac=case["static"], dist=case.get("dist", "gaussian"))[:2]
     if case.get("grid"):
         for v in q + r:
             v.feature[:] = np.round(v.feature * case["grid"]) / case["grid"]
@@ -89,7 +89,9 @@ def main():
                     rf=(lo_f, lo_f + int(rng.integers(0, 40))), planted=float(rng.uniform(0.0, 0.5)),
                     static=float(rng.choice([0.0, 0.05, 0.3])), grid=int(rng.choice([0, 0, 2, 4, 8])),
                     bias=float(rng.choice([0.0, 0.0, 0.5])),
-                    seed_rows=int(rng.choice([0, 0, 0, 8, 40, 150, 600])))
+                    seed_rows=int(rng.choice([0, 0, 0, 8, 40, 150, 600])),
+                    # the distribution class of the rows (vsc2022_amd/synth.py): half of the cases are not isotropic
+                    dist=str(rng.choice(["gaussian"] * 5 + ["clusters", "powerlaw", "offset", "temporal", "neardup"])))
         world = int(rng.integers(2, 5))
         q, r = dataset(case)
         if len(q) < world:

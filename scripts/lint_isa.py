@@ -381,6 +381,10 @@ def main():
     for p in problems:
         print(p)
     print(f"lint_isa: {nf} kernels, {ni} instructions, {len(problems)} violation(s)")
+    if nf == 0:
+        # (the code-object extraction fell back to the host ELF, or the library holds no gfx950 code: nothing was checked)
+        print("lint_isa: NO gfx950 kernel was parsed -- that is a failed lint, not a clean one")
+        return 2
     return 1 if problems else 0
 
 

@@ -117,3 +117,42 @@ def pair_scores(orc, a, b, metric=None, chunk=256):
         m = orc.scores(a[k0:k0 + chunk], b[k0:k0 + chunk]) if metric is None else orc.scores(a[k0:k0 + chunk], b[k0:k0 + chunk], metric)
         out[k0:k0 + chunk] = np.diagonal(m)
     return out
+
+
+def check_localisation_sample(orc, q_feats, q_off, r_feats, r_off, pair_q, pair_r, nbox, boxes, bscore, bias, n=2000,
+                              seed=0, tn_kw=None):
+    """A stratified sample of localised pairs recomputed by the CPU oracle: orc.pair_sims (the fp32 fma chains + bias,
+    vsc/baseline/localization.py:75-80) -> orc.tn (Temporal Network) -> MaxSim score `sims[x1:x2, y1:y2].max() - bias`
+    (localization.py:88-92, half-open slice); boxes and score BITS must equal the engine's.
+
+    q_feats / r_feats: torch tensors in HBM (the rows the aligner sees); *_off: numpy video offsets; pair_q / pair_r /
+    nbox / boxes / bscore: numpy arrays of the localised pairs in rank order.  Strata: the first and the last 10 % of the
+    sample by rank, the rest split between pairs with and without boxes.  Returns (pairs checked, boxes checked)."""
+    import torch
+
+    tn_kw = dict(tn_max_step=5, min_length=4) if tn_kw is None else tn_kw
+    rng = np.random.default_rng(seed)
+    n_pairs = len(pair_q)
+    n = min(n, n_pairs)
+    edge = max(1, n // 10)
+    pick = set(range(min(edge, n_pairs))) | set(range(max(0, n_pairs - edge), n_pairs))
+    with_box, without = np.flatnonzero(nbox > 0), np.flatnonzero(nbox == 0)
+    rest = max(0, n - len(pick))
+    for pool, share in ((with_box, rest // 2), (without, rest - rest // 2)):
+        if len(pool):
+            pick |= set(rng.choice(pool, min(share, len(pool)), replace=False).tolist())
+    pick = np.array(sorted(pick), dtype=np.int64)
+    n_boxes = 0
+    for k in pick:
+        qv, rv = int(pair_q[k]), int(pair_r[k])
+        a = q_feats[int(q_off[qv]) : int(q_off[qv + 1])].cpu().numpy()
+        b = r_feats[int(r_off[rv]) : int(r_off[rv + 1])].cpu().numpy()
+        sims = orc.pair_sims(a, b, bias)
+        exp = orc.tn(sims, **tn_kw)
+        got = boxes[k, : int(nbox[k])].tolist()
+        assert got == [list(e) for e in exp], (int(k), qv, rv, got, exp)
+        for b_, (x1, y1, x2, y2) in enumerate(exp):
+            score = np.float32(sims[x1:x2, y1:y2].max() - np.float32(bias))
+            assert score.view(np.uint32) == np.float32(bscore[k, b_]).view(np.uint32), (int(k), b_, float(score), float(bscore[k, b_]))
+        n_boxes += len(exp)
+    return len(pick), n_boxes

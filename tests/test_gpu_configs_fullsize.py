@@ -25,20 +25,12 @@ def pair_scores(orc, a, b):
 
 
 def _exact_index(rows, dim):
-    """An index over `rows` whose searches run on the exact fp32 MFMA kernels alone (VSC_PREFILTER=0 is read when a
-    handle is created, include/vscmi.h): the route without bounds, candidate lists or thresholds to get wrong."""
+    """An index over `rows` whose searches run on the exact fp32 MFMA kernels alone (option "prefilter" = 0, set while
+    the handle is empty, include/vscmi.h): the route without bounds, candidate lists or thresholds to get wrong."""
     from vsc2022_amd import _lib
     from vsc2022_amd.vsc.index import FlatIndex
 
-    old = os.environ.get("VSC_PREFILTER")
-    os.environ["VSC_PREFILTER"] = "0"
-    try:
-        exact = FlatIndex(dim, _lib.METRIC_INNER_PRODUCT, 0)
-    finally:
-        if old is None:
-            os.environ.pop("VSC_PREFILTER", None)
-        else:
-            os.environ["VSC_PREFILTER"] = old
+    exact = FlatIndex(dim, _lib.METRIC_INNER_PRODUCT, 0, options={"prefilter": 0})
     exact.add(rows)
     return exact
 
@@ -128,6 +120,16 @@ def test_config4_full_pipeline_40k_query_videos(gpu, orc):
     nbox = res.nbox.cpu().numpy()
     loc = set(zip(cq[: res.n_localized][nbox > 0].tolist(), cr[: res.n_localized][nbox > 0].tolist()))
     assert len(planted & loc) >= 0.95 * len(planted)
+    # ---- a stratified sample of the 200 k localised pairs recomputed by the CPU oracle (similarity
+    # matrix by fp32 fma chains + bias 0.5, Temporal Network with the reference's tn_max_step=5 / min_length=4, MaxSim
+    # bits) -- a deterministic WRONG box would have passed the recall / determinism checks above
+    from helpers import check_localisation_sample
+
+    n_loc = res.n_localized
+    n_checked, n_boxes = check_localisation_sample(
+        orc, m.tn_q_feats, m.q_off, m.tn_ref_feats, m.r_off, cq[:n_loc], cr[:n_loc], nbox, res.boxes.cpu().numpy(),
+        res.box_score.cpu().numpy(), 0.5, n=2000, seed=11)
+    assert n_checked >= 2000 and n_boxes >= 500, (n_checked, n_boxes)
     res2 = m.match(bias=0.5)
     assert torch.equal(res.cand_q, res2.cand_q) and torch.equal(res.cand_r, res2.cand_r)
     assert torch.equal(res.cand_score.view(torch.int32), res2.cand_score.view(torch.int32))

@@ -66,21 +66,11 @@ def test_fullsize_search_properties(fullsize, orc):
 
 def _exact_index(torch, refs, dim):
     """A second index over the same rows whose every search runs on the exact fp32 MFMA kernel alone (the switches are
-    read when a handle is created, include/vscmi.h)."""
-    import os
-
+    options of the handle, set while it is empty: include/vscmi.h)."""
     from vsc2022_amd import _lib
     from vsc2022_amd.vsc.index import FlatIndex
 
-    old = os.environ.get("VSC_PREFILTER")
-    os.environ["VSC_PREFILTER"] = "0"
-    try:
-        exact = FlatIndex(dim, _lib.METRIC_INNER_PRODUCT, 0)
-    finally:
-        if old is None:
-            os.environ.pop("VSC_PREFILTER", None)
-        else:
-            os.environ["VSC_PREFILTER"] = old
+    exact = FlatIndex(dim, _lib.METRIC_INNER_PRODUCT, 0, options={"prefilter": 0})
     exact.add(refs)
     return exact
 

@@ -143,3 +143,29 @@ def test_tie_on_the_cut_happens_and_is_resolved_both_ways(gpu, tmp_path):
         assert f[0]
         seen.add((bool(f[1]), bool(f[2])))
     assert (True, True) in seen and (True, False) in seen, seen
+
+
+def test_rows_above_is_complete_with_ties_and_an_undersized_budget(gpu, orc):
+    """`DeviceMatcher._rows_above` must return EVERY pair above the radius.  The seeded search keeps
+    the re-threshold rule; with more than 2 x budget hits and a group of equal scores at the (budget+1)-th place fewer
+    than `budget` hits come back and the radius has moved -- a short list is then NOT a complete one.  Grid descriptors
+    (a handful of distinct scores), budgets far below the number of hits."""
+    from vsc2022_amd.engine import DeviceMatcher
+
+    rng = np.random.default_rng(3)
+    dim, nr, nq = 32, 3000, 96
+    r = (np.round(rng.standard_normal((nr, dim)) * 1.5) / 4).astype(np.float32)
+    q = (np.round(rng.standard_normal((nq, dim)) * 1.5) / 4).astype(np.float32)
+    m = DeviceMatcher(r, np.array([0, nr], dtype=np.int64), 0)
+    m.set_queries(q, np.array([0, nq], dtype=np.int64))
+    S = orc.scores(q, r)
+    rows = torch.from_numpy(q).cuda()
+    for radius, budget in ((-1e9, 1024), (0.0, 1024), (1.0, 2000), (float(np.sort(S.ravel())[-5000]), 1500)):
+        want = np.argwhere(S > np.float32(radius))
+        i, j, s = m._rows_above(rows, radius, budget)
+        got = np.stack([i.cpu().numpy(), j.cpu().numpy()], axis=1)
+        got = got[np.lexsort((got[:, 1], got[:, 0]))]
+        assert len(got) == len(want) and np.array_equal(got, want), (radius, budget, len(got), len(want))
+        assert np.array_equal(s.cpu().numpy().view(np.uint32),
+                              S[i.cpu().numpy(), j.cpu().numpy()].view(np.uint32))
+    assert getattr(m, "rows_above_reruns", 0) > 0   # (the undersized budgets really were undersized)

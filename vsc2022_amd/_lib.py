@@ -80,11 +80,19 @@ def build(force: bool = False) -> str:
         # a fresh library is checked for the hazards the compiler cannot see inside the kernels' inline assembly
         # (scripts/lint_isa.py: VALU-written SGPRs read by VMEM too early, registers of outstanding stream loads touched
         # before their s_waitcnt -- what a different register allocation could silently introduce)
+        # ADVISORY here: the library compiled and stays usable whatever the lint says -- a missing llvm-objdump or a
+        # false positive must not take the product down; `make lint` and tests/test_isa_lint.py are the hard gate
         import sys
 
         lint = os.path.join(os.path.dirname(_HERE), "scripts", "lint_isa.py")
         if os.path.exists(lint):
-            subprocess.check_call([sys.executable, lint, LIB_PATH])
+            try:
+                res = subprocess.run([sys.executable, lint, LIB_PATH], capture_output=True, text=True)
+                if res.returncode != 0:
+                    print(f"[vsc2022_amd] ISA lint of {LIB_PATH} reported problems (advisory; `make -C {CSRC} lint` is the "
+                          f"gate):\n{res.stdout[-2000:]}{res.stderr[-2000:]}", file=sys.stderr)
+            except OSError as exc:
+                print(f"[vsc2022_amd] ISA lint could not run ({exc}); the library is built", file=sys.stderr)
     return LIB_PATH
 
 

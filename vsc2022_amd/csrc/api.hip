@@ -243,6 +243,7 @@ static int read_option(const vsc_index* idx, const char* name, double* out) {
     else if (is("sort_hits")) *out = idx->sort_hits;
     else if (is("density_hint")) *out = idx->density_hint;
     else if (is("last_topk_route")) *out = idx->last_topk_route;  // (read-only: what the last vsc_index_global_topk did)
+    else if (is("i8_fallbacks")) *out = (double)idx->stat_i8_fallbacks;  // (read-only: searches that left int8 for fp16)
     else {
         set_error("vsc_index_get_option: unknown option '%s'", name);
         return VSC_ERR_INVALID;
@@ -327,7 +328,10 @@ int vsc_index_create(int dim, int metric, int device, vsc_index_t** out) {
 int vsc_index_destroy(vsc_index_t* idx) {
     if (!idx) return VSC_OK;
     (void)hipSetDevice(idx->device);
-    (void)hipStreamSynchronize(idx->stream);
+    // a caller's stream (vsc_index_set_stream) may be gone by now -- a torch side stream freed before the handle is
+    // collected --: its handle is never touched again; the device is drained instead
+    if (idx->stream == idx->own_stream) (void)hipStreamSynchronize(idx->own_stream);
+    else (void)hipDeviceSynchronize();
     idx->ref.release();
     idx->refh.release();
     idx->refn.release();
@@ -350,7 +354,10 @@ int vsc_index_set_stream(vsc_index_t* idx, void* hip_stream, int own) {
         return VSC_ERR_INVALID;
     }
     VSC_HIP(hipSetDevice(idx->device));
-    VSC_HIP(hipStreamSynchronize(idx->stream));  // nothing of this handle is left on the stream it leaves
+    // nothing of this handle is left on the stream it leaves (a caller's stream is not touched: it may already be
+    // destroyed -- every entry point returns with its work complete, the device-wide drain is a formality)
+    if (idx->stream == idx->own_stream) VSC_HIP(hipStreamSynchronize(idx->own_stream));
+    else (void)hipDeviceSynchronize();
     VSC_TRY(prof_collect(idx));
     idx->stream = own ? idx->own_stream : (hipStream_t)hip_stream;  // (NULL = HIP's default stream, torch's default)
     return VSC_OK;

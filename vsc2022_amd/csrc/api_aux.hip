@@ -50,7 +50,8 @@ int vsc_set_aux_stream(int device, void* hip_stream, int own) {
         return VSC_ERR_HIP;
     }
     std::lock_guard<std::mutex> lk(c->mu);
-    VSC_HIP(hipStreamSynchronize(c->stream));
+    if (c->stream == c->own_stream) VSC_HIP(hipStreamSynchronize(c->own_stream));
+    else (void)hipDeviceSynchronize();  // (a caller's stream may be gone: never touched again, see vsc_index_set_stream)
     c->stream = own ? c->own_stream : (hipStream_t)hip_stream;
     return VSC_OK;
 }
@@ -297,7 +298,8 @@ int vsc_tn_set_stream(vsc_tn_ctx_t* c, void* hip_stream, int own) {
         return VSC_ERR_INVALID;
     }
     VSC_HIP(hipSetDevice(c->device));
-    VSC_HIP(hipStreamSynchronize(c->stream));
+    if (c->stream == c->own_stream) VSC_HIP(hipStreamSynchronize(c->own_stream));
+    else (void)hipDeviceSynchronize();  // (a caller's stream may be gone: never touched again, see vsc_index_set_stream)
     c->stream = own ? c->own_stream : (hipStream_t)hip_stream;
     return VSC_OK;
 }
@@ -385,7 +387,8 @@ int vsc_tn_set_queries(vsc_tn_ctx_t* c, const float* qfeat, const int64_t* q_off
 int vsc_tn_destroy(vsc_tn_ctx_t* c) {
     if (!c) return VSC_OK;
     (void)hipSetDevice(c->device);
-    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    if (c->stream == c->own_stream) { if (c->own_stream) (void)hipStreamSynchronize(c->own_stream); }
+    else (void)hipDeviceSynchronize();
     c->qfeat.release(); c->rfeat.release(); c->d_qoff.release(); c->d_roff.release();
     c->d_pq.release(); c->d_pr.release(); c->d_work.release(); c->d_nbox.release();
     c->d_boxes.release(); c->d_bmax.release(); c->slab.release(); c->sims.release();

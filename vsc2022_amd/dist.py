@@ -132,7 +132,14 @@ def _all_gather_vec(v: torch.Tensor, group) -> torch.Tensor:
 
 @dataclass
 class SelectInfo:
-    """What the selection saw at the cut (identical on every rank)."""
+    """What the selection saw at the cut (identical on every rank).
+
+    PRECONDITION for n_ties / tie_on_cut (and n_take under ties="all"): every rank's list is COMPLETE down to tau -- the
+    selection only looks at each list's leading k_total + 1 elements and knows nothing about hits a truncated local
+    search never listed.  Callers that can hold incomplete lists (`sharded_hits`, `merge_hits`) establish completeness
+    first (`exact`, all-reduced) and read the flags from that final, exact round only; `emulate_schedule` /
+    `kth_best_unsorted` / `engine.DeviceMatcher.sharded_schedule_search` pass lists that are complete by construction
+    (every hit beyond the schedule's radius).  `total` is always exact."""
     total: int = 0          # elements over all ranks' lists
     n_above: int = 0        # ... strictly beyond tau
     n_ties: int = 0         # ... equal to tau (each rank's list counted up to its first k_total + 1 elements)

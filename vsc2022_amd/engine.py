@@ -264,7 +264,9 @@ class DeviceMatcher:
         n_out, radius = ctypes.c_int64(0), ctypes.c_float(0.0)
         self._order()
         if index is not self.index and self.torch_stream:
-            index.use_stream(torch.cuda.current_stream(self.tdev).cuda_stream)
+            st = torch.cuda.current_stream(self.tdev).cuda_stream
+            if index._stream != st:   # (vsc_index_set_stream synchronises the stream it leaves: only on a real change)
+                index.use_stream(st)
         if seed_radius is None:
             _lib.check(_lib.lib().vsc_index_global_topk(
                 index.handle, _dev_ptr(q), nq, _lib.MEM_DEVICE, int(K),
@@ -330,6 +332,7 @@ class DeviceMatcher:
         n_loc_cut = int(LOCALIZE_PER_QUERY * nq_glob)
         if not sharded:
             hi, hj, hs, radius = self.search(K)
+            self.last_hits = (hi, hj, hs)   # (views of the search's output buffers: valid until the next search)
             pq, pr, ps, pf = self.pair_max(hi, hj, hs)
             n_cand = min(int(ps.numel()), n_cand_cut)
             n_loc = min(n_cand, n_loc_cut) if localize else 0
@@ -345,6 +348,7 @@ class DeviceMatcher:
         dropped = info.total < min(K, self.last_shard_stats["n_rows"] * self.index.ntotal)
         proven, tie = True, bool(info.tie_on_cut or dropped)
         n_take = int(hs.numel())
+        self.last_hits = (hi, hj, hs)       # this rank's share of the K hits (rows LOCAL)
         pq, pr, ps, pf = self.pair_max(hi, hj, hs)
         first_i = hi[pf].to(torch.int64) + row_base if pf.numel() else pf
         first_j = hj[pf].to(torch.int64) if pf.numel() else pf
@@ -365,14 +369,20 @@ class DeviceMatcher:
         """EVERY pair of the query rows `rows` with score > radius (strict): (i relative to rows, j, s), sorted by (score
         desc, row asc, ref asc).  Steady batches from `radius` (`vsc_index_global_topk_seeded`: pre-filters + exact stage)
         with a budget the list must stay below -- a full list may be a truncated one: the budget doubles and the rows run
-        again.  index: another index than the matcher's (the rank's column slice of the references)."""
+        again.  index: another index than the matcher's (the rank's column slice of the references).
+
+        A list SHORTER than the budget is complete only if the search's radius never moved: the seeded entry keeps the
+        schedule's re-threshold rule (more than 2 x budget kept -> the radius becomes the (budget+1)-th best, strict
+        filter), and with a group of equal scores at that position fewer than `budget` hits come back although every
+        hit in (radius, new radius] is gone.  Same acceptance rule as `FlatIndex.range_scores`."""
         idx = self.index if index is None else index
         cap_all = int(rows.shape[0]) * max(idx.ntotal, 1)
         budget = max(1024, min(int(budget), cap_all))
         while True:
             i, j, s, rad = self.search(budget, seed_radius=float(radius), rows=rows, index=idx)
-            if int(s.numel()) < budget or budget >= cap_all:
+            if budget >= cap_all or (int(s.numel()) < budget and np.float32(rad) == np.float32(radius)):
                 break
+            self.rows_above_reruns = getattr(self, "rows_above_reruns", 0) + 1
             budget = min(cap_all, budget * 2)
         return i.clone(), j.clone(), s.clone()
 

@@ -1,4 +1,4 @@
-"""Aligners other than the Temporal Network behind `vcsl.vta.build_vta_model`: "DTW" and "DP".
+"""Aligners other than the Temporal Network behind `vcsl.vta.build_vta_model`: "DTW", "DP" and "HV".
 
 The reference passes any `model_type` through to VCSL (vsc/baseline/localization.py:40-46) and never asks for anything
 but "TN" (vsc/baseline/sscd_baseline.py:121,131; vsc/baseline/dns_baseline.py:202); VCSL's own DTW / DP are CPU code
@@ -29,6 +29,23 @@ DP(discontinue=3, min_sim=0.2, min_length=5, max_iou=0.3, max_path=10)
     2. The best cell (ties: first in row-major order) is traced back to its start -> one path; its rows and columns are
        removed from further paths (S is recomputed on the remaining cells); at most max_path paths.
     3. Paths in extraction order -> boxes -> the min_length / max_iou filter.
+
+HV(discontinue=3, min_sim=0.2, min_length=5, max_iou=0.3, max_path=10, tolerance=1)
+    Temporal Hough voting (Douze et al., "An image-based approach to video copy detection with spatio-temporal
+    post-filtering", 2010, section V; VCSL benchmarks it as "HV"): a copied segment is a run of matching frames along ONE
+    temporal offset r - q.
+    1. Every matching cell (sims >= min_sim) votes for its offset d = r - q with weight sims[q, r]; H[d] = the sum of the
+       votes of the offsets d - tolerance ... d + tolerance (the band a slightly re-timed copy spreads over).
+    2. Offsets in descending H (ties: smaller |d|, then smaller d), the best max_path of them with H > 0.
+    3. Per chosen offset: the matching cells of its band, ordered by (q, r), are cut into runs wherever more than
+       `discontinue` query frames in a row hold no matching cell of the band; run -> box [min q, min r, max q, max r],
+       run score = the sum of its cells' sims (float64 sum in (q, r) order).
+    4. All runs of all chosen offsets in descending score (ties: earlier offset of step 2, then earlier run) -> the
+       min_length / max_iou filter (a copy seen from two neighbouring offsets survives once).
+
+SPD (VCSL's "similarity pattern detection") is a TRAINED detector network over the similarity matrix: without VCSL's
+weights (not in the reference checkout, no network here) there is nothing to restate -- `build_vta_model("SPD")` raises
+and says so; a user who has the weights registers the model with `vcsl.vta.register_vta_model`.
 """
 from typing import List, Sequence, Tuple
 
@@ -133,7 +150,7 @@ def _dp_scores(gain: np.ndarray, alive: np.ndarray, reach: int):
         best = np.zeros(m)
         arg = np.full((m, 2), -1, dtype=np.int64)
         for a, b in steps:
-            if i - a < 0:
+            if i - a < 0 or b >= m:   # (a step wider than the matrix reaches no cell)
                 continue
             prev = np.full(m, -np.inf)
             prev[b:] = S[i - a, : m - b]
@@ -176,6 +193,46 @@ def dp(sims: np.ndarray, discontinue: int = 3, min_sim: float = 0.2, min_length:
     return _keep(boxes, min_length, max_iou)
 
 
+def hv(sims: np.ndarray, discontinue: int = 3, min_sim: float = 0.2, min_length: int = 5, max_iou: float = 0.3,
+       max_path: int = 10, tolerance: int = 1) -> List[List[int]]:
+    sims = np.asarray(sims)
+    if sims.ndim != 2 or 0 in sims.shape:
+        return []
+    n, m = sims.shape
+    qs, rs = np.nonzero(sims >= min_sim)           # row-major: (q, r) ascending
+    if len(qs) == 0:
+        return []
+    w = sims[qs, rs].astype(np.float64)
+    off = rs - qs                                    # in [-(n-1), m-1]
+    votes = np.zeros(n + m - 1, dtype=np.float64)
+    np.add.at(votes, off + (n - 1), w)
+    tol = int(tolerance)
+    padded = np.concatenate([np.zeros(tol), votes, np.zeros(tol)])
+    H = np.zeros_like(votes)
+    for t in range(2 * tol + 1):                     # H[d] = votes[d - tol] + ... + votes[d + tol], in that order
+        H += padded[t : t + len(votes)]
+    offsets = np.arange(-(n - 1), m)
+    order = sorted(range(len(offsets)), key=lambda k: (-H[k], abs(int(offsets[k])), int(offsets[k])))
+    runs = []                                        # (score, peak rank, run number, box)
+    for rank, k in enumerate(order[: int(max_path)]):
+        if not H[k] > 0.0:
+            break
+        d = int(offsets[k])
+        band = np.nonzero(np.abs(off - d) <= tol)[0]  # cells of the band, still (q, r) ascending
+        start, count = 0, 0
+        for x in range(1, len(band) + 1):
+            if x == len(band) or qs[band[x]] - qs[band[x - 1]] > discontinue + 1:
+                cells = band[start:x]
+                box = [int(qs[cells].min()), int(rs[cells].min()), int(qs[cells].max()), int(rs[cells].max())]
+                score = 0.0
+                for c in cells:
+                    score += float(w[c])
+                runs.append((score, rank, count, box))
+                start, count = x, count + 1
+    runs.sort(key=lambda r: (-r[0], r[1], r[2]))
+    return _keep([r[3] for r in runs], min_length, max_iou)
+
+
 class _HostAligner:
     """`forward_sim([(name, sims), ...]) -> [(name, boxes), ...]` in input order, names echoed (the contract of
     vsc/baseline/localization.py:58-66).  `concurrency` (a process-pool size in VCSL) is accepted and ignored."""
@@ -201,3 +258,8 @@ class DTW(_HostAligner):
 class DP(_HostAligner):
     _fn = staticmethod(dp)
     _defaults = dict(discontinue=3, min_sim=0.2, min_length=5, max_iou=0.3, max_path=10)
+
+
+class HV(_HostAligner):
+    _fn = staticmethod(hv)
+    _defaults = dict(discontinue=3, min_sim=0.2, min_length=5, max_iou=0.3, max_path=10, tolerance=1)

@@ -3,9 +3,10 @@ tests/test_localization.py:17): `build_vta_model(model_type, **kwargs)` returnin
 `forward_sim([(name, sims), ...]) -> [(name, [[q_lo, r_lo, q_hi, r_hi], ...]), ...]`.
 
 "TN" -- the only model the reference ever requests (sscd_baseline.py:121,131; dns_baseline.py:202) -- runs on the GPU
-(libvscmi vsc_tn_forward_sim, one candidate pair per workgroup).  "DTW" and "DP" (vsc2022_amd/vcsl/aligners.py) are host
-code over the similarity matrices, as VCSL's own are: the reference's route, off the hot path.  The third-party VCSL
-source is not part of the reference checkout; see DESIGN.md ("TN: parity unpinned" -- the same holds for DTW / DP).
+(libvscmi vsc_tn_forward_sim, one candidate pair per workgroup).  "DTW", "DP" and "HV" (vsc2022_amd/vcsl/aligners.py) are
+host code over the similarity matrices, as VCSL's own are: the reference's route, off the hot path.  "SPD" is a trained
+detector network whose weights ship with VCSL only: not buildable here (aligners.py, module docstring).  The third-party
+VCSL source is not part of the reference checkout; see DESIGN.md ("TN: parity unpinned" -- the same holds for these).
 """
 import ctypes
 from typing import List, Optional, Sequence, Tuple
@@ -82,14 +83,15 @@ def build_vta_model(method="TN", concurrency: int = 1, **config):
         return method  # a ready-made aligner
     if method == "TN":
         return TN(concurrency=concurrency, **config)
-    if method in ("DTW", "DP") and method not in _REGISTRY:
+    if method in ("DTW", "DP", "HV") and method not in _REGISTRY:
         from vsc2022_amd.vcsl import aligners
 
         return getattr(aligners, method)(concurrency=concurrency, **config)
     if method in _REGISTRY:
         return _REGISTRY[method](concurrency=concurrency, **config)
     raise NotImplementedError(
-        f"alignment model {method!r}: 'TN' (GPU), 'DTW' and 'DP' (host) ship with this package; VCSL's 'HV' and 'SPD' (a "
-        "trained detector network) do not -- the VCSL source is not part of the reference checkout and the reference "
-        "never requests them; register another aligner with vsc2022_amd.vcsl.vta.register_vta_model"
+        f"alignment model {method!r}: 'TN' (GPU), 'DTW', 'DP' and 'HV' (host) ship with this package; VCSL's 'SPD' is a "
+        "TRAINED detector network over the similarity matrix -- its weights ship with VCSL, which is not part of the "
+        "reference checkout, and the reference never requests it; register a model that has them with "
+        "vsc2022_amd.vcsl.vta.register_vta_model"
     )

@@ -122,7 +122,11 @@ class FlatIndex:
     `.range_search(x, radius) -> (lims, D, I)`.
     """
 
-    def __init__(self, d: int, metric: int = METRIC_INNER_PRODUCT, device: Optional[int] = None):
+    def __init__(self, d: int, metric: int = METRIC_INNER_PRODUCT, device: Optional[int] = None,
+                 options: Optional[dict] = None):
+        """options: {name: value} applied with `set_option` while the index is still empty -- the explicit form of the
+        VSC_* environment switches (include/vscmi.h), including the ones that decide which images of the reference
+        rows are kept ("prefilter", "i8", "f16_kernel", "i8_exclude") and can only be set before the first `add`."""
         if metric not in (METRIC_INNER_PRODUCT, METRIC_L2):
             raise ValueError(f"unsupported metric {metric}")
         self.d = int(d)
@@ -131,6 +135,8 @@ class FlatIndex:
         self._h = ctypes.c_void_p()
         self._stream = None  # None: the handle's own stream; else the hipStream_t value it was bound to (0 = default stream)
         _lib.check(_lib.lib().vsc_index_create(self.d, metric, self.device, ctypes.byref(self._h)))
+        for name, value in (options or {}).items():
+            self.set_option(name, value)
 
     def __del__(self):
         h = getattr(self, "_h", None)
