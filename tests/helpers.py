@@ -141,6 +141,9 @@ def check_localisation_sample(orc, q_feats, q_off, r_feats, r_off, pair_q, pair_
     for pool, share in ((with_box, rest // 2), (without, rest - rest // 2)):
         if len(pool):
             pick |= set(rng.choice(pool, min(share, len(pool)), replace=False).tolist())
+    if len(pick) < n:  # (the strata overlap, or one of them is smaller than its share: fill up from the rest)
+        rest_pool = np.setdiff1d(np.arange(n_pairs), np.fromiter(pick, dtype=np.int64), assume_unique=False)
+        pick |= set(rng.choice(rest_pool, n - len(pick), replace=False).tolist())
     pick = np.array(sorted(pick), dtype=np.int64)
     n_boxes = 0
     for k in pick:
