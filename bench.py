@@ -752,6 +752,10 @@ def main():
     pm_ms, pm_calls, pm_bytes = _aux(0)
     tn_ms, tn_calls, tn_bytes = _aux(1)
     digest = result_digest(torch, matcher, res)   # (collective at N > 1: every rank takes part, all hold the same tables)
+    # the sharded search's phases of the LAST step, max over ranks (dist.PhaseTimer: recorded without synchronising)
+    shard_phases = None
+    if world > 1 and getattr(matcher, "last_shard_stats", None):
+        shard_phases = vdist.reduce_phase_report(matcher.last_shard_stats.get("phases", {}), dev)
     if use_dist:
         t = torch.tensor([dt], dtype=torch.float64, device="cpu" if share_gpu else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -917,7 +921,15 @@ def main():
             st = getattr(matcher, "last_shard_stats", None)
             if st:
                 out["sharded_search"] = dict(mode=os.environ.get("VSC_SHARD_MODE", "cols"), share_gpu=share_gpu,
-                                             **{k: (round(v, 4) if isinstance(v, float) else v) for k, v in st.items()})
+                                             **{k: (round(v, 4) if isinstance(v, float) else v) for k, v in st.items() if k != "phases"})
+                # per phase of the last step, MAX over ranks: host wall ms, device ms between HIP events on the engine's
+                # stream (no synchronisation added), calls, bytes handed to the collective
+                out["sharded_search"]["phases_max_over_ranks"] = shard_phases
+                out["sharded_search"]["phases_note"] = (
+                    "gather_queries = all-gather of the score-normalised query rows; search = the rank's column slice of every "
+                    "batch (library calls); count = per-batch all-reduce of the kept total (+ its host sync); events = exact "
+                    "distributed (K+1)-th best by radix-select histograms + filter; handover = all-to-all of the kept hits to "
+                    "the row owners; final_sort_and_cut = radix sort + distributed cut at K")
         if world == 1:
             # the untimed legs must never cost the headline line: a failure in one of them is reported, not raised
             if not args.no_extra:

@@ -222,7 +222,38 @@ int vsc_sort_hits(const int32_t* hit_i, const int32_t* hit_j, const float* hit_s
                   int64_t max_row, int64_t max_ref, int32_t* out_i, int32_t* out_j, float* out_s, int out_mem,
                   int device);
 
-/* The stream of the entry points that own no handle on `device` (vsc_pair_max, vsc_sort_hits, vsc_row_normalize, vsc_tn_forward_sim):
+/* Exact order statistics over UNSORTED score lists that are spread over ranks -- the re-threshold events of
+ * range_search_max_results (vsc/index.py:147-154: "more than 2K kept -> radius = the (K+1)-th best") when the kept list
+ * lives on several GPUs (vsc2022_amd/dist.py:kth_best_unsorted), without sorting anything: a 4 x 8-bit radix select whose
+ * per-level histograms are summed by the CALLER (one all-reduce of 256 counters per level).
+ *   state   int64[4] in device memory: {key prefix found so far, its mask, 1-based rank still wanted among the keys that
+ *           match the prefix, scores strictly above the prefix so far}; start with {0, 0, k, 0}.
+ *   vsc_score_histogram   hist[256] (device int64) <- per-digit counts, digit = bits [shift, shift+8) of the key, over the
+ *           scores whose key matches state's prefix; shift = 24, 16, 8, 0 in that order.  key = order-preserving image of
+ *           score + 0.0f (-0.0 and +0.0 share a key, as they compare equal in the reference's float comparisons).
+ *   vsc_score_pick        narrows state by the (summed) histogram of that level.
+ * After the level with shift 0 state[0] is the key of the k-th best score of the union and state[3] the number of scores
+ * strictly above it; the sum of the first level's histogram is the size of the union (k beyond it: state is meaningless).
+ * Device pointers only.  On a caller's stream (vsc_set_aux_stream) both calls only ENQUEUE -- the caller's next operation on
+ * that stream is ordered behind them and a whole selection runs without a host round trip --; on the library's own
+ * stream they return when done. */
+int vsc_score_histogram(const float* scores, int64_t n, const int64_t* state, int shift, int64_t* hist, int device);
+int vsc_score_pick(const int64_t* hist, int64_t* state, int shift, int device);
+
+/* perm[n] (int32) <- the stable argsort of a score list, best first: equal scores (-0.0 == +0.0) keep their input order.
+ * Merges the ranks' candidate lists (vsc/candidates.py:38-40 sorts with Python's stable sort; the concatenation of the
+ * ranks' lists in rank order IS first-appearance order, vsc2022_amd/dist.py:merge_candidates).  Host or device arrays. */
+int vsc_argsort_scores(const float* scores, int64_t n, int mem, int32_t* perm, int perm_mem, int device);
+
+/* Per-row merge of k-NN lists from reference shards (BASELINE configs[4]; vsc2022_amd/dist.py:ref_sharded_knn): row x of
+ * scores / ids holds m candidates (ids: GLOBAL reference rows, < 0 = empty slot); out_* [nq, k] <- the k best per row
+ * under (score desc, id asc) -- what faiss index.search returns on the concatenated reference set (vsc/index.py:174);
+ * missing slots hold -1 and -FLT_MAX.  1 <= k <= m <= 1024; device pointers. */
+int vsc_merge_topk(const float* scores, const int64_t* ids, int64_t nq, int m, int k, float* out_s, int64_t* out_ids,
+                   int device);
+
+/* The stream of the entry points that own no handle on `device` (vsc_pair_max, vsc_sort_hits, vsc_score_histogram, vsc_score_pick,
+ * vsc_argsort_scores, vsc_merge_topk, vsc_row_normalize, vsc_tn_forward_sim):
  * as vsc_index_set_stream. */
 int vsc_set_aux_stream(int device, void* hip_stream, int own);
 

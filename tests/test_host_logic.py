@@ -45,7 +45,7 @@ def test_no_device_fails_loudly_not_silently():
     with pytest.raises(RuntimeError):
         build_vta_model("TN").forward_sim([("a", np.eye(4, dtype=np.float32))])
     with pytest.raises(NotImplementedError):
-        build_vta_model("HV")
+        build_vta_model("SPD")   # (a trained detector network: not buildable, vsc2022_amd/vcsl/aligners.py)
 
 
 def test_video_feature_contract():

@@ -159,6 +159,92 @@ int vsc_sort_hits(const int32_t* hit_i, const int32_t* hit_j, const float* hit_s
     return VSC_OK;
 }
 
+// One level of an order statistic over unsorted scores that are spread over ranks (include/vscmi.h).  Device pointers
+// only; on a caller's stream (vsc_set_aux_stream) the work is merely enqueued -- the caller's next operation on that
+// stream (the all-reduce of the histogram) is ordered behind it --, on the library's own stream the call waits.
+int vsc_score_histogram(const float* scores, int64_t n, const int64_t* state, int shift, int64_t* hist, int device) {
+    if (n < 0 || (n > 0 && !scores) || !state || !hist || (shift != 0 && shift != 8 && shift != 16 && shift != 24)) {
+        set_error("vsc_score_histogram: invalid argument");
+        return VSC_ERR_INVALID;
+    }
+    VSC_TRY(check_device(device));
+    VSC_HIP(hipSetDevice(device));
+    DeviceCtx* c = device_ctx(device);
+    if (!c) {
+        set_error("vsc_score_histogram: cannot create device context");
+        return VSC_ERR_HIP;
+    }
+    std::lock_guard<std::mutex> lk(c->mu);
+    VSC_TRY(launch_score_hist(scores, (long long)n, reinterpret_cast<const long long*>(state), shift,
+                              reinterpret_cast<long long*>(hist), c->stream));
+    if (c->stream == c->own_stream) VSC_HIP(hipStreamSynchronize(c->stream));
+    return VSC_OK;
+}
+
+int vsc_score_pick(const int64_t* hist, int64_t* state, int shift, int device) {
+    if (!hist || !state || (shift != 0 && shift != 8 && shift != 16 && shift != 24)) {
+        set_error("vsc_score_pick: invalid argument");
+        return VSC_ERR_INVALID;
+    }
+    VSC_TRY(check_device(device));
+    VSC_HIP(hipSetDevice(device));
+    DeviceCtx* c = device_ctx(device);
+    if (!c) {
+        set_error("vsc_score_pick: cannot create device context");
+        return VSC_ERR_HIP;
+    }
+    std::lock_guard<std::mutex> lk(c->mu);
+    VSC_TRY(launch_score_pick(reinterpret_cast<const long long*>(hist), reinterpret_cast<long long*>(state), shift, c->stream));
+    if (c->stream == c->own_stream) VSC_HIP(hipStreamSynchronize(c->stream));
+    return VSC_OK;
+}
+
+int vsc_argsort_scores(const float* scores, int64_t n, int mem, int32_t* perm, int perm_mem, int device) {
+    if (n < 0 || (n > 0 && (!scores || !perm))) {
+        set_error("vsc_argsort_scores: invalid argument");
+        return VSC_ERR_INVALID;
+    }
+    if (n == 0) return VSC_OK;
+    VSC_TRY(check_device(device));
+    VSC_HIP(hipSetDevice(device));
+    DeviceCtx* c = device_ctx(device);
+    if (!c) {
+        set_error("vsc_argsort_scores: cannot create device context");
+        return VSC_ERR_HIP;
+    }
+    std::lock_guard<std::mutex> lk(c->mu);
+    Workspace& ws = c->ws;
+    const void* ds;
+    VSC_TRY(to_device(scores, (size_t)n * 4, mem, ws.hA[2], &ds, c->stream));
+    const int32_t* p = nullptr;
+    VSC_TRY(argsort_scores_desc((const float*)ds, n, ws.w0, ws.w1, ws.w2, ws.w3, ws.tmp, &p, c->stream));
+    VSC_HIP(hipMemcpyAsync(perm, p, (size_t)n * 4, perm_mem == VSC_MEM_HOST ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice,
+                           c->stream));
+    VSC_HIP(hipStreamSynchronize(c->stream));
+    return VSC_OK;
+}
+
+int vsc_merge_topk(const float* scores, const int64_t* ids, int64_t nq, int m, int k, float* out_s, int64_t* out_ids,
+                   int device) {
+    if (nq < 0 || m <= 0 || k <= 0 || m > 1024 || k > m || (nq > 0 && (!scores || !ids || !out_s || !out_ids))) {
+        set_error("vsc_merge_topk: invalid argument (1 <= k <= m <= 1024 candidates per row)");
+        return VSC_ERR_INVALID;
+    }
+    if (nq == 0) return VSC_OK;
+    VSC_TRY(check_device(device));
+    VSC_HIP(hipSetDevice(device));
+    DeviceCtx* c = device_ctx(device);
+    if (!c) {
+        set_error("vsc_merge_topk: cannot create device context");
+        return VSC_ERR_HIP;
+    }
+    std::lock_guard<std::mutex> lk(c->mu);
+    VSC_TRY(launch_merge_topk(scores, reinterpret_cast<const long long*>(ids), (long long)nq, m, k, out_s,
+                              reinterpret_cast<long long*>(out_ids), c->stream));
+    VSC_HIP(hipStreamSynchronize(c->stream));
+    return VSC_OK;
+}
+
 int vsc_row_normalize(const float* x, int64_t n, int dim, int x_mem, float* out, int out_mem, int device) {
     if (n < 0 || dim <= 0 || (n > 0 && (!x || !out))) {
         set_error("vsc_row_normalize: invalid argument");

@@ -160,6 +160,10 @@ int launch_quant_query_panels(const float*, int, int, int, void*, int, float4*, 
 int launch_row_absmax(const float*, int, int, const ExcludedDims&, float*, hipStream_t);
 int launch_row_bias_thresholds(const float*, int, int, const float*, const float*, const ExcludedDims&, float*, hipStream_t);
 int sort_rows_by_threshold(const float*, int64_t, DevBuf&, DevBuf&, DevBuf&, DevBuf&, DevBuf&, const int32_t**, hipStream_t);
+int argsort_scores_desc(const float*, int64_t, DevBuf&, DevBuf&, DevBuf&, DevBuf&, DevBuf&, const int32_t**, hipStream_t);
+int launch_score_hist(const float*, long long, const long long*, int, long long*, hipStream_t);
+int launch_score_pick(const long long*, long long*, int, hipStream_t);
+int launch_merge_topk(const float*, const long long*, long long, int, int, float*, long long*, hipStream_t);
 int sort_rows_by_threshold_then_scale(const float*, const float*, int64_t, int, DevBuf&, DevBuf&, DevBuf&, DevBuf&, DevBuf&,
                                       const int32_t**, hipStream_t);
 int launch_pack_half_frag(const float*, int64_t, int, _Float16*, float*, int64_t, int64_t, int, hipStream_t);

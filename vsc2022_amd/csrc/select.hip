@@ -8,6 +8,7 @@
 //
 // HBM-bound: one radix-select = 4 passes over <= ~2K + batch scores (4 B each); one compaction
 // pass over 12 B/hit.  Negligible next to the similarity kernel; kept simple.
+#include <cfloat>
 #include "kernels.h"
 
 namespace vscmi {
@@ -182,6 +183,144 @@ int enqueue_rethreshold(SelectCtl* ctl, int32_t* ai, int32_t* aj, float* as, int
     hipLaunchKernelGGL(select_compact_kernel, dim3(GRID), dim3(256), 0, stream, ctl, ai, aj, as, bi, bj, bs);
     hipLaunchKernelGGL(select_copyback_kernel, dim3(GRID), dim3(256), 0, stream, ctl, bi, bj, bs, ai, aj, as);
     hipLaunchKernelGGL(select_end_kernel, dim3(1), dim3(1), 0, stream, ctl);
+    VSC_HIP(hipGetLastError());
+    return VSC_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Order statistics over UNSORTED score lists that are spread over ranks (vsc_score_histogram / vsc_score_pick; the
+// sharded schedule's re-threshold events and the reference-sharded selections, vsc2022_amd/dist.py): the same 4 x 8-bit
+// radix select as above, but with the histogram of every level handed OUT -- the caller adds the ranks' histograms (one
+// all-reduce of 256 counters) and hands the sum back to `score_pick_kernel`, which narrows the key prefix.  The state
+// stays in device memory (int64[4]: key prefix, prefix mask, 1-based rank still wanted among the matching keys, scores
+// strictly above the prefix so far), so a whole selection runs without a host round trip.
+// Keys: f2key(score + 0.0f) -- -0.0 and +0.0 share a key, as they compare equal in the reference's float comparisons.
+__global__ __launch_bounds__(256) void score_hist_kernel(const float* __restrict__ s, long long n, const long long* __restrict__ state,
+                                                         int shift, unsigned long long* __restrict__ hist) {
+    __shared__ unsigned int lh[256];
+    lh[threadIdx.x] = 0;
+    __syncthreads();
+    const unsigned int prefix = (unsigned int)state[0], pmask = (unsigned int)state[1];
+    const int lane = threadIdx.x & 63;
+    // (16-byte loads where the list allows them: the head up to the first 16-byte boundary and the tail run scalar)
+    const long long head = min(n, (long long)(((16 - ((uintptr_t)s & 15)) & 15) >> 2));
+    const long long n4 = (n - head) / 4;
+    const float4* s4 = reinterpret_cast<const float4*>(s + head);
+    const long long rounds = (n4 + 255) & ~255ll;
+    for (long long q = (long long)blockIdx.x * 256 + threadIdx.x; q < rounds; q += (long long)gridDim.x * 256) {
+        float v[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+        const bool in = q < n4;
+        if (in) {
+            const float4 t = s4[q];
+            v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const unsigned int key = f2key(v[e] + 0.0f);
+            const bool valid = in && (key & pmask) == prefix;
+            const unsigned int bin = (key >> shift) & 255u;
+            if (shift == 24) {  // (a kept list shares sign and exponent: count equal digits inside the wave first)
+                unsigned long long todo = __ballot(valid);
+                while (todo) {
+                    const int leader = __ffsll((long long)todo) - 1;
+                    const unsigned int lb = __shfl(bin, leader);
+                    const unsigned long long same = __ballot(valid && bin == lb);
+                    if (lane == leader) atomicAdd(&lh[lb], (unsigned int)__popcll(same));
+                    todo &= ~same;
+                }
+            } else if (valid) {
+                atomicAdd(&lh[bin], 1u);
+            }
+        }
+    }
+    if (blockIdx.x == 0) {  // the unaligned head and the tail (< 4 + 3 scores)
+        const long long tail0 = head + n4 * 4;
+        const long long extra = head + (n - tail0);
+        if ((long long)threadIdx.x < extra) {
+            const long long x = (long long)threadIdx.x < head ? threadIdx.x : tail0 + (threadIdx.x - head);
+            const unsigned int key = f2key(s[x] + 0.0f);
+            if ((key & pmask) == prefix) atomicAdd(&lh[(key >> shift) & 255u], 1u);
+        }
+    }
+    __syncthreads();
+    if (lh[threadIdx.x]) atomicAdd(&hist[threadIdx.x], (unsigned long long)lh[threadIdx.x]);
+}
+
+__global__ void score_pick_kernel(const long long* __restrict__ hist, long long* __restrict__ state, int shift) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    long long need = state[2], above = state[3];
+    int d = 255;
+    for (; d > 0; --d) {
+        if (need <= hist[d]) break;
+        need -= hist[d];
+        above += hist[d];
+    }
+    // (fewer than `need` scores in the union: d ends at 0 and the caller reads total < k from the first level's sum)
+    state[0] = (long long)((unsigned int)state[0] | ((unsigned int)d << shift));
+    state[1] = (long long)((unsigned int)state[1] | (255u << shift));
+    state[2] = need;
+    state[3] = above;
+}
+
+int launch_score_hist(const float* s, long long n, const long long* state, int shift, long long* hist, hipStream_t stream) {
+    VSC_HIP(hipMemsetAsync(hist, 0, 256 * sizeof(long long), stream));
+    if (n > 0) {
+        const int grid = (int)std::min<long long>(1024, (n / 4 + 255) / 256 + 1);
+        hipLaunchKernelGGL(score_hist_kernel, dim3(grid), dim3(256), 0, stream, s, n, state, shift,
+                           reinterpret_cast<unsigned long long*>(hist));
+        VSC_HIP(hipGetLastError());
+    }
+    return VSC_OK;
+}
+
+int launch_score_pick(const long long* hist, long long* state, int shift, hipStream_t stream) {
+    hipLaunchKernelGGL(score_pick_kernel, dim3(1), dim3(64), 0, stream, hist, state, shift);
+    VSC_HIP(hipGetLastError());
+    return VSC_OK;
+}
+
+// Per-row merge of reference shards' k-NN lists (vsc_merge_topk; BASELINE configs[4], vsc2022_amd/dist.py:ref_sharded_knn): row x
+// holds m = shards x k candidates (score, global reference id; id < 0 = empty slot); the k best under (score desc, id asc)
+// -- the order one index over the concatenated reference set produces -- by rank counting: every candidate counts the
+// candidates that beat it (m <= 1024: <= 16 per lane, the row in LDS), and the ones with rank < k go to slot `rank`.
+// One wavefront per row; ids are unique across shards, empty slots order by position.
+__global__ __launch_bounds__(256) void merge_topk_kernel(const float* __restrict__ s, const long long* __restrict__ ids, long long nq,
+                                                         int m, int k, float* __restrict__ out_s, long long* __restrict__ out_ids) {
+    extern __shared__ unsigned char lds_raw[];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    float* ls = reinterpret_cast<float*>(lds_raw) + (size_t)wave * m;
+    long long* li = reinterpret_cast<long long*>(lds_raw + (size_t)4 * m * 4) + (size_t)wave * m;
+    const long long row = (long long)blockIdx.x * 4 + wave;
+    if (row >= nq) return;
+    for (int e = lane; e < m; e += 64) {
+        const long long id = ids[row * m + e];
+        ls[e] = id < 0 ? -INFINITY : s[row * m + e];
+        li[e] = id < 0 ? 0x7fffffffffffffffLL : id;
+    }
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_s_waitcnt(0);  // (the row's LDS writes of this wave are complete)
+    for (int e = lane; e < m; e += 64) {
+        const float se = ls[e];
+        const long long ie = li[e];
+        int rank = 0;
+        for (int f = 0; f < m; ++f) {
+            const float sf = ls[f];
+            const long long jf = li[f];
+            rank += (sf > se) || (sf == se && (jf < ie || (jf == ie && f < e)));
+        }
+        if (rank < k) {
+            const bool empty = ie == 0x7fffffffffffffffLL;
+            out_s[row * k + rank] = empty ? -FLT_MAX : se;
+            out_ids[row * k + rank] = empty ? -1 : ie;
+        }
+    }
+}
+
+int launch_merge_topk(const float* s, const long long* ids, long long nq, int m, int k, float* out_s, long long* out_ids,
+                      hipStream_t stream) {
+    if (nq <= 0) return VSC_OK;
+    const size_t lds = (size_t)4 * m * (4 + 8);
+    hipLaunchKernelGGL(merge_topk_kernel, dim3((unsigned)((nq + 3) / 4)), dim3(256), lds, stream, s, ids, nq, m, k, out_s, out_ids);
     VSC_HIP(hipGetLastError());
     return VSC_OK;
 }

@@ -117,6 +117,35 @@ int sort_rows_by_threshold(const float* thr, int64_t n, DevBuf& w0, DevBuf& w1, 
     return VSC_OK;
 }
 
+// Stable argsort of a score list, best first (vsc_argsort_scores: the merge of the ranks' candidate lists, vsc2022_amd/dist.py
+// merge_candidates -- equal scores keep their input order, which there is rank order = first-appearance order).
+__global__ __launch_bounds__(256) void score_keys_kernel(const float* __restrict__ s, long long n, uint32_t* __restrict__ keys,
+                                                         int32_t* __restrict__ vals) {
+    const long long x = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (x >= n) return;
+    keys[x] = f2key(s[x] + 0.0f);   // (-0.0 == +0.0, as in the reference's float comparisons)
+    vals[x] = (int32_t)x;
+}
+
+int argsort_scores_desc(const float* s, int64_t n, DevBuf& w0, DevBuf& w1, DevBuf& w2, DevBuf& w3, DevBuf& tmp,
+                        const int32_t** perm, hipStream_t stream) {
+    *perm = nullptr;
+    if (n <= 0) return VSC_OK;
+    VSC_TRY(w0.reserve(sizeof(uint32_t) * n));
+    VSC_TRY(w1.reserve(sizeof(uint32_t) * n));
+    VSC_TRY(w2.reserve(sizeof(int32_t) * n));
+    VSC_TRY(w3.reserve(sizeof(int32_t) * n));
+    VSC_TRY(tmp.reserve(radix_tmp_bytes(n)));
+    uint32_t *ka = w0.as<uint32_t>(), *kb = w1.as<uint32_t>();
+    int32_t *va = w2.as<int32_t>(), *vb = w3.as<int32_t>();
+    hipLaunchKernelGGL(score_keys_kernel, dim3(grid_for(n)), dim3(256), 0, stream, s, (long long)n, ka, va);
+    VSC_HIP(hipGetLastError());
+    const int w = radix_sort_pairs<uint32_t, int32_t>(ka, kb, va, vb, n, 0, 32, true, tmp.p, stream);
+    if (w < 0) { set_error("radix sort launch failed"); return VSC_ERR_HIP; }
+    *perm = w ? vb : va;
+    return VSC_OK;
+}
+
 // ... and, inside groups of `group` consecutive positions of that order, by the rows' scale (their largest |x|): the
 // panels of the int8 kernel share ONE quantisation scale per 128 rows, so a panel of rows that would have picked
 // nearly that scale themselves keeps the panel's error bound E_q near a single row's (the radius search sorts all its

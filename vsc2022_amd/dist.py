@@ -44,6 +44,87 @@ import torch
 import torch.distributed as dist
 
 
+class PhaseTimer:
+    """Per-phase accounting of the sharded search WITHOUT synchronising anything (the first real
+    N-GPU run must come back with a breakdown, not one number): for every phase the host wall time of its calls
+    (`time.perf_counter`, as the host saw it), the device time between a pair of events recorded on torch's current
+    stream (HIP events; the library's handles run on that stream, and RCCL's collectives make it wait for them), the
+    number of calls and the bytes handed to collectives.  `collect()` reads the events once, after the caller's own final
+    host sync.  Phases whose work is only enqueued show little wall time and their true device time; phases that end in a
+    host sync (a library call, `.item()`) show both."""
+
+    def __init__(self, device=None, enabled: bool = True):
+        self.on_gpu = enabled and device is not None and torch.device(device).type == "cuda"
+        self.enabled = enabled
+        self.wall, self.calls, self.moved, self.events = {}, {}, {}, []
+
+    class _Phase:
+        def __init__(self, timer, name):
+            self.t, self.name = timer, name
+
+        def __enter__(self):
+            import time
+
+            if self.t.on_gpu:
+                self.e0 = torch.cuda.Event(enable_timing=True)
+                self.e0.record()
+            self.w0 = time.perf_counter()
+            return self
+
+        def __exit__(self, *exc):
+            import time
+
+            t = self.t
+            t.wall[self.name] = t.wall.get(self.name, 0.0) + time.perf_counter() - self.w0
+            t.calls[self.name] = t.calls.get(self.name, 0) + 1
+            if t.on_gpu:
+                e1 = torch.cuda.Event(enable_timing=True)
+                e1.record()
+                t.events.append((self.name, self.e0, e1))
+            return False
+
+    class _Null:
+        def __enter__(self):
+            return self
+
+        def __exit__(self, *exc):
+            return False
+
+    def phase(self, name: str):
+        return PhaseTimer._Phase(self, name) if self.enabled else PhaseTimer._Null()
+
+    def add_bytes(self, name: str, n: int):
+        if self.enabled:
+            self.moved[name] = self.moved.get(name, 0) + int(n)
+
+    def collect(self) -> dict:
+        """{phase: {"wall_ms", "device_ms", "calls", "bytes"}} (events are read here: call after the final host sync)"""
+        dev_ms = {}
+        if self.on_gpu and self.events:
+            self.events[-1][2].synchronize()
+            for name, e0, e1 in self.events:
+                dev_ms[name] = dev_ms.get(name, 0.0) + e0.elapsed_time(e1)
+        out = {}
+        for name in self.wall:
+            out[name] = {"wall_ms": round(1e3 * self.wall[name], 3), "device_ms": round(dev_ms.get(name, 0.0), 3),
+                         "calls": self.calls[name], "bytes": self.moved.get(name, 0)}
+        return out
+
+
+def reduce_phase_report(report: dict, device, group=None) -> dict:
+    """max over ranks of every figure of a PhaseTimer report (the slowest rank sets the step time), identical on all ranks"""
+    rank, world = _world(group)
+    if world == 1 or not report:
+        return report
+    names = sorted(report)
+    fields = ("wall_ms", "device_ms", "calls", "bytes")
+    t = torch.tensor([[float(report[n][f]) for f in fields] for n in names], dtype=torch.float64, device=device)
+    h = t.cpu() if _via_host(t, group) else t
+    dist.all_reduce(h, op=dist.ReduceOp.MAX, group=group)
+    vals = h.cpu().tolist()
+    return {n: {f: (int(v) if f in ("calls", "bytes") else round(v, 3)) for f, v in zip(fields, row)} for n, row in zip(names, vals)}
+
+
 def score_keys(scores: torch.Tensor) -> torch.Tensor:
     """Order-preserving fp32 -> integer key (int64 holding a uint32): larger score, larger key; -0.0 and +0.0 share
     a key, as they compare equal in the reference's float comparisons."""
@@ -402,8 +483,7 @@ def emulate_schedule_radius(range_scores: Callable[[int, int, float], torch.Tens
         total = all_reduce_sum_int(n_kept, dev, group)
         if total > 2 * k_global:
             allk = torch.cat(kept) if kept else torch.zeros(0, dtype=torch.float32, device=dev)
-            allk = torch.sort(allk, descending=True).values
-            _, tau = distributed_prefix_select(allk, k_global + 1, group)
+            tau, _ = kth_best_unsorted(allk, k_global + 1, group)
             radius = float(tau)
             allk = allk[allk > radius]
             kept, n_kept = ([allk] if allk.numel() else []), int(allk.numel())
@@ -428,28 +508,85 @@ def predict_schedule_density(n_rows: int, k_global: int, n_refs: int) -> List[Tu
     return out
 
 
+class _RadixState:
+    """State of one distributed 4 x 8-bit radix select (include/vscmi.h, vsc_score_histogram): {key prefix, prefix mask, rank
+    still wanted among the matching keys (1-based, from the top), scores strictly above the prefix}.  HBM tensors run
+    through libvscmi (`vsc_score_histogram` / `vsc_score_pick`: no sort, no host round trip); CPU tensors (the gloo tests,
+    where the oracle supplies the searches) through the torch restatement below -- the level walk and the collectives are
+    the same code either way."""
+
+    def __init__(self, k: int, device: torch.device):
+        self.device = device
+        self.on_gpu = device.type == "cuda"
+        if self.on_gpu:
+            self.t = torch.tensor([0, 0, int(k), 0], dtype=torch.int64, device=device)
+        else:
+            self.prefix, self.mask, self.need, self.above = 0, 0, int(k), 0
+
+    def hist(self, scores: torch.Tensor, shift: int) -> torch.Tensor:
+        """int64[256]: digit counts (bits [shift, shift + 8) of the key) of the scores whose key matches the prefix"""
+        if self.on_gpu:
+            from vsc2022_amd import _lib
+            from vsc2022_amd.engine import bind_aux_stream
+
+            scores = scores.contiguous()
+            h = torch.empty(256, dtype=torch.int64, device=self.device)
+            bind_aux_stream(self.device)   # (the library's device stream = torch's current stream: stream-ordered, no sync)
+            _lib.check(_lib.lib().vsc_score_histogram(scores.data_ptr(), int(scores.numel()), self.t.data_ptr(), int(shift),
+                                                      h.data_ptr(), self.device.index))
+            return h
+        keys = score_keys(scores)
+        sel = keys[(keys & self.mask) == self.prefix]
+        return torch.bincount((sel >> shift) & 255, minlength=256).to(torch.int64)
+
+    def pick(self, hist: torch.Tensor, shift: int):
+        """narrow the prefix by the (summed) histogram of this level"""
+        if self.on_gpu:
+            from vsc2022_amd import _lib
+
+            _lib.check(_lib.lib().vsc_score_pick(hist.data_ptr(), self.t.data_ptr(), int(shift), self.device.index))
+            return
+        h = hist.tolist()
+        d = 255
+        while d > 0:
+            if self.need <= h[d]:
+                break
+            self.need -= h[d]
+            self.above += h[d]
+            d -= 1
+        self.prefix |= d << shift
+        self.mask |= 255 << shift
+
+    def result(self, total: torch.Tensor) -> Tuple[int, int, int]:
+        """(key of the k-th best, scores strictly above it, size of the union) -- the selection's one host sync"""
+        if self.on_gpu:
+            key, _, _, above, tot = (int(x) for x in torch.cat([self.t, total.reshape(1)]).cpu())
+            return key, above, tot
+        return self.prefix, self.above, int(total)
+
+
 def kth_best_unsorted(scores: torch.Tensor, k: int, group=None) -> Tuple[float, int]:
     """(k-th best score, total count) over all ranks' UNSORTED fp32 score tensors (k is 1-based; -inf when fewer than k
-    scores exist): a local sort of the scores alone (the lists themselves stay as they are and are filtered once the
-    radius is known) + the exact distributed selection.  (A histogram of the unsorted keys was tried first: the scores of
-    a kept list share their upper 16 key bits with a few hundred others, `bincount` serialises on those bins -- 0.4 s per
-    event on 1e8 scores against 25 ms for the sort.)"""
-    srt = torch.sort(scores, descending=True).values if scores.numel() else scores
-    _, tau, info = distributed_prefix_select(srt, int(k), group, return_info=True)
-    if info.total == k:  # (the selection answers -inf for "the whole union": the k-th best is then the smallest score)
-        t = torch.tensor([-float(srt[-1]) if srt.numel() else float("-inf")], dtype=torch.float64, device=scores.device)
-        rank, world = _world(group)
-        if world > 1:
-            h = t.cpu() if _via_host(t, group) else t
-            dist.all_reduce(h, op=dist.ReduceOp.MAX, group=group)
-            t = h
-        return -float(t.item()), int(info.total)
-    return (float("-inf") if info.total < k else float(tau)), int(info.total)
+    scores exist).  Nothing is sorted: an exact 4 x 8-bit radix select over the order-preserving keys, the ranks'
+    256-counter histograms summed by one all-reduce per level (2 KB each) -- `vsc_score_histogram` / `vsc_score_pick` on
+    libvscmi's wave-aggregated histogram kernel, the state in HBM, ONE host sync at the end.  (Round 5 sorted every
+    rank's kept scores with torch.sort at every event of the schedule: 13 events x ~1e8 / world scores.)"""
+    dev = scores.device
+    st = _RadixState(int(k), dev)
+    total = None
+    for shift in (24, 16, 8, 0):
+        h = _all_reduce_sum(st.hist(scores, shift), group)
+        if total is None:
+            total = h.sum()
+        st.pick(h, shift)
+    key, _, tot = st.result(total)
+    return (float("-inf") if tot < k else float(key_to_score(key))), tot
 
 
 def emulate_schedule(search_rows: Callable[[int, int, float], Tuple[torch.Tensor, torch.Tensor, torch.Tensor]], n_rows: int,
                      k_global: int, group=None, device=None, trace: Optional[list] = None,
-                     handover: Optional[Tuple[int, Callable]] = None, timing: Optional[Tuple[Callable, dict]] = None):
+                     handover: Optional[Tuple[int, Callable]] = None, timer: Optional[PhaseTimer] = None,
+                     n_cols_total: Optional[int] = None):
     """range_search_max_results(max_results=2K, min_results=K) over the reference's batch schedule (vsc/index.py:147-154,
     inner product), run over QUERY SHARDS: returns (final radius t, i, j, s) -- this rank's part of {s > t}, the set the
     reference sorts and cuts at K.  Exact, ties included: nothing is decided by a proof about the cut.
@@ -467,7 +604,14 @@ def emulate_schedule(search_rows: Callable[[int, int, float], Tuple[torch.Tensor
     statistics are sums over ranks), so the batches before `row` may be searched under ANOTHER partition -- the engine
     splits the doubling batches at the head of the query set by reference COLUMNS, every rank searching all of their rows
     against its slice --; before the first batch that starts at or after `row`, fn(i, j, s) -> (i, j, s) hands every kept
-    hit to the rank that owns its query row (i: whatever search_rows returned for those batches in, local rows out)."""
+    hit to the rank that owns its query row (i: whatever search_rows returned for those batches in, local rows out).
+
+    timer: a `PhaseTimer` that accounts the phases "count" (the per-batch all-reduce) and "events".  n_cols_total: the
+    number of reference rows over ALL ranks; with it the per-batch count all-reduce (and its host sync) is skipped while
+    the kept total known from the last count plus everything the batches since then could have added -- rows x
+    n_cols_total each -- cannot exceed 2K: no event is possible there."""
+    timer = timer if timer is not None else PhaseTimer(enabled=False)
+    known_total, since = 0, 0     # kept hits over all ranks at the last count; upper bound of what was added since
     radius = -1e10
     kept_i: List[torch.Tensor] = []
     kept_j: List[torch.Tensor] = []
@@ -489,23 +633,27 @@ def emulate_schedule(search_rows: Callable[[int, int, float], Tuple[torch.Tensor
         if s.numel():
             kept_i.append(i); kept_j.append(j); kept_s.append(s)
             n_kept += int(s.numel())
-        t0 = timing[0]() if timing else 0.0
-        total = all_reduce_sum_int(n_kept, dev, group)
-        if timing:
-            timing[1]["t_count"] = timing[1].get("t_count", 0.0) + timing[0]() - t0
-        event = total > 2 * k_global
+        since += (r1 - r0) * int(n_cols_total) if n_cols_total is not None else 0
+        if n_cols_total is not None and known_total + since <= 2 * k_global:
+            total, event = known_total + since, False     # (an upper bound; no event can happen: no collective, no sync)
+            timer.calls["count_skipped"] = timer.calls.get("count_skipped", 0) + 1
+        else:
+            with timer.phase("count"):
+                total = all_reduce_sum_int(n_kept, dev, group)
+            known_total, since = total, 0
+            event = total > 2 * k_global
         if event:
-            t0 = timing[0]() if timing else 0.0
-            alls = torch.cat(kept_s) if kept_s else torch.zeros(0, dtype=torch.float32, device=dev)
-            tau, _ = kth_best_unsorted(alls, k_global + 1, group)
-            radius = float(tau)
-            if kept_s:
-                m = alls > radius
-                kept_i, kept_j, kept_s = [torch.cat(kept_i)[m]], [torch.cat(kept_j)[m]], [alls[m]]
-                n_kept = int(kept_s[0].numel())
-            if timing:
-                timing[1]["t_events"] = timing[1].get("t_events", 0.0) + timing[0]() - t0
-                timing[1]["events"] = timing[1].get("events", 0) + 1
+            with timer.phase("events"):
+                alls = torch.cat(kept_s) if kept_s else torch.zeros(0, dtype=torch.float32, device=dev)
+                tau, _ = kth_best_unsorted(alls, k_global + 1, group)
+                radius = float(tau)
+                if kept_s:
+                    m = alls > radius
+                    kept_i, kept_j, kept_s = [torch.cat(kept_i)[m]], [torch.cat(kept_j)[m]], [alls[m]]
+                    n_kept = int(kept_s[0].numel())
+            # (what an event leaves: the hits STRICTLY above the (K+1)-th best -- at most K; an upper bound is all the skip
+            # rule above needs)
+            known_total, since = k_global, 0
         if trace is not None:
             trace.append((r0, r1, radius, total, event))
     if handover is not None:  # (the whole query set lies before `row`)
@@ -531,10 +679,27 @@ def merge_candidates(q_vid: torch.Tensor, r_vid: torch.Tensor, score: torch.Tens
     allp = all_gather_varlen(packed, group)
     s = allp[:, 2].to(torch.int32).view(torch.float32)
     # stable sort by score desc over (rank-ordered) concatenation == (score desc, first_i, first_j)
-    order = torch.sort(-s.to(torch.float64), stable=True).indices
+    order = argsort_scores_desc(s)
     allp = allp[order]
     return ShardedCandidates(allp[:, 0].to(torch.int32), allp[:, 1].to(torch.int32),
                              allp[:, 2].to(torch.int32).view(torch.float32), allp[:, 3], allp[:, 4])
+
+
+def argsort_scores_desc(s: torch.Tensor) -> torch.Tensor:
+    """Stable argsort of a score list, best first (equal scores keep their order; -0.0 == +0.0): libvscmi's radix sort
+    for HBM tensors (`vsc_argsort_scores`), torch's stable sort for the CPU tensors of the gloo tests."""
+    if not s.is_cuda:
+        return torch.sort(-s.to(torch.float64), stable=True).indices
+    from vsc2022_amd import _lib
+    from vsc2022_amd.engine import bind_aux_stream
+
+    s = s.to(torch.float32).contiguous()
+    perm = torch.empty(int(s.numel()), dtype=torch.int32, device=s.device)
+    if s.numel():
+        bind_aux_stream(s.device)
+        _lib.check(_lib.lib().vsc_argsort_scores(s.data_ptr(), int(s.numel()), _lib.MEM_DEVICE, perm.data_ptr(), _lib.MEM_DEVICE,
+                                                 s.device.index))
+    return perm.to(torch.int64)
 
 
 def shard_ranges(n_items: int, world: int) -> List[Tuple[int, int]]:
@@ -566,6 +731,19 @@ def ref_sharded_knn(local_scores: torch.Tensor, local_ids: torch.Tensor, k: int,
     allp = torch.cat(outs, dim=1).to(local_scores.device)  # [nq, world*k, 2]
     s = allp[..., 0].to(torch.int32).view(torch.float32)
     ids = allp[..., 1]
+    if s.is_cuda and world * k <= 1024:
+        # libvscmi's per-row rank-counting merge (`vsc_merge_topk`): one wavefront per query row
+        from vsc2022_amd import _lib
+        from vsc2022_amd.engine import bind_aux_stream
+
+        s, ids = s.contiguous(), ids.contiguous()
+        out_s = torch.empty((nq, k), dtype=torch.float32, device=s.device)
+        out_i = torch.empty((nq, k), dtype=torch.int64, device=s.device)
+        if nq:
+            bind_aux_stream(s.device)
+            _lib.check(_lib.lib().vsc_merge_topk(s.data_ptr(), ids.data_ptr(), int(nq), int(world * k), int(k), out_s.data_ptr(),
+                                                 out_i.data_ptr(), s.device.index))
+        return out_s, out_i
     empty = ids < 0
     # sort by (score desc, id asc): stable sort by id first, then stable by score
     big = torch.iinfo(torch.int64).max

@@ -426,6 +426,10 @@ class DeviceMatcher:
         import sys
         import time as _time
 
+        # phases accounted without synchronising (dist.PhaseTimer: host wall time + HIP-event device time per phase, bytes per
+        # collective) -- always on; VSC_SHARD_DEBUG=1 additionally synchronises around the legacy t_* wall clocks below
+        timer = vdist.PhaseTimer(dev)
+
         def clock():
             if debug:
                 torch.cuda.synchronize()
@@ -456,7 +460,8 @@ class DeviceMatcher:
                 if c > int(ss.numel()):
                     continue  # (the sample does not reach that deep: the batch is searched when the schedule gets there)
                 floor = float(np.nextafter(np.float32(ss[c - 1].item()), np.float32(-np.inf)))
-                i, j, sc = self._rows_above(self.q_feats[a:b], floor, int(1.3 * (b - a) * c / m) + (1 << 16))
+                with timer.phase("prepare_row_lists"):
+                    i, j, sc = self._rows_above(self.q_feats[a:b], floor, int(1.3 * (b - a) * c / m) + (1 << 16))
                 lists[(a, b)] = (floor, i + a, j, sc)
                 stats["prepared"] += 1
                 stats["prepared_hits"] += int(sc.numel())
@@ -472,7 +477,9 @@ class DeviceMatcher:
         if by_cols:
             ha, hb = local(0, head_end)
             t0 = clock()
-            head_q = vdist.all_gather_varlen(self.q_feats[ha:max(ha, hb)], group)   # rank order = row order
+            with timer.phase("gather_queries"):
+                head_q = vdist.all_gather_varlen(self.q_feats[ha:max(ha, hb)], group)   # rank order = row order
+            timer.add_bytes("gather_queries", int(head_q.numel()) * 4)
             stats["t_gather"] = clock() - t0
             c0, c1 = [(x // 64) * 64 for x in vdist.shard_ranges(nr, world)[rank]]
             if rank == world - 1:
@@ -495,7 +502,8 @@ class DeviceMatcher:
                 # the exact / fp16 / int8 rule of the single-process schedule for this batch (K / (rows so far x references));
                 # the budget below is several times the hits expected and would send int8 batches to the fp16 kernel
                 col_index.set_option("density_hint", min(1.0, K / (float(r0) * nr)) if r0 > 0 else 1.0)
-                i, j, sc = self._rows_above(head_q[r0:r1], radius, head_budget(r0, r1 - r0, 1.3 / world), index=col_index)
+                with timer.phase("search"):
+                    i, j, sc = self._rows_above(head_q[r0:r1], radius, head_budget(r0, r1 - r0, 1.3 / world), index=col_index)
                 stats["on_demand"] += 1
                 stats["t_on_demand"] = stats.get("t_on_demand", 0.0) + clock() - t0
                 return i + r0, j + c0, sc          # GLOBAL rows until the hand-over
@@ -511,7 +519,8 @@ class DeviceMatcher:
                 print(f"[shard {row_base}] batch at row {r0}: floor {got[0]:.6f} > radius {radius:.6f} ({int(got[3].numel())} listed)",
                       file=sys.stderr, flush=True)
             t0 = clock()
-            i, j, sc = self._rows_above(self.q_feats[a:b], radius, head_budget(r0, b - a, 1.0))
+            with timer.phase("search"):
+                i, j, sc = self._rows_above(self.q_feats[a:b], radius, head_budget(r0, b - a, 1.0))
             stats["t_on_demand"] = stats.get("t_on_demand", 0.0) + clock() - t0
             return i + a, j, sc
 
@@ -520,7 +529,9 @@ class DeviceMatcher:
             t0 = clock()
             bases = torch.tensor(vdist._all_gather_scalar(row_base, dev, group), dtype=torch.int64, device=dev)
             owner = torch.searchsorted(bases, i.to(torch.int64), right=True) - 1
-            got = vdist.send_to_owners(torch.stack([i, j, sc.view(torch.int32)], dim=1), owner, group)
+            with timer.phase("handover"):
+                got = vdist.send_to_owners(torch.stack([i, j, sc.view(torch.int32)], dim=1), owner, group)
+            timer.add_bytes("handover", int(i.numel()) * 12)
             stats["t_handover"] = clock() - t0
             return got[:, 0] - row_base, got[:, 1].contiguous(), got[:, 2].contiguous().view(torch.float32)
 
@@ -528,17 +539,22 @@ class DeviceMatcher:
         t0 = clock()
         radius, hi, hj, hs = vdist.emulate_schedule(search_rows, n_rows, K, group, dev,
                                                     handover=(head_end, to_row_owners) if by_cols else None,
-                                                    timing=(clock, stats) if debug else None)
+                                                    timer=timer, n_cols_total=nr)
         stats["t_emulate"] = clock() - t0
         t0 = clock()
         # (score desc, row asc, ref asc): the order the reference's stable sort leaves, then the global cut at K
-        if hs.numel():
-            hi, hj, hs = sort_hits_device(hi, hj, hs, max_row=nq_loc, max_ref=nr)
-        n_take, tau, info = vdist.distributed_prefix_select(hs, K, group, ties="rank", return_info=True)
+        with timer.phase("final_sort_and_cut"):
+            if hs.numel():
+                hi, hj, hs = sort_hits_device(hi, hj, hs, max_row=nq_loc, max_ref=nr)
+            n_take, tau, info = vdist.distributed_prefix_select(hs, K, group, ties="rank", return_info=True)
         stats["t_final"] = clock() - t0
+        # (the selection's host sync is behind us: reading the events costs nothing more)
+        stats["phases"] = timer.collect()
+        stats["count_skipped"] = timer.calls.get("count_skipped", 0)
+        stats["rows_above_reruns"] = getattr(self, "rows_above_reruns", 0)
         self.last_shard_stats = stats
         if debug:
-            print(f"[shard {row_base}] " + " ".join(f"{k}={v:.3f}" if isinstance(v, float) else f"{k}={v}" for k, v in stats.items()),
+            print(f"[shard {row_base}] " + " ".join(f"{k}={v:.3f}" if isinstance(v, float) else f"{k}={v}" for k, v in stats.items() if k != "phases"),
                   file=sys.stderr, flush=True)
         return hi[:n_take], hj[:n_take], hs[:n_take], radius, info
 

@@ -128,7 +128,13 @@ class RefShardedIndex:
                               hs.contiguous().view(torch.int32).to(torch.int64)], dim=1)
         allp = vdist.all_gather_varlen(packed, self.group)
         s = allp[:, 2].to(torch.int32).view(torch.float32)
-        # (score desc, row asc, ref asc): stable sorts from the least significant key up
+        if s.is_cuda and int(allp[:, 1].max().item() if allp.shape[0] else 0) < (1 << 31):
+            # libvscmi's radix sorts (`vsc_sort_hits`: score desc, row asc, ref asc -- vsc/index.py:158-165)
+            from vsc2022_amd.engine import sort_hits_device
+
+            oi, oj, os_ = sort_hits_device(allp[:, 0], allp[:, 1], s, max_row=n)
+            return oi[: int(K)], oj[: int(K)].to(torch.int64), os_[: int(K)], tau
+        # (score desc, row asc, ref asc): stable sorts from the least significant key up (CPU tensors: the gloo tests)
         o = torch.sort(allp[:, 1], stable=True).indices
         o = o[torch.sort(allp[o, 0], stable=True).indices]
         o = o[torch.sort(-s[o].to(torch.float64), stable=True).indices][: int(K)]
