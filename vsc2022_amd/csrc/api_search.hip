@@ -345,12 +345,9 @@ static int enqueue_batch(vsc_index* idx, const float* qpacked, int64_t i0, int64
 }
 
 int init_ctl(vsc_index* idx, float radius_score_space) {
-    SelectCtl h;
-    memset(&h, 0, sizeof(h));
-    h.radius = radius_score_space;
-    VSC_HIP(hipMemcpyAsync(idx->ws.ctl.p, &h, sizeof(h), hipMemcpyHostToDevice, idx->stream));
-    VSC_HIP(hipStreamSynchronize(idx->stream));  // h is a stack object
-    return VSC_OK;
+    // (a one-workgroup kernel instead of a host-staged copy + synchronisation: the sharded schedule calls the seeded
+    // search once per batch and rank, and every host round trip is ~40 us of idle GPU there -- profiles/r06_rank_work.md)
+    return launch_ctl_init(idx->ws.ctl.as<SelectCtl>(), radius_score_space, idx->stream);
 }
 
 
@@ -406,6 +403,24 @@ static int global_topk_impl(vsc_index_t* idx, const float* q, int64_t nq, int q_
             const bool i8 = f16 && allow_i8 && (idx->i8_mode == 2 || dens < idx->i8_density);
             used_i8 |= i8;
             VSC_TRY(enqueue_batch(idx, qp, i0, i1, cap, f16, i8));
+            // The re-threshold round is predicated on the device (kept > 2K) and costs twelve launches even when it does
+            // nothing.  Behind the LAST batch the control block is read back anyway: the round is enqueued there only
+            // if that read says it has work to do (the one-batch calls of the sharded schedule almost never do).
+            if (i1 < nq) {
+                hipEvent_t stop;
+                VSC_TRY(prof_begin(idx, &stop, 3));
+                VSC_TRY(enqueue_rethreshold(ctl, idx->ws.hA[0].as<int32_t>(), idx->ws.hA[1].as<int32_t>(),
+                                            idx->ws.hA[2].as<float>(), idx->ws.hB[0].as<int32_t>(),
+                                            idx->ws.hB[1].as<int32_t>(), idx->ws.hB[2].as<float>(),
+                                            (unsigned long long)K, idx->stream));
+                VSC_TRY(prof_end(idx, stop, 0.0, 3));
+            }
+            if (!seeded && bs < 20000) bs *= 2;
+            i0 = i1;
+        }
+        VSC_HIP(hipMemcpyAsync(&h, ctl, sizeof(h), hipMemcpyDeviceToHost, idx->stream));
+        VSC_HIP(hipStreamSynchronize(idx->stream));
+        if (!h.overflow && h.n > 2ull * (unsigned long long)K) {
             hipEvent_t stop;
             VSC_TRY(prof_begin(idx, &stop, 3));
             VSC_TRY(enqueue_rethreshold(ctl, idx->ws.hA[0].as<int32_t>(), idx->ws.hA[1].as<int32_t>(),
@@ -413,11 +428,9 @@ static int global_topk_impl(vsc_index_t* idx, const float* q, int64_t nq, int q_
                                         idx->ws.hB[1].as<int32_t>(), idx->ws.hB[2].as<float>(),
                                         (unsigned long long)K, idx->stream));
             VSC_TRY(prof_end(idx, stop, 0.0, 3));
-            if (!seeded && bs < 20000) bs *= 2;
-            i0 = i1;
+            VSC_HIP(hipMemcpyAsync(&h, ctl, sizeof(h), hipMemcpyDeviceToHost, idx->stream));
+            VSC_HIP(hipStreamSynchronize(idx->stream));
         }
-        VSC_HIP(hipMemcpyAsync(&h, ctl, sizeof(h), hipMemcpyDeviceToHost, idx->stream));
-        VSC_HIP(hipStreamSynchronize(idx->stream));
         VSC_TRY(prof_collect(idx));
         idx->stat_candidates = h.n_cand_total;
         if (!h.overflow) break;

@@ -171,6 +171,20 @@ __global__ void select_end_kernel(SelectCtl* c) {
     if (c->active) c->n = c->n_tmp;
 }
 
+// A fresh control block for a search: everything zero, the radius set (stream-ordered: no host staging, no sync).
+__global__ void ctl_init_kernel(SelectCtl* c, float radius) {
+    unsigned int* w = reinterpret_cast<unsigned int*>(c);
+    for (unsigned x = threadIdx.x; x < sizeof(SelectCtl) / 4; x += blockDim.x) w[x] = 0u;
+    __syncthreads();
+    if (threadIdx.x == 0) c->radius = radius;
+}
+int launch_ctl_init(SelectCtl* ctl, float radius, hipStream_t stream) {
+    static_assert(sizeof(SelectCtl) % 4 == 0, "SelectCtl is cleared word by word");
+    hipLaunchKernelGGL(ctl_init_kernel, dim3(1), dim3(256), 0, stream, ctl, radius);
+    VSC_HIP(hipGetLastError());
+    return VSC_OK;
+}
+
 // Enqueue one "if n > 2K: radius <- (K+1)-th best; keep score > radius" round.
 int enqueue_rethreshold(SelectCtl* ctl, int32_t* ai, int32_t* aj, float* as, int32_t* bi, int32_t* bj,
                         float* bs, unsigned long long K, hipStream_t stream) {
