@@ -546,7 +546,7 @@ def config2_shape_leg(args, torch, dev, dim):
     return out
 
 
-def distribution_leg(args, torch, dev, dim, dist, score_norm=False, exhaustive=True, steps=2):
+def distribution_leg(args, torch, dev, dim, dist, score_norm=False, exhaustive=True, steps=2, geo_kw=None):
     """BASELINE configs[1]'s shape (8000 query videos x 25 frames vs 2 M reference frames) on descriptors of another
     distribution class (vsc2022_amd/synth.py): what the pre-filters' bounds, the density rules and
     the 1-NN ranges -- all tuned on isotropic rows -- do on clustered / anisotropic / shifted data.  Reports ms per
@@ -559,11 +559,13 @@ def distribution_leg(args, torch, dev, dim, dist, score_norm=False, exhaustive=T
     from vsc2022_amd.vsc.index import FlatIndex
 
     n_qv, qf, n_rv, rf = args.query_videos, args.query_frames, args.ref_videos, args.ref_frames
-    geo = None if dist == "gaussian" else synth.Geometry(dist, dim, args.seed)
+    geo = None if dist == "gaussian" else synth.Geometry(dist, dim, args.seed, **(geo_kw or {}))
     refs = synth_on_device(torch, dev, args.seed, n_rv, rf, dim, dist=dist, geometry=geo, duplicates=True)
     queries = synth_on_device(torch, dev, args.seed + 1000, n_qv, qf, dim, dist=dist, geometry=geo)
     gt = plant_copies(torch, dev, args.seed + 2000, queries, n_qv, qf, refs, n_rv, rf)
     out = {"data": dist, "score_normalised": bool(score_norm)}
+    if geo_kw:
+        out["geometry"] = dict(geo_kw)
     bias = 0.0
     if score_norm:
         noise = synth_on_device(torch, dev, args.seed + 77, n_rv * rf, 1, dim, static_frac=0.0, dist=dist, geometry=geo)

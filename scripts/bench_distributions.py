@@ -25,6 +25,7 @@ def main():
     ap.add_argument("--score-norm", action="store_true", help="also the score-normalised form of every class")
     ap.add_argument("--query-videos", type=int, default=8000)
     ap.add_argument("--no-exhaustive", action="store_true")
+    ap.add_argument("--geo", default="", help='JSON keyword arguments of synth.Geometry, e.g. \'{"n_dominant": 0}\'')
     a = ap.parse_args()
     sys.argv = sys.argv[:1]
     args = bench.parse()
@@ -34,7 +35,8 @@ def main():
     for dist in a.classes.split(","):
         for sn in ((False, True) if a.score_norm else (False,)):
             try:
-                rep = bench.distribution_leg(args, torch, dev, args.dim, dist, score_norm=sn, exhaustive=not a.no_exhaustive)
+                rep = bench.distribution_leg(args, torch, dev, args.dim, dist, score_norm=sn, exhaustive=not a.no_exhaustive,
+                                             geo_kw=json.loads(a.geo) if a.geo else None)
             except Exception as exc:  # noqa: BLE001
                 rep = {"data": dist, "score_normalised": sn, "error": f"{type(exc).__name__}: {exc}"}
             print(json.dumps(rep), flush=True)

@@ -584,6 +584,21 @@ def _emulate_worker(rank, world, port, Ks, out_path, by_cols=False):
             head_end = min([a for a, _ in vdist.exponential_batches(len(q)) if a >= 96] + [len(q)])
             radius, hi_, hj_, hs_ = vdist.emulate_schedule(search_rows, len(q), K, trace=trace,
                                                            handover=(head_end, to_row_owners) if by_cols else None)
+            if world == 2:
+                # the same walk with the per-batch count all-reduce skipped wherever no event is possible (n_cols_total: the
+                # engine's form of the call, round 6) and the phases accounted by a PhaseTimer: same radius, same hits
+                timer = vdist.PhaseTimer(None)
+                radius2, hi2, hj2, hs2 = vdist.emulate_schedule(search_rows, len(q), K, n_cols_total=len(r), timer=timer,
+                                                                handover=(head_end, to_row_owners) if by_cols else None)
+                assert np.float32(radius2) == np.float32(radius)
+                o1 = np.lexsort((hj_.numpy(), hi_.numpy()))
+                o2 = np.lexsort((hj2.numpy(), hi2.numpy()))
+                assert np.array_equal(hi2.numpy()[o2], hi_.numpy()[o1]) and np.array_equal(hj2.numpy()[o2], hj_.numpy()[o1])
+                assert np.array_equal(hs2.numpy()[o2].view(np.uint32), hs_.numpy()[o1].view(np.uint32))
+                rep = timer.collect()
+                n_batches = len(vdist.exponential_batches(len(q)))
+                assert rep.get("count", {"calls": 0})["calls"] + timer.calls.get("count_skipped", 0) == n_batches
+                res[f"k{K}"] = np.array([timer.calls.get("count_skipped", 0)])
             order = np.lexsort((hj_.numpy(), hi_.numpy(), -hs_.numpy().astype(np.float64)))
             hs_sorted = hs_[torch.from_numpy(order)]
             n_take, tau, info = vdist.distributed_prefix_select(hs_sorted, K, ties="rank", return_info=True)
@@ -630,6 +645,8 @@ def test_emulated_schedule_over_query_shards_is_the_references(tmp_path, world, 
         if K in cls["dropped"]:
             assert len(s) < K
     assert used > 0 and redone > 0, (used, redone)   # both ways of answering a batch were exercised
+    if world == 2:
+        assert sum(int(p[f"k{K}"][0]) for p in parts for K in Ks) > 0   # (counts really were skipped somewhere)
 
 
 def test_kth_best_unsorted_single_process():

@@ -160,10 +160,49 @@ __global__ __launch_bounds__(256) void group_scale_keys_kernel(const int32_t* __
     keys[p] = ((uint32_t)(p >> group_shift) << 20) | (f2key(scale[perm[p]]) >> 12);
 }
 
+// The same order in ONE launch when a group fits a workgroup (<= 1024 positions; the default is 512): the positions are
+// already grouped, so the "sort by (group, scale)" is a stable sort by scale INSIDE every group -- rank counting in LDS,
+// one workgroup per group: rank(p) = #{p' of the group: key(p') < key(p), or equal and p' < p}.  Same keys (the top 20
+// bits of the scale's order-preserving image), same stable order as the four radix passes it replaces -- which were 16
+// launches of ~5 us kernels per batch and rank of the column-sharded schedule (profiles/r06_rank_work.md).
+__global__ __launch_bounds__(1024) void group_scale_rank_kernel(const int32_t* __restrict__ perm, const float* __restrict__ scale, int n,
+                                                                int group_shift, int32_t* __restrict__ out) {
+    __shared__ uint32_t key[1024];
+    const int G = 1 << group_shift;
+    const int base = blockIdx.x << group_shift;
+    const int cnt = min(G, n - base);
+    const int t = threadIdx.x;
+    int32_t row = 0;
+    uint32_t mine = 0;
+    if (t < cnt) {
+        row = perm[base + t];
+        mine = f2key(scale[row]) >> 12;
+        key[t] = mine;
+    }
+    __syncthreads();
+    if (t >= cnt) return;
+    int rank = 0;
+    for (int f = 0; f < cnt; ++f) {
+        const uint32_t kf = key[f];
+        rank += (kf < mine) || (kf == mine && f < t);
+    }
+    out[base + rank] = row;
+}
+
 int sort_rows_by_threshold_then_scale(const float* thr, const float* scale, int64_t n, int group_shift, DevBuf& w0, DevBuf& w1,
                                       DevBuf& w2, DevBuf& w3, DevBuf& tmp, const int32_t** perm, hipStream_t stream) {
     VSC_TRY(sort_rows_by_threshold(thr, n, w0, w1, w2, w3, tmp, perm, stream));
     if (n <= 0 || (n >> group_shift) >= 4096) return VSC_OK;  // (12 bits of group number)
+    if (group_shift <= 10) {
+        int32_t* va = const_cast<int32_t*>(*perm);
+        int32_t* vb = va == w2.as<int32_t>() ? w3.as<int32_t>() : w2.as<int32_t>();
+        const int G = 1 << group_shift;
+        hipLaunchKernelGGL(group_scale_rank_kernel, dim3((unsigned)((n + G - 1) >> group_shift)), dim3(std::max(64, G)), 0, stream,
+                           va, scale, (int)n, group_shift, vb);
+        VSC_HIP(hipGetLastError());
+        *perm = vb;
+        return VSC_OK;
+    }
     uint32_t *ka = w0.as<uint32_t>(), *kb = w1.as<uint32_t>();
     int32_t* va = const_cast<int32_t*>(*perm);
     int32_t* vb = va == w2.as<int32_t>() ? w3.as<int32_t>() : w2.as<int32_t>();
