@@ -502,8 +502,14 @@ class DeviceMatcher:
                 # the exact / fp16 / int8 rule of the single-process schedule for this batch (K / (rows so far x references));
                 # the budget below is several times the hits expected and would send int8 batches to the fp16 kernel
                 col_index.set_option("density_hint", min(1.0, K / (float(r0) * nr)) if r0 > 0 else 1.0)
+                # the budget: 1.3 x an even share of what the whole batch can hold -- or 1.5 x the share THIS slice showed in the
+                # batch before, whichever is larger (with copied / clustered reference videos a slice can hold several
+                # times its even share, and an undersized budget costs a second search of the batch)
+                share = max(1.3 / world, min(1.0, 1.5 * stats.get("slice_share", 0.0)))
                 with timer.phase("search"):
-                    i, j, sc = self._rows_above(head_q[r0:r1], radius, head_budget(r0, r1 - r0, 1.3 / world), index=col_index)
+                    i, j, sc = self._rows_above(head_q[r0:r1], radius, head_budget(r0, r1 - r0, share), index=col_index)
+                stats["slice_share"] = float(sc.numel()) / max(head_budget(r0, r1 - r0, 1.0) - (1 << 20), 1)
+                stats["slice_share_max"] = max(stats.get("slice_share_max", 0.0), stats["slice_share"])
                 stats["on_demand"] += 1
                 stats["t_on_demand"] = stats.get("t_on_demand", 0.0) + clock() - t0
                 return i + r0, j + c0, sc          # GLOBAL rows until the hand-over
