@@ -1,0 +1,24 @@
+import sys, time, os
+sys.path.insert(0, os.getcwd())
+import torch, numpy as np
+from vsc2022_amd import _lib
+from vsc2022_amd.vsc.index import FlatIndex
+dev = torch.device("cuda", 0)
+def unit(n, d, seed):
+    g = torch.Generator(device=dev); g.manual_seed(seed)
+    x = torch.randn((n, d), generator=g, device=dev); return x / x.norm(dim=1, keepdim=True)
+shard = unit(4_000_000, 512, 100); q = unit(4096, 512, 7)
+idx = FlatIndex(512, _lib.METRIC_INNER_PRODUCT, 0); idx.add(shard)
+def t(f, name):
+    torch.cuda.synchronize(); t0 = time.perf_counter(); r = f(); torch.cuda.synchronize(); print(name, round(time.perf_counter() - t0, 3), flush=True); return r
+for rep in range(2):
+    t(lambda: idx.search(q, 20), "knn20")
+    for K in (62501, 200001):
+        r = t(lambda: idx.global_topk(q, K, device_out=True), f"topk {K}")
+        print("  n", r[2].numel(), "radius", r[3])
+    t(lambda: idx.range_scores(q[:2048], 0.2, 400000, device_out=True), "range_scores")
+print("--- the first two batches of emulate_schedule_radius on this shard")
+t(lambda: idx.range_scores(q[:32], -1e10, 400000, device_out=True), "range_scores batch 0-32 at -1e10")
+t(lambda: idx.range_scores(q[32:96], 0.14785, 400000, device_out=True), "range_scores batch 32-96 at 0.14785")
+t(lambda: idx.range_scores(q[32:96], 0.14785, 400000, device_out=True), "again")
+t(lambda: idx.global_topk(q[32:96], 400000, device_out=True, seed_radius=0.14785), "seeded topk 400000")

@@ -158,6 +158,17 @@ def _full_worker(rank, world, port, out_dir):
         from vsc2022_amd.refshard import RefShardedIndex
         from vsc2022_amd.vsc.index import FlatIndex
 
+        import time as _time
+
+        t_mark = [_time.perf_counter()]
+
+        def mark(what):   # VSC_TEST_TIMING=1: where the seconds of this test go (4 processes share one GPU)
+            if os.environ.get("VSC_TEST_TIMING") == "1":
+                torch.cuda.synchronize()
+                now = _time.perf_counter()
+                print(f"[full_worker {rank}] {what}: {now - t_mark[0]:.2f} s", file=sys.stderr, flush=True)
+                t_mark[0] = now
+
         dev = torch.device("cuda", 0)
         n, d = FULL["refs_per_rank"], FULL["dim"]
         shard = _unit(n, d, 100 + rank, dev)
@@ -171,11 +182,16 @@ def _full_worker(rank, world, port, out_dir):
         dist.all_reduce(rows)
         q[:64] = rows.to(dev)
         local = FlatIndex(d, _lib.METRIC_INNER_PRODUCT, 0)
+        mark("data")
         local.add(shard)
+        mark("add")
         idx = RefShardedIndex(local, rank * n, world * n, None, dev)
         D, I = idx.search(q, FULL["k"])
+        mark("search 1")
         D2, I2 = idx.search(q, FULL["k"])           # idempotence
+        mark("search 2")
         i, j, s, tau = idx.global_topk(q, FULL["K"])
+        mark("global_topk")
         # sample for the oracle: the shard rows that the merged results of 24 query rows point into, + 3000 more
         sample_q = np.r_[np.arange(8), np.arange(64, 64 + 16)]
         want = np.unique(I[sample_q].ravel())
