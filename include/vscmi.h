@@ -82,6 +82,10 @@ int vsc_device_count(void);
  *   VSC_I8_MAX_REL=f          sqrt(dim) x mean(E_r / N'_r) of the references above which the index never starts
  *                             on int8 (default 0.35: the 8-bit bound would pass too much of the matrix)
  *   VSC_I8_EXCLUDE=0          keep coordinates on which all references agree inside the int8 images
+ *   VSC_I8_CENTER=0|1|2       the int8 reference image holds y - mu, mu = the mean of the rows present when the image is first
+ *                             written; the rows' x . mu moves their thresholds (exact: x.y = x.(y - mu) + x.mu).  1 (default):
+ *                             when the mean carries >= 2 % of the rows' energy (uncentred embeddings; isotropic rows are left
+ *                             alone), 0 never, 2 always (tests).  Read-only options "i8_center_on", "i8_center_share"
  *   VSC_I8_SORT=0             int8 launches see their rows in batch order (default: sorted by threshold / scale)
  *   VSC_I8_GROUP=n            radius searches with per-row thresholds (excluded coordinates): inside groups of 2^n
  *                             rows of the threshold order the rows are ordered by scale (default 9; 0: off)
@@ -114,7 +118,7 @@ int vsc_index_create(int dim, int metric, int device, vsc_index_t** out);
 int vsc_index_destroy(vsc_index_t* idx);
 /* Programmatic form of the switches above (the reference's analogue: faiss.ParameterSpace().set_index_parameter(index,
  * name, value) on the object vsc/index.py:82 creates).  Options that decide which images of the reference rows are kept
- * ("prefilter" 0 <-> non-0, "i8" 0 <-> non-0, "f16_kernel", "i8_exclude") can only change while the index is empty:
+ * ("prefilter" 0 <-> non-0, "i8" 0 <-> non-0, "f16_kernel", "i8_exclude", "i8_center") can only change while the index is empty:
  * VSC_ERR_INVALID otherwise, as for an unknown name or an out-of-range value.  "cand_budget": entries of the candidate
  * list a k-NN threshold pass may ask for (default 2^28; the rows per launch are halved until it fits). */
 int vsc_index_set_option(vsc_index_t* idx, const char* name, double value);

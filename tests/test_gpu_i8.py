@@ -26,33 +26,16 @@ def bits(x):
     return np.ascontiguousarray(x, dtype=np.float32).view(np.uint32)
 
 
-class env:
-    """VSC_PREFILTER / VSC_I8 are read when an index handle is created."""
-
-    def __init__(self, **kv):
-        self.kv = kv
-
-    def __enter__(self):
-        self.old = {k: os.environ.get(k) for k in self.kv}
-        for k, v in self.kv.items():
-            if v is None:
-                os.environ.pop(k, None)
-            else:
-                os.environ[k] = v
-
-    def __exit__(self, *exc):
-        for k, v in self.old.items():
-            if v is None:
-                os.environ.pop(k, None)
-            else:
-                os.environ[k] = v
+def opts(**kv):
+    """{VSC_X: value-or-None} in the spelling of the environment switches -> the handle's options (set while it is empty:
+    `FlatIndex(d, options=...)` -> vsc_index_set_option; no test mutates os.environ around a handle's creation)."""
+    return {k[4:].lower(): float(v) for k, v in kv.items() if v is not None}
 
 
 def forced_index(d):
     from vsc2022_amd.vsc.index import FlatIndex
 
-    with env(VSC_PREFILTER="2", VSC_I8="2"):
-        return FlatIndex(d)
+    return FlatIndex(d, options=opts(VSC_PREFILTER="2", VSC_I8="2"))
 
 
 def i8_launches(idx):
@@ -199,8 +182,7 @@ def test_int8_chosen_by_density_equals_fp16_and_fp32_routes(gpu):
     K = 300000
     outs = []
     for kv in (dict(VSC_I8=None, VSC_PREFILTER=None), dict(VSC_I8="0", VSC_PREFILTER=None), dict(VSC_I8="0", VSC_PREFILTER="0")):
-        with env(**kv):
-            idx = FlatIndex(128)
+        idx = FlatIndex(128, options=opts(**kv))
         idx.profile(True)
         idx.add(r)
         out = idx.global_topk(q, K)
@@ -287,8 +269,7 @@ def test_int8_is_chosen_for_score_normalised_descriptors(gpu):
     outs = []
     for kv in (dict(VSC_I8=None, VSC_PREFILTER=None, VSC_I8_EXCLUDE=None), dict(VSC_I8="0", VSC_PREFILTER=None, VSC_I8_EXCLUDE=None),
                dict(VSC_I8="0", VSC_PREFILTER="0", VSC_I8_EXCLUDE=None)):
-        with env(**kv):
-            idx = FlatIndex(128)
+        idx = FlatIndex(128, options=opts(**kv))
         idx.profile(True)
         idx.add(r)
         out = idx.global_topk(q, K)
@@ -297,6 +278,107 @@ def test_int8_is_chosen_for_score_normalised_descriptors(gpu):
     for other in outs[1:]:
         assert_same(outs[0][0][:3], other[0][:3])
         assert outs[0][0][3] == other[0][3]
+
+
+def shifted(rng, n, d, mean_cos, dominant=0, geometry_seed=3):
+    """unit rows with a common direction: two random rows at cosine ~ mean_cos (uncentred embeddings); `dominant`
+    coordinates at 4 x the scale.  Direction and dominant coordinates come from `geometry_seed`: shared by both sides."""
+    geo = np.random.default_rng(geometry_seed)
+    mu = unit(geo, 1, d)[0] * np.sqrt(d * mean_cos / (1.0 - mean_cos))
+    x = rng.standard_normal((n, d)).astype(np.float32) + mu.astype(np.float32)
+    if dominant:
+        x[:, geo.permutation(d)[:dominant]] *= 4.0
+    return (x / np.linalg.norm(x, axis=1, keepdims=True)).astype(np.float32)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("nq,nr,d,K,k,cos,centre", [(700, 3000, 128, 900, 5, 0.3, 2), (300, 2500, 512, 400, 1, 0.5, 1),
+                                                  (1100, 5000, 65, 3000, 20, 0.1, 2), (900, 4000, 256, 50000, 3, 0.0, 2)])
+def test_centred_int8_image_is_invisible_in_the_results(gpu, orc, nq, nr, d, K, k, cos, centre):
+    """quant_i8.hip "CENTRED references": the int8 image holds y - mu, the rows' x . mu moves their thresholds.  Forced
+    onto every pre-filtered batch (centre = 2: always; 1: decided from the mean's share of the energy), rows added in two
+    pieces (the centre is fixed at the first catch-up), top-K / k-NN / range search against the oracle bit for bit."""
+    from vsc2022_amd.vsc.index import FlatIndex
+
+    rng = np.random.default_rng(nq + d)
+    q, r = shifted(rng, nq, d, cos, 2), shifted(rng, nr, d, cos, 2)
+    r[40:70] = r[40]                     # exact ties
+    q[5] = r[40]
+    idx = FlatIndex(d, options=opts(VSC_PREFILTER="2", VSC_I8="2", VSC_I8_CENTER=str(centre)))
+    idx.profile(True)
+    idx.add(r[: nr // 3])
+    top = idx.global_topk(q, K)          # (first search: the centre is decided on a third of the rows)
+    assert_same(top[:3], orc.global_threshold_search(q, r[: nr // 3], K))
+    idx.add(r[nr // 3 :])
+    assert idx.get_option("i8_center_on") == (1.0 if (centre == 2 or cos >= 0.05) else 0.0)
+    top = idx.global_topk(q, K)
+    assert_same(top[:3], orc.global_threshold_search(q, r, K))
+    D, I = idx.search(q, k)
+    Do, Io = orc.knn(q, r, k)
+    assert np.array_equal(I, Io) and np.array_equal(bits(D), bits(Do))
+    radius = float(np.sort(top[2])[len(top[2]) // 2]) if len(top[2]) else 0.5
+    lims, Dr, Ir = idx.range_search(q, radius)
+    ol, oD, oI = orc.range_search(q, r, radius)
+    assert np.array_equal(lims, ol) and np.array_equal(Ir, oI) and np.array_equal(bits(Dr), bits(oD))
+    assert i8_launches(idx) > 0
+
+
+@pytest.mark.gpu
+def test_centring_and_excluded_coordinates_together(gpu, orc):
+    """Score-normalised rows WITH a common direction: one coordinate is 1 on every reference (left out of the image, its
+    contribution in the rows' thresholds) and the other coordinates are centred; rows that break the constant coordinate
+    arrive later (the excluded set shrinks, the image is rewritten with the same centre)."""
+    from vsc2022_amd.vsc.index import FlatIndex
+
+    rng = np.random.default_rng(5)
+    d, nq, nr = 129, 600, 4000
+    q = np.concatenate([shifted(rng, nq, d - 1, 0.3), -rng.uniform(0.15, 0.45, (nq, 1)).astype(np.float32)], axis=1)
+    r = np.concatenate([shifted(rng, nr, d - 1, 0.3), np.ones((nr, 1), np.float32)], axis=1)
+    q, r = np.ascontiguousarray(q), np.ascontiguousarray(r)
+    idx = FlatIndex(d, options=opts(VSC_PREFILTER="2", VSC_I8="2"))
+    idx.profile(True)
+    idx.add(r)
+    for K in (500, 20000):
+        assert_same(idx.global_topk(q, K)[:3], orc.global_threshold_search(q, r, K))
+    assert idx.get_option("i8_center_on") == 1.0
+    D, I = idx.search(q, 4)
+    Do, Io = orc.knn(q, r, 4)
+    assert np.array_equal(I, Io) and np.array_equal(bits(D), bits(Do))
+    more = r[:500].copy()
+    more[:, -1] = 0.5                    # the last coordinate is no longer constant
+    idx.add(more)
+    r2 = np.concatenate([r, more])
+    assert_same(idx.global_topk(q, 3000)[:3], orc.global_threshold_search(q, r2, 3000))
+    D, I = idx.search(q, 2)
+    Do, Io = orc.knn(q, r2, 2)
+    assert np.array_equal(I, Io) and np.array_equal(bits(D), bits(Do))
+    assert i8_launches(idx) > 0
+
+
+@pytest.mark.gpu
+def test_centring_is_decided_by_the_data_and_cuts_the_candidates(gpu):
+    """Default rule (i8_center = 1): isotropic rows are not centred (nothing changes for them), rows at mutual cosine 0.4
+    are -- and the centred image passes fewer candidates to the exact stage than the uncentred one, with the same result."""
+    from vsc2022_amd.vsc.index import FlatIndex
+
+    rng = np.random.default_rng(9)
+    iso = FlatIndex(128)
+    iso.add(unit(rng, 20000, 128))
+    iso.global_topk(unit(rng, 64, 128), 100)
+    assert iso.get_option("i8_center_on") == 0.0 and iso.get_option("i8_center_share") < 0.01
+    q, r = shifted(rng, 20000, 256, 0.4), shifted(np.random.default_rng(10), 150000, 256, 0.4)
+    outs = []
+    for c in (0, 1):
+        idx = FlatIndex(256, options=opts(VSC_PREFILTER="2", VSC_I8="2", VSC_I8_CENTER=str(c)))
+        idx.profile(True)
+        idx.add(r)
+        top = idx.global_topk(q, 400000)
+        outs.append((top, idx.profile_read(reset=True)["candidates"], idx.get_option("i8_center_on")))
+    assert outs[0][2] == 0.0 and outs[1][2] == 1.0
+    assert_same(outs[0][0][:3], outs[1][0][:3])
+    assert outs[0][0][3] == outs[1][0][3]
+    print("candidates uncentred / centred:", outs[0][1], outs[1][1])
+
 
 
 @pytest.mark.gpu
@@ -308,6 +390,19 @@ def test_parity_suites_with_forced_int8():
                         "tests/test_gpu_edge_cases.py", "tests/test_gpu_golden.py", "tests/test_gpu_sharded.py",
                         "tests/test_gpu_prefilter.py", "-k", "not forced_prefilter and not fp32_path_at_scale "
                         "and not chosen_by_size"],
+                       cwd=ROOT, env=e, capture_output=True, text=True, timeout=1800)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+
+
+@pytest.mark.gpu
+def test_parity_suites_with_a_centred_int8_image():
+    """VSC_I8_CENTER=2 (every index centres its int8 reference image, whatever the data) with int8 forced onto every
+    pre-filtered batch: the search / edge-case / golden / distribution suites and this file's oracle tests again."""
+    e = dict(os.environ, VSC_PREFILTER="2", VSC_TEST_QUICK="1", VSC_I8="2", VSC_I8_CENTER="2")
+    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", "tests/test_gpu_search.py",
+                        "tests/test_gpu_edge_cases.py", "tests/test_gpu_golden.py", "tests/test_gpu_i8.py",
+                        "tests/test_gpu_distributions.py", "-k", "matches_oracle or extreme_rows or range_search or golden or "
+                        "edge or search or constant_reference or excluded_coordinates or small_sets"],
                        cwd=ROOT, env=e, capture_output=True, text=True, timeout=1800)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
 
@@ -336,10 +431,9 @@ def test_paired_work_items_give_the_same_candidates_and_results(gpu, orc, nq, nr
     q, r = unit(rng, nq, d), unit(rng, nr, d)
     outs = []
     for pair in ("0", "2"):
-        with env(VSC_PREFILTER="2", VSC_I8="2", VSC_I8P_PAIR=pair):
-            from vsc2022_amd.vsc.index import FlatIndex
+        from vsc2022_amd.vsc.index import FlatIndex
 
-            idx = FlatIndex(d)
+        idx = FlatIndex(d, options=opts(VSC_PREFILTER="2", VSC_I8="2", VSC_I8P_PAIR=pair))
         idx.profile(True)
         idx.add(r)
         top = idx.global_topk(q, K)
@@ -381,8 +475,7 @@ def test_knn_rows_per_launch_do_not_change_results(gpu, k):
     outs = []
     for kv in (dict(VSC_KNN_STEP=None, VSC_PREFILTER="2", VSC_I8="2"), dict(VSC_KNN_STEP="32768", VSC_PREFILTER="2", VSC_I8="2"),
                dict(VSC_KNN_STEP=None, VSC_PREFILTER="0", VSC_I8=None)):
-        with env(**kv):
-            idx = FlatIndex(64)
+        idx = FlatIndex(64, options=opts(**kv))
         idx.profile(True)
         idx.add(r)
         D, I = idx.search(q, k)

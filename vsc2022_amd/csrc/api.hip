@@ -124,7 +124,7 @@ struct OptionName { const char* name; const char* env; };
 static const OptionName kOptions[] = {
     {"prefilter", "VSC_PREFILTER"}, {"prefilter_density", "VSC_PREFILTER_DENSITY"}, {"f16_kernel", "VSC_F16_KERNEL"},
     {"i8", "VSC_I8"}, {"i8_density", "VSC_I8_DENSITY"}, {"i8_max_rel", "VSC_I8_MAX_REL"}, {"i8_exclude", "VSC_I8_EXCLUDE"},
-    {"i8_sort", "VSC_I8_SORT"}, {"i8_group", "VSC_I8_GROUP"}, {"i8p_order", "VSC_I8P_ORDER"}, {"i8p_slice", "VSC_I8P_SLICE"},
+    {"i8_sort", "VSC_I8_SORT"}, {"i8_center", "VSC_I8_CENTER"}, {"i8_group", "VSC_I8_GROUP"}, {"i8p_order", "VSC_I8P_ORDER"}, {"i8p_slice", "VSC_I8P_SLICE"},
     {"i8p_pair", "VSC_I8P_PAIR"}, {"i8_screen", "VSC_I8_SCREEN"}, {"i8_knn", "VSC_I8_KNN"}, {"knn_step", "VSC_KNN_STEP"},
     {"knn_step_max", "VSC_KNN_STEP_MAX"}, {"knn_step_work", "VSC_KNN_STEP_WORK"}, {"rescore_sort", "VSC_RESCORE_SORT"},
     {"knn_levels", "VSC_KNN_LEVELS"}, {"knn_subset", "VSC_KNN_SUBSET"}, {"knn_s0div", "VSC_KNN_S0DIV"},
@@ -171,6 +171,13 @@ static int apply_option(vsc_index* idx, const char* name, double v) {
         const bool e = v != 0.0;
         if (e != idx->i8_exclude) VSC_TRY(option_needs_empty(idx, name));
         idx->i8_exclude = e;
+        return VSC_OK;
+    }
+    if (is("i8_center")) {  // 0 never, 1 by the mean's share of the rows' energy (default), 2 always (tests)
+        const int m = (int)v;
+        if (m < 0 || m > 2) goto bad;
+        if (m != idx->i8_center) VSC_TRY(option_needs_empty(idx, name));
+        idx->i8_center = m;
         return VSC_OK;
     }
     if (is("prefilter_density")) { if (!(v > 0.0)) goto bad; idx->prefilter_density = v; return VSC_OK; }
@@ -243,6 +250,9 @@ static int read_option(const vsc_index* idx, const char* name, double* out) {
     else if (is("sort_hits")) *out = idx->sort_hits;
     else if (is("density_hint")) *out = idx->density_hint;
     else if (is("last_topk_route")) *out = idx->last_topk_route;  // (read-only: what the last vsc_index_global_topk did)
+    else if (is("i8_center")) *out = idx->i8_center;
+    else if (is("i8_center_on")) *out = idx->i8_mu_on;        // (read-only: is the int8 reference image centred?)
+    else if (is("i8_center_share")) *out = idx->i8_mu_ratio;  // (read-only: |mean|^2 / mean |row|^2 when it was decided)
     else if (is("i8_fallbacks")) *out = (double)idx->stat_i8_fallbacks;  // (read-only: searches that left int8 for fp16)
     else {
         set_error("vsc_index_get_option: unknown option '%s'", name);
@@ -337,6 +347,7 @@ int vsc_index_destroy(vsc_index_t* idx) {
     idx->refn.release();
     idx->ref8.release();
     idx->ref8m.release();
+    idx->i8_mu.release();
     for (auto& b : idx->cand) b.release();
     idx->ws.release();
     for (auto& e : idx->ev_pool) {
@@ -403,10 +414,63 @@ int vsc_index_sync(vsc_index_t* idx) {
 
 // (Re)write rows [row0, row0 + rows) of the int8 image and their meta from the packed fp32 rows, with the index's
 // current set of excluded coordinates; the first `count_rows - row0` of them enter the looseness statistic.
+// The centre as the kernels read it: packed order, zero on the coordinates the image leaves out.
+static int i8_upload_centre(vsc_index* idx) {
+    if (!idx->i8_mu_on) return VSC_OK;
+    std::vector<float> eff(idx->i8_mu_host);
+    for (int c = 0; c < idx->i8_ex.n; ++c) eff[(size_t)k_slot(idx->i8_ex.idx[c])] = 0.0f;
+    VSC_TRY(idx->i8_mu.reserve((size_t)idx->dpad * sizeof(float)));
+    VSC_HIP(hipMemcpyAsync(idx->i8_mu.p, eff.data(), (size_t)idx->dpad * sizeof(float), hipMemcpyHostToDevice, idx->stream));
+    VSC_HIP(hipStreamSynchronize(idx->stream));  // eff is a local
+    idx->i8_mu_ex = idx->i8_ex;
+    return VSC_OK;
+}
+
+// Decide ONCE, from the rows present at the first catch-up, whether the image is centred and on what: the mean of those
+// rows (any fixed vector would be exact; the mean is what shortens the rows most).  Centring is on when the mean carries
+// at least 2 % of the rows' energy on the kept coordinates (option i8_center = 1), always (2) or never (0).
+static int i8_decide_centre(vsc_index* idx, int64_t rows) {
+    idx->i8_mu_decided = true;
+    idx->i8_mu_on = false;
+    if (idx->i8_center == 0 || rows <= 0) return VSC_OK;
+    const int dpad = idx->dpad;
+    VSC_TRY(idx->ws.tmp.reserve((size_t)2 * dpad * sizeof(double)));
+    double* d_sum = idx->ws.tmp.as<double>();
+    VSC_TRY(launch_col_sums(idx->ref.as<float>(), rows, dpad, d_sum, d_sum + dpad, idx->stream));
+    std::vector<double> h((size_t)2 * dpad);
+    VSC_HIP(hipMemcpyAsync(h.data(), d_sum, h.size() * sizeof(double), hipMemcpyDeviceToHost, idx->stream));
+    VSC_HIP(hipStreamSynchronize(idx->stream));
+    idx->i8_mu_host.assign((size_t)dpad, 0.0f);
+    double mu2 = 0.0, e2 = 0.0;
+    bool finite = true;
+    for (int k = 0; k < idx->dim; ++k) {
+        if (idx->i8_ex.holds(k)) continue;
+        const int p = k_slot(k);
+        const double m = h[(size_t)p] / (double)rows;
+        finite = finite && std::isfinite(m) && std::isfinite(h[(size_t)dpad + p]);
+        idx->i8_mu_host[(size_t)p] = (float)m;
+        mu2 += m * m;
+        e2 += h[(size_t)dpad + p] / (double)rows;
+    }
+    idx->i8_mu_ratio = e2 > 0.0 ? mu2 / e2 : 0.0;
+    if (!finite) return VSC_OK;  // (rows holding inf / NaN: no centre; such rows pass every pair anyway)
+    idx->i8_mu_on = idx->i8_center == 2 || idx->i8_mu_ratio >= 0.02;
+    if (idx->debug_i8)
+        fprintf(stderr, "[vscmi] int8 reference image: mean carries %.4f of the rows' energy over %lld rows -> %s\n", idx->i8_mu_ratio,
+                (long long)rows, idx->i8_mu_on ? "centred" : "not centred");
+    return i8_upload_centre(idx);
+}
+
 static int i8_quantise(vsc_index* idx, int64_t row0, int64_t rows, int64_t count_rows) {
     if (rows <= 0) return VSC_OK;
+    if (idx->i8_mu_on) {
+        // the excluded set changed since the centre was uploaded: zero it on the coordinates that are left out now
+        bool same = idx->i8_mu_ex.n == idx->i8_ex.n;
+        for (int c = 0; same && c < idx->i8_ex.n; ++c) same = idx->i8_mu_ex.idx[c] == idx->i8_ex.idx[c];
+        if (!same) VSC_TRY(i8_upload_centre(idx));
+    }
     VSC_TRY(launch_quant_ref_frag(idx->ref.as<float>(), idx->dpad, idx->ref8.p, idx->ref8m.as<float4>(), row0, rows,
-                                  idx->dpad8, idx->i8_ex, idx->stream));
+                                  idx->dpad8, idx->i8_ex, idx->i8_mu_on ? idx->i8_mu.as<float>() : nullptr, idx->stream));
     const int64_t real = std::max<int64_t>(0, std::min(row0 + rows, count_rows) - row0);
     VSC_TRY(idx->ws.cnt.reserve(2 * sizeof(double)));
     VSC_TRY(launch_meta_looseness(idx->ref8m.as<float4>() + row0, real, idx->ws.cnt.as<double>(), idx->stream));
@@ -464,6 +528,7 @@ static int i8_after_add(vsc_index* idx, int64_t first_new, int64_t n, int64_t ne
         return VSC_OK;
     }
     idx->i8_ex = ex;
+    if (!idx->i8_mu_decided) VSC_TRY(i8_decide_centre(idx, first_new + n));
     if (idx->i8_dirty) return VSC_OK;  // everything is rewritten before the next search anyway
     return i8_quantise(idx, first_new, need_rows - first_new, first_new + n);
 }

@@ -33,6 +33,7 @@ struct Workspace {
     DevBuf cs[4], cstmp, csn;  // candidates of a launch compacted + sorted by reference row (keys, values, ping-pong)
     DevBuf tailfill;        // fill levels of the chunks of the candidate list's shared tail (cand_list.h)
     DevBuf rt8c;            // the rows' largest |x| (second sort key of launches with per-row thresholds)
+    DevBuf rt8d;            // centred reference image: x . mu and sum |x mu| of the launch's rows
     DevBuf rt8, rt8b;       // ... and its row thresholds in position order (rows sorted by threshold inside a launch);
                             // rt8b: thresholds lowered by the excluded coordinates' contribution, in row order
     DevBuf sample, sk[3], tk[3];  // proven top-K route (api_search.hip): the row sample, its sorted hits, the K + 1 best of the steady run
@@ -41,7 +42,7 @@ struct Workspace {
         for (auto& b : sk) b.release();
         for (auto& b : tk) b.release();
         qh.release(); qn.release(); ci.release(); cj.release(); segcnt.release(); rowthr.release(); slices.release();
-        q8.release(); pstat.release(); rt8.release(); rt8b.release(); rt8c.release(); tailfill.release();
+        q8.release(); pstat.release(); rt8.release(); rt8b.release(); rt8c.release(); rt8d.release(); tailfill.release();
         for (auto& b : cs) b.release();
         cstmp.release(); csn.release();
         for (auto& b : hA) b.release();
@@ -97,6 +98,16 @@ struct vsc_index {
     // for all rows before the next search when it changed)
     std::vector<unsigned> cmin_key, cmax_key;
     ExcludedDims i8_ex;
+    // Centre of the int8 reference image (quant_i8.hip, "CENTRED references"): the mean of the rows present when the image
+    // was first written, in the rows' packed order; i8_mu is its device copy with zeros on the excluded coordinates
+    // (re-uploaded when that set changes).  i8_center: 0 never, 1 when the mean carries >= 2 % of the rows' energy
+    // (default), 2 always (tests).
+    int i8_center = 1;
+    bool i8_mu_decided = false, i8_mu_on = false;
+    double i8_mu_ratio = 0.0;
+    std::vector<float> i8_mu_host;
+    DevBuf i8_mu;
+    ExcludedDims i8_mu_ex;
     bool i8_dirty = false;
     int64_t i8_rows = 0;  // rows [0, i8_rows) of the image are current
     // rows [i8_seen, ntotal) have been added but not yet folded into the per-coordinate min / max nor quantised: `add`

@@ -94,12 +94,21 @@ int enqueue_f16(vsc_index* idx, const float* qpacked, int64_t i0, int64_t i1, in
             const int32_t* perm = nullptr;
             float* rt_pos = nullptr;
             const float* thr_src = row_thr ? row_thr + i0 : nullptr;
-            if (idx->i8_ex.n > 0) {
+            if (idx->i8_ex.n > 0 || idx->i8_mu_on) {
                 // coordinates the images leave out (all references agree on them) act through the rows' thresholds:
-                // t_row - sum_c q_c v_c, with t_row the row's k-NN threshold or the search radius
+                // t_row - sum_c q_c v_c, with t_row the row's k-NN threshold or the search radius; a centred reference
+                // image (quant_i8.hip) adds the rows' x . mu the same way
                 VSC_TRY(idx->ws.rt8b.reserve((size_t)nqb * sizeof(float)));
+                const float *cen = nullptr, *cmag = nullptr;
+                if (idx->i8_mu_on) {
+                    VSC_TRY(idx->ws.rt8d.reserve((size_t)2 * nqb * sizeof(float)));
+                    VSC_TRY(launch_row_center(qpacked + i0 * idx->dpad, idx->dpad, nqb, idx->i8_mu.as<float>(),
+                                              idx->ws.rt8d.as<float>(), idx->ws.rt8d.as<float>() + nqb, idx->stream));
+                    cen = idx->ws.rt8d.as<float>();
+                    cmag = cen + nqb;
+                }
                 VSC_TRY(launch_row_bias_thresholds(qpacked + i0 * idx->dpad, idx->dpad, nqb, thr_src, &ctl->radius,
-                                                   idx->i8_ex, idx->ws.rt8b.as<float>(), idx->stream));
+                                                   idx->i8_ex, cen, cmag, idx->ws.rt8b.as<float>(), idx->stream));
                 thr_src = idx->ws.rt8b.as<float>();
             }
             // VSC_I8_SORT=0: rows in their own order (A/B; the kernel then gates blocks of unrelated thresholds)

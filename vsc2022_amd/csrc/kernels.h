@@ -152,13 +152,16 @@ void sim_f16p_plan(int64_t nq, int64_t nr, int* npanel, int* nsteps, int* slice,
 int launch_sim_f16p(const SimF16PArgs&, int grid, hipStream_t);
 int launch_sim_i8p(const SimI8PArgs&, int grid, hipStream_t);
 bool sim_i8p_pairs(int dpad8, int npanel, int nsteps, int slice, bool force);  // does a launch of this size use work items of two panels?
-int launch_quant_ref_frag(const float*, int, void*, float4*, int64_t, int64_t, int, const ExcludedDims&, hipStream_t);
+int launch_quant_ref_frag(const float*, int, void*, float4*, int64_t, int64_t, int, const ExcludedDims&, const float*, hipStream_t);
+int launch_col_sums(const float*, int64_t, int, double*, double*, hipStream_t);
+int launch_row_center(const float*, int, int, const float*, float*, float*, hipStream_t);
 int launch_dim_minmax(const float*, int64_t, int, unsigned*, unsigned*, hipStream_t);
 int launch_meta_looseness(const float4*, int64_t, double*, hipStream_t);
 int launch_quant_query_panels(const float*, int, int, int, void*, int, float4*, const int32_t*, const float*, float*,
                               const ExcludedDims&, hipStream_t);
 int launch_row_absmax(const float*, int, int, const ExcludedDims&, float*, hipStream_t);
-int launch_row_bias_thresholds(const float*, int, int, const float*, const float*, const ExcludedDims&, float*, hipStream_t);
+int launch_row_bias_thresholds(const float*, int, int, const float*, const float*, const ExcludedDims&, const float*, const float*, float*,
+                               hipStream_t);
 int sort_rows_by_threshold(const float*, int64_t, DevBuf&, DevBuf&, DevBuf&, DevBuf&, DevBuf&, const int32_t**, hipStream_t);
 int argsort_scores_desc(const float*, int64_t, DevBuf&, DevBuf&, DevBuf&, DevBuf&, DevBuf&, const int32_t**, hipStream_t);
 int launch_ctl_init(SelectCtl*, float, hipStream_t);

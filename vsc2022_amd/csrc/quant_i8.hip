@@ -25,6 +25,16 @@
 // per-row-threshold variant applies.  N stays the norm of the WHOLE row (the rounding of the exact fp32 chain scales
 // with it), N' is the norm of what the image represents:
 //     | x . y - b - s_x s_y (q_x . q_y) | <= E_x N'_y + (N'_x + E_x) E_y       (x, y restricted to the kept coordinates)
+//
+// CENTRED references (round 6).  Descriptors with a common direction (every pair at cosine 0.2 ... 0.5: uncentred
+// embeddings) spend their 8 bits on that direction: the scale follows mu, the bound grows, and at cosine 0.5 the
+// score-normalised search left int8 for fp16 (profiles/r06_distributions.md).  For ANY fixed vector mu
+//     x . y = x . (y - mu) + x . mu ,
+// so the reference image may hold y - mu (mu = the mean of the rows present when the image is first written; kept
+// from then on) and the second term, a per-query-row constant like b above, moves the row's threshold
+// (row_center + row_bias_thresholds).  The image then represents y' = fl(y - mu): E is the residual of y', N' = ||y'||,
+// and the rounding of the subtraction itself, |y - mu - y'| <= 2^-24 |y - mu| per coordinate, is added to E.  The
+// queries are not touched.  Excluded coordinates stay excluded (mu is 0 there).
 #include <algorithm>
 
 #include "kernels.h"
@@ -50,7 +60,8 @@ __device__ __forceinline__ int quant1(float x, float inv_s, float s, float& ss_e
 // and coordinates past dim are zero).  Rows [row0, row0 + rows) of the index are (re)written.
 __global__ __launch_bounds__(256) void quant_ref_frag_kernel(const float* __restrict__ packed, int dpad,
                                                              i32x4* __restrict__ image, float4* __restrict__ meta,
-                                                             int64_t row0, int64_t rows, int dpad8, ExcludedDims ex) {
+                                                             int64_t row0, int64_t rows, int dpad8, ExcludedDims ex,
+                                                             const float* __restrict__ mu) {
     const int lane = threadIdx.x & 63;
     const int64_t rel = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (rel >= rows) return;
@@ -69,11 +80,22 @@ __global__ __launch_bounds__(256) void quant_ref_frag_kernel(const float* __rest
 #pragma unroll
         for (int e = 0; e < 16; ++e) v[e] = 0.0f;
     }
+    float m16[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) m16[e] = 0.0f;
+    if (mu && lane * 16 < dpad) {   // the centre, in the rows' packed order (zero on excluded coordinates)
+        const float4* ms = reinterpret_cast<const float4*>(mu + lane * 16);
+        const float4 e0 = ms[0], o0 = ms[1], e1 = ms[2], o1 = ms[3];
+        const float t[16] = {e0.x, o0.x, e0.y, o0.y, e0.z, o0.z, e0.w, o0.w, e1.x, o1.x, e1.y, o1.y, e1.z, o1.z, e1.w, o1.w};
+#pragma unroll
+        for (int e = 0; e < 16; ++e) m16[e] = t[e];
+    }
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
         const float x = v[e];
         bad |= !(fabsf(x) <= 3.0e38f);
-        ss_n = __fmaf_rn(x, x, ss_n);
+        ss_n = __fmaf_rn(x, x, ss_n);        // N: the norm of the row as the exact chain sees it
+        v[e] = x - m16[e];                   // what the image represents (mu = 0: the row itself, exactly)
         if (ex.holds(lane * 16 + e)) v[e] = 0.0f;  // excluded coordinate: not in the image
         amax = fmaxf(amax, fabsf(v[e]));
         ss_k = __fmaf_rn(v[e], v[e], ss_k);
@@ -105,19 +127,20 @@ __global__ __launch_bounds__(256) void quant_ref_frag_kernel(const float* __rest
     if (lane == 0) {
         float4 m;
         m.x = inv_s;
-        m.y = bad ? INFINITY : norm_up(ss_e, dpad);
-        m.z = bad ? INFINITY : norm_up(ss_n, dpad);
         m.w = bad ? INFINITY : norm_up(ss_k, dpad);
+        // (centred image: + the rounding of y - mu itself, <= 2^-24 per coordinate relative to |y - mu|)
+        m.y = bad ? INFINITY : norm_up(ss_e, dpad) + (mu ? 6.0e-8f * m.w : 0.0f);
+        m.z = bad ? INFINITY : norm_up(ss_n, dpad);
         meta[row] = m;
     }
 }
 
 // image / meta: bases of the whole fragment-major image and of the whole meta table
 int launch_quant_ref_frag(const float* packed, int dpad, void* image, float4* meta, int64_t row0, int64_t rows, int dpad8,
-                          const ExcludedDims& ex, hipStream_t stream) {
+                          const ExcludedDims& ex, const float* mu, hipStream_t stream) {
     if (rows <= 0) return VSC_OK;
     hipLaunchKernelGGL(quant_ref_frag_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, stream, packed, dpad,
-                       reinterpret_cast<i32x4*>(image), meta, row0, rows, dpad8, ex);
+                       reinterpret_cast<i32x4*>(image), meta, row0, rows, dpad8, ex, mu);
     VSC_HIP(hipGetLastError());
     return VSC_OK;
 }
@@ -147,6 +170,62 @@ int launch_dim_minmax(const float* packed, int64_t rows, int dpad, unsigned* mn,
     const unsigned chunks = (unsigned)std::max<int64_t>(1, std::min<int64_t>(1024, rows / 256));
     hipLaunchKernelGGL(dim_minmax_kernel, dim3((unsigned)((dpad + 255) / 256), chunks), dim3(256), 0, stream, packed, rows,
                        dpad, mn, mx);
+    VSC_HIP(hipGetLastError());
+    return VSC_OK;
+}
+
+// Per-coordinate sum and sum of squares over packed rows (double), packed-position order: the centre of the int8 image
+// and the share of the rows' energy that lies along it.
+__global__ __launch_bounds__(256) void col_sums_kernel(const float* __restrict__ packed, int64_t rows, int dpad,
+                                                       double* __restrict__ sum, double* __restrict__ sumsq) {
+    const int64_t per = (rows + gridDim.y - 1) / gridDim.y;
+    const int64_t r0 = (int64_t)blockIdx.y * per, r1 = min(rows, r0 + per);
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= dpad || r0 >= r1) return;
+    double a = 0.0, b = 0.0;
+    for (int64_t r = r0; r < r1; ++r) {
+        const double x = (double)packed[r * dpad + p];
+        a += x;
+        b += x * x;
+    }
+    atomicAdd(&sum[p], a);
+    atomicAdd(&sumsq[p], b);
+}
+
+int launch_col_sums(const float* packed, int64_t rows, int dpad, double* sum, double* sumsq, hipStream_t stream) {
+    VSC_HIP(hipMemsetAsync(sum, 0, (size_t)dpad * sizeof(double), stream));
+    VSC_HIP(hipMemsetAsync(sumsq, 0, (size_t)dpad * sizeof(double), stream));
+    if (rows <= 0) return VSC_OK;
+    const unsigned chunks = (unsigned)std::max<int64_t>(1, std::min<int64_t>(1024, rows / 256));
+    hipLaunchKernelGGL(col_sums_kernel, dim3((unsigned)((dpad + 255) / 256), chunks), dim3(256), 0, stream, packed, rows, dpad, sum,
+                       sumsq);
+    VSC_HIP(hipGetLastError());
+    return VSC_OK;
+}
+
+// c[r] = x_r . mu and cmag[r] = sum_k |x_rk mu_k| over the packed coordinates (mu is 0 on excluded ones): the share of a
+// query row's scores that the centred reference image does not carry.  One wave per row.
+__global__ __launch_bounds__(256) void row_center_kernel(const float* __restrict__ qpacked, int dpad, int nq,
+                                                         const float* __restrict__ mu, float* __restrict__ c,
+                                                         float* __restrict__ cmag) {
+    const int lane = threadIdx.x & 63;
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= nq) return;
+    const float* q = qpacked + (int64_t)r * dpad;
+    float a = 0.0f, m = 0.0f;
+    for (int p = lane; p < dpad; p += 64) {
+        const float x = q[p], u = mu[p];
+        a = __fmaf_rn(x, u, a);
+        m = __fmaf_rn(fabsf(x), fabsf(u), m);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { a += __shfl_xor(a, off); m += __shfl_xor(m, off); }
+    if (lane == 0) { c[r] = a; cmag[r] = m; }
+}
+
+int launch_row_center(const float* qpacked, int dpad, int nq, const float* mu, float* c, float* cmag, hipStream_t stream) {
+    if (nq <= 0) return VSC_OK;
+    hipLaunchKernelGGL(row_center_kernel, dim3((unsigned)((nq + 3) / 4)), dim3(256), 0, stream, qpacked, dpad, nq, mu, c, cmag);
     VSC_HIP(hipGetLastError());
     return VSC_OK;
 }
@@ -301,9 +380,13 @@ int launch_row_absmax(const float* qpacked, int dpad, int nq, const ExcludedDims
 // threshold `base_thr[row]`, or the search radius *radius) has
 //     (score restricted to the kept coordinates)  >  t - b_q,      b_q = sum_c q_c v_c.
 // b is evaluated in fp32 (an fma chain over <= 8 terms): its own rounding, <= n 2^-23 sum |q_c v_c|, is subtracted too.
+// Centred reference image: c[r] = x_r . mu (row_center_kernel) is subtracted as well; its rounding (a tree of fp32
+// fmas over <= dpad terms: far below (dpad + 2) 2^-23 cmag[r]) goes into the slack.
 __global__ __launch_bounds__(256) void row_bias_thresholds_kernel(const float* __restrict__ qpacked, int dpad, int nq,
                                                                   const float* __restrict__ base_thr,
                                                                   const float* __restrict__ radius, ExcludedDims ex,
+                                                                  const float* __restrict__ cen,
+                                                                  const float* __restrict__ cmag,
                                                                   float* __restrict__ thr) {
     const int r = blockIdx.x * 256 + threadIdx.x;
     if (r >= nq) return;
@@ -317,17 +400,18 @@ __global__ __launch_bounds__(256) void row_bias_thresholds_kernel(const float* _
             mag = __fmaf_rn(fabsf(x), fabsf(ex.val[c]), mag);
         }
     const float t = base_thr ? base_thr[r] : *radius;
-    const float lowered = t - b;
-    // (the subtraction's own rounding: 2^-24 relative to the larger operand; a NaN / inf bias leaves a NaN / -inf
+    const float c = cen ? cen[r] : 0.0f;
+    const float lowered = (t - b) - c;
+    // (the subtractions' own rounding: 2^-24 relative to the larger operand; a NaN / inf bias leaves a NaN / -inf
     // threshold, and the kernel passes every pair of such a row)
-    thr[r] = lowered - 1.2e-7f * ((float)ex.n * mag + fabsf(t) + fabsf(b));
+    thr[r] = lowered - 1.2e-7f * ((float)ex.n * mag + (cen ? (float)(dpad + 2) * cmag[r] : 0.0f) + fabsf(t) + fabsf(b) + 2.0f * fabsf(c));
 }
 
 int launch_row_bias_thresholds(const float* qpacked, int dpad, int nq, const float* base_thr, const float* radius,
-                               const ExcludedDims& ex, float* thr, hipStream_t stream) {
+                               const ExcludedDims& ex, const float* cen, const float* cmag, float* thr, hipStream_t stream) {
     if (nq <= 0) return VSC_OK;
     hipLaunchKernelGGL(row_bias_thresholds_kernel, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, stream, qpacked, dpad,
-                       nq, base_thr, radius, ex, thr);
+                       nq, base_thr, radius, ex, cen, cmag, thr);
     VSC_HIP(hipGetLastError());
     return VSC_OK;
 }
