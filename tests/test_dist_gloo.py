@@ -776,3 +776,42 @@ def test_send_to_owners_and_varlen_gather_world3(tmp_path):
     allv = np.concatenate([p["rows"][:, 1] for p in parts])
     for r in range(world):
         assert np.array_equal(np.load(tmp_path / f"g{r}.npy"), allv)
+
+
+def _phase_worker(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        sys.path[:0] = [ROOT]
+        import json
+
+        from vsc2022_amd import dist as vdist
+
+        t = vdist.PhaseTimer(None)
+        for _ in range(2 + rank):
+            with t.phase("search"):
+                pass
+        if rank == 1:                       # a phase only ONE rank ever entered (row lists, a head without its rows)
+            with t.phase("prepare_row_lists"):
+                pass
+            t.add_bytes("prepare_row_lists", 77)
+        t.add_bytes("search", 10 * (rank + 1))
+        rep = vdist.reduce_phase_report(t.collect(), torch.device("cpu"))
+        with open(os.path.join(out_dir, f"phases{rank}.json"), "w") as f:
+            json.dump(rep, f)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_phase_report_is_reduced_over_ranks_that_saw_different_phases(tmp_path):
+    """`dist.reduce_phase_report` (bench.py's `sharded_search.phases_max_over_ranks`): max over ranks of every figure; a rank
+    that never entered a phase must still take part in the collective with a tensor of the same shape."""
+    import json
+
+    mp.spawn(_phase_worker, args=(3, 29700 + os.getpid() % 200, str(tmp_path)), nprocs=3, join=True)
+    reps = [json.load(open(tmp_path / f"phases{r}.json")) for r in range(3)]
+    assert reps[0] == reps[1] == reps[2]
+    assert set(reps[0]) == {"search", "prepare_row_lists"}
+    assert reps[0]["search"]["calls"] == 4 and reps[0]["search"]["bytes"] == 30
+    assert reps[0]["prepare_row_lists"]["calls"] == 1 and reps[0]["prepare_row_lists"]["bytes"] == 77

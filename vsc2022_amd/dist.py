@@ -111,18 +111,26 @@ class PhaseTimer:
         return out
 
 
+# the phases engine.DeviceMatcher.sharded_schedule_search / emulate_schedule account (reduce_phase_report needs the same list on every rank)
+PHASE_NAMES = ("gather_queries", "prepare_row_lists", "search", "count", "events", "handover", "final_sort_and_cut")
+
+
 def reduce_phase_report(report: dict, device, group=None) -> dict:
     """max over ranks of every figure of a PhaseTimer report (the slowest rank sets the step time), identical on all ranks"""
     rank, world = _world(group)
-    if world == 1 or not report:
+    if world == 1:
         return report
-    names = sorted(report)
+    # (a fixed list of phases: a rank that never entered one -- no row list to prepare, no rows in the head -- must still
+    # bring a tensor of the same shape to the collective)
+    names = list(PHASE_NAMES) + sorted(n for n in report if n not in PHASE_NAMES and n.startswith("x_"))
     fields = ("wall_ms", "device_ms", "calls", "bytes")
-    t = torch.tensor([[float(report[n][f]) for f in fields] for n in names], dtype=torch.float64, device=device)
+    zero = dict.fromkeys(fields, 0)
+    t = torch.tensor([[float(report.get(n, zero)[f]) for f in fields] for n in names], dtype=torch.float64, device=device)
     h = t.cpu() if _via_host(t, group) else t
     dist.all_reduce(h, op=dist.ReduceOp.MAX, group=group)
     vals = h.cpu().tolist()
-    return {n: {f: (int(v) if f in ("calls", "bytes") else round(v, 3)) for f, v in zip(fields, row)} for n, row in zip(names, vals)}
+    out = {n: {f: (int(v) if f in ("calls", "bytes") else round(v, 3)) for f, v in zip(fields, row)} for n, row in zip(names, vals)}
+    return {n: v for n, v in out.items() if v["calls"] > 0}
 
 
 def score_keys(scores: torch.Tensor) -> torch.Tensor:
