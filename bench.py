@@ -616,6 +616,8 @@ def distribution_leg(args, torch, dev, dim, dist, score_norm=False, exhaustive=T
         "int8_prefilter_tops": _rate(p["i8_flops"], p["i8_ms"], 1e12),
         "i8_fallbacks": int(m.index.get_option("i8_fallbacks")),
         "i8_enabled": int(m.index.get_option("i8")),
+        # (is the int8 reference image centred on the rows' mean, and the share of the rows' energy that mean carries)
+        "i8_center_on": int(m.index.get_option("i8_center_on")), "i8_center_share": m.index.get_option("i8_center_share"),
     })
     if exhaustive:
         exact = FlatIndex(int(refs.shape[1]), _lib.METRIC_INNER_PRODUCT, dev.index, options={"prefilter": 0})
@@ -942,6 +944,9 @@ def main():
                         out["extra"] = {"config2_shape": config2_shape_leg(args, torch, dev, dim)}
                         # non-Gaussian descriptors: the same shape on a cluster mixture
                         out["extra"]["clustered"] = distribution_leg(args, torch, dev, dim, "clusters")
+                        # ... and on rows with a common direction + dominant coordinates, score-normalised (the class the int8
+                        # bound is most sensitive to; its reference image is centred on the rows' mean)
+                        out["extra"]["shifted"] = distribution_leg(args, torch, dev, dim, "offset", score_norm=True)
                     else:
                         out["extra"] = extra_legs(args, torch, dev, matcher, queries, n_qv, qf, n_rv, rf, dim)
                         ms_fresh = out["ms_per_step"] + out["extra"]["set_queries_ms"]
