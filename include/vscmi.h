@@ -244,6 +244,13 @@ int vsc_sort_hits(const int32_t* hit_i, const int32_t* hit_j, const float* hit_s
 int vsc_score_histogram(const float* scores, int64_t n, const int64_t* state, int shift, int64_t* hist, int device);
 int vsc_score_pick(const int64_t* hist, int64_t* state, int shift, int device);
 
+/* The other half of a re-threshold event (apply_maxres inside faiss.contrib.exhaustive_search, reached at vsc/index.py:147-154:
+ * "re-filter every kept batch with a strict s > radius") for a kept list the caller holds in HBM: out_* <- the (row, ref,
+ * score) triples with score > radius (STRICT), in no particular order; *n_out (host) their number.  Device arrays of n entries;
+ * out_* of capacity n, not aliasing the inputs. */
+int vsc_filter_hits(const int32_t* hit_i, const int32_t* hit_j, const float* hit_s, int64_t n, float radius, int32_t* out_i,
+                    int32_t* out_j, float* out_s, int64_t* n_out, int device);
+
 /* perm[n] (int32) <- the stable argsort of a score list, best first: equal scores (-0.0 == +0.0) keep their input order.
  * Merges the ranks' candidate lists (vsc/candidates.py:38-40 sorts with Python's stable sort; the concatenation of the
  * ranks' lists in rank order IS first-appearance order, vsc2022_amd/dist.py:merge_candidates).  Host or device arrays. */
@@ -257,7 +264,7 @@ int vsc_merge_topk(const float* scores, const int64_t* ids, int64_t nq, int m, i
                    int device);
 
 /* The stream of the entry points that own no handle on `device` (vsc_pair_max, vsc_sort_hits, vsc_score_histogram, vsc_score_pick,
- * vsc_argsort_scores, vsc_merge_topk, vsc_row_normalize, vsc_tn_forward_sim):
+ * vsc_filter_hits, vsc_argsort_scores, vsc_merge_topk, vsc_row_normalize, vsc_tn_forward_sim):
  * as vsc_index_set_stream. */
 int vsc_set_aux_stream(int device, void* hip_stream, int own);
 

@@ -85,6 +85,27 @@ def test_merge_topk_equals_the_lexicographic_merge(gpu):
         _lib.check(_lib.lib().vsc_merge_topk(ts.data_ptr(), ti.data_ptr(), 1, 4, 5, out_s.data_ptr(), out_i.data_ptr(), 0))
 
 
+def test_filter_hits_keeps_exactly_the_hits_beyond_the_radius(gpu):
+    from vsc2022_amd.dist import filter_hits
+
+    rng = np.random.default_rng(4)
+    for trial in range(16):
+        n = int(rng.choice([0, 1, 255, 2048, 2049, 100003, 3_000_000]))
+        x = _scores(rng, n, trial % 4)
+        i = rng.integers(0, 1 << 20, n).astype(np.int32)
+        j = rng.integers(0, 1 << 21, n).astype(np.int32)
+        radius = float(np.median(x)) if n else 0.0
+        gi, gj, gs = filter_hits(torch.from_numpy(i).cuda(), torch.from_numpy(j).cuda(), torch.from_numpy(x).cuda(), radius)
+        keep = x > np.float32(radius)
+        want = sorted(zip(i[keep].tolist(), j[keep].tolist(), x[keep].view(np.uint32).tolist()))
+        got = sorted(zip(gi.cpu().tolist(), gj.cpu().tolist(), gs.cpu().numpy().view(np.uint32).tolist()))
+        assert got == want, (trial, n, len(got), len(want))
+    # +-inf radii: everything / nothing
+    t = torch.arange(5, dtype=torch.float32, device="cuda")
+    z = torch.zeros(5, dtype=torch.int32, device="cuda")
+    assert filter_hits(z, z, t, float("-inf"))[2].numel() == 5 and filter_hits(z, z, t, float("inf"))[2].numel() == 0
+
+
 def test_score_histogram_rejects_bad_arguments(gpu):
     from vsc2022_amd import _lib
 

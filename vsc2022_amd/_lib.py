@@ -38,7 +38,7 @@ EXPORTS = (
     "vsc_index_metric", "vsc_index_set_hit_capacity", "vsc_index_sync", "vsc_index_knn",
     "vsc_index_set_option", "vsc_index_get_option", "vsc_index_set_stream", "vsc_tn_set_stream", "vsc_set_aux_stream",
     "vsc_index_range_search", "vsc_index_global_topk", "vsc_index_global_topk_seeded", "vsc_index_candidates", "vsc_pair_max", "vsc_sort_hits", "vsc_row_normalize",
-    "vsc_score_histogram", "vsc_score_pick", "vsc_argsort_scores", "vsc_merge_topk",
+    "vsc_score_histogram", "vsc_score_pick", "vsc_filter_hits", "vsc_argsort_scores", "vsc_merge_topk",
     "vsc_tn_create", "vsc_tn_set_queries", "vsc_tn_destroy", "vsc_tn_localize", "vsc_tn_forward_sim", "vsc_tn_similarity",
     "vsc_index_profile", "vsc_index_profile_read", "vsc_index_profile_read_class", "vsc_index_search_stats",
     "vsc_aux_profile", "vsc_aux_profile_read", "vsc_bias_act_bf16", "vsc_gemm_bias_act_bf16", "vsc_pool3x3s2_bias_relu_bf16", "vsc_conv_bias_act_bf16",
@@ -167,6 +167,7 @@ def lib():
         L.vsc_row_normalize.argtypes = [vp, i64, i32, i32, vp, i32, i32]
         L.vsc_score_histogram.argtypes = [vp, i64, vp, i32, vp, i32]
         L.vsc_score_pick.argtypes = [vp, vp, i32, i32]
+        L.vsc_filter_hits.argtypes = [vp, vp, vp, i64, f32, vp, vp, vp, pi64, i32]
         L.vsc_argsort_scores.argtypes = [vp, i64, i32, vp, i32, i32]
         L.vsc_merge_topk.argtypes = [vp, vp, i64, i32, i32, vp, vp, i32]
         L.vsc_tn_create.argtypes = [vp, vp, i64, vp, vp, i64, i32, i32, i32, ctypes.POINTER(vp)]

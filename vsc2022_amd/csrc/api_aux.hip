@@ -199,6 +199,32 @@ int vsc_score_pick(const int64_t* hist, int64_t* state, int shift, int device) {
     return VSC_OK;
 }
 
+int vsc_filter_hits(const int32_t* hit_i, const int32_t* hit_j, const float* hit_s, int64_t n, float radius, int32_t* out_i,
+                    int32_t* out_j, float* out_s, int64_t* n_out, int device) {
+    if (n < 0 || !n_out || (n > 0 && (!hit_i || !hit_j || !hit_s || !out_i || !out_j || !out_s)) || !(radius == radius)) {
+        set_error("vsc_filter_hits: invalid argument");
+        return VSC_ERR_INVALID;
+    }
+    *n_out = 0;
+    if (n == 0) return VSC_OK;
+    VSC_TRY(check_device(device));
+    VSC_HIP(hipSetDevice(device));
+    DeviceCtx* c = device_ctx(device);
+    if (!c) {
+        set_error("vsc_filter_hits: cannot create device context");
+        return VSC_ERR_HIP;
+    }
+    std::lock_guard<std::mutex> lk(c->mu);
+    VSC_TRY(c->ws.cnt.reserve(sizeof(unsigned long long)));
+    VSC_TRY(launch_filter_hits(hit_i, hit_j, hit_s, (long long)n, radius, out_i, out_j, out_s, c->ws.cnt.as<unsigned long long>(),
+                               c->stream));
+    unsigned long long kept = 0;
+    VSC_HIP(hipMemcpyAsync(&kept, c->ws.cnt.p, sizeof(kept), hipMemcpyDeviceToHost, c->stream));
+    VSC_HIP(hipStreamSynchronize(c->stream));
+    *n_out = (int64_t)kept;
+    return VSC_OK;
+}
+
 int vsc_argsort_scores(const float* scores, int64_t n, int mem, int32_t* perm, int perm_mem, int device) {
     if (n < 0 || (n > 0 && (!scores || !perm))) {
         set_error("vsc_argsort_scores: invalid argument");

@@ -165,6 +165,8 @@ int launch_row_bias_thresholds(const float*, int, int, const float*, const float
 int sort_rows_by_threshold(const float*, int64_t, DevBuf&, DevBuf&, DevBuf&, DevBuf&, DevBuf&, const int32_t**, hipStream_t);
 int argsort_scores_desc(const float*, int64_t, DevBuf&, DevBuf&, DevBuf&, DevBuf&, DevBuf&, const int32_t**, hipStream_t);
 int launch_ctl_init(SelectCtl*, float, hipStream_t);
+int launch_filter_hits(const int32_t*, const int32_t*, const float*, long long, float, int32_t*, int32_t*, float*, unsigned long long*,
+                       hipStream_t);
 int launch_score_hist(const float*, long long, const long long*, int, long long*, hipStream_t);
 int launch_score_pick(const long long*, long long*, int, hipStream_t);
 int launch_merge_topk(const float*, const long long*, long long, int, int, float*, long long*, hipStream_t);

@@ -276,6 +276,69 @@ __global__ void score_pick_kernel(const long long* __restrict__ hist, long long*
     state[3] = above;
 }
 
+// Stand-alone form of the compaction above for hit lists a caller keeps itself (vsc_filter_hits; the sharded schedule's events,
+// vsc2022_amd/dist.py: "everything at or below the new radius goes"): (i, j, s) with s > radius (STRICT) from A to B, any order.
+__global__ __launch_bounds__(256) void filter_hits_kernel(const int32_t* __restrict__ ai, const int32_t* __restrict__ aj,
+                                                          const float* __restrict__ as, long long n, float radius,
+                                                          int32_t* __restrict__ bi, int32_t* __restrict__ bj, float* __restrict__ bs,
+                                                          unsigned long long* __restrict__ n_out) {
+    constexpr int PER_THREAD = 8, CHUNK = 256 * PER_THREAD;
+    __shared__ unsigned int wave_cnt[4];
+    __shared__ unsigned long long chunk_base;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long long n_chunks = (n + CHUNK - 1) / CHUNK;
+    for (long long ch = blockIdx.x; ch < n_chunks; ch += gridDim.x) {
+        const long long x0 = ch * CHUNK + threadIdx.x;
+        float s[PER_THREAD];
+        unsigned int keep_bits = 0;
+#pragma unroll
+        for (int e = 0; e < PER_THREAD; ++e) {
+            const long long x = x0 + (long long)e * 256;
+            s[e] = x < n ? as[x] : 0.0f;
+            keep_bits |= (unsigned int)((x < n) && (s[e] > radius)) << e;
+        }
+        unsigned long long bal[PER_THREAD];
+        unsigned int wave_total = 0;
+#pragma unroll
+        for (int e = 0; e < PER_THREAD; ++e) {
+            bal[e] = __ballot((keep_bits >> e) & 1u);
+            wave_total += (unsigned int)__popcll(bal[e]);
+        }
+        if (lane == 0) wave_cnt[wave] = wave_total;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const unsigned int tot = wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
+            chunk_base = tot ? atomicAdd(n_out, (unsigned long long)tot) : 0ull;
+        }
+        __syncthreads();
+        unsigned long long pos = chunk_base;
+        for (int w = 0; w < wave; ++w) pos += wave_cnt[w];
+        const unsigned long long below = (1ull << lane) - 1ull;
+#pragma unroll
+        for (int e = 0; e < PER_THREAD; ++e) {
+            if ((keep_bits >> e) & 1u) {
+                const long long x = x0 + (long long)e * 256;
+                const unsigned long long p = pos + (unsigned int)__popcll(bal[e] & below);
+                bi[p] = ai[x];
+                bj[p] = aj[x];
+                bs[p] = s[e];
+            }
+            pos += (unsigned int)__popcll(bal[e]);
+        }
+        __syncthreads();
+    }
+}
+
+int launch_filter_hits(const int32_t* ai, const int32_t* aj, const float* as, long long n, float radius, int32_t* bi, int32_t* bj,
+                       float* bs, unsigned long long* n_out, hipStream_t stream) {
+    VSC_HIP(hipMemsetAsync(n_out, 0, sizeof(unsigned long long), stream));
+    if (n <= 0) return VSC_OK;
+    const int grid = (int)std::min<long long>(1024, (n + 2047) / 2048);
+    hipLaunchKernelGGL(filter_hits_kernel, dim3(grid), dim3(256), 0, stream, ai, aj, as, n, radius, bi, bj, bs, n_out);
+    VSC_HIP(hipGetLastError());
+    return VSC_OK;
+}
+
 int launch_score_hist(const float* s, long long n, const long long* state, int shift, long long* hist, hipStream_t stream) {
     VSC_HIP(hipMemsetAsync(hist, 0, 256 * sizeof(long long), stream));
     if (n > 0) {

@@ -656,9 +656,9 @@ def emulate_schedule(search_rows: Callable[[int, int, float], Tuple[torch.Tensor
                 tau, _ = kth_best_unsorted(alls, k_global + 1, group)
                 radius = float(tau)
                 if kept_s:
-                    m = alls > radius
-                    kept_i, kept_j, kept_s = [torch.cat(kept_i)[m]], [torch.cat(kept_j)[m]], [alls[m]]
-                    n_kept = int(kept_s[0].numel())
+                    ki, kj, ks = filter_hits(torch.cat(kept_i), torch.cat(kept_j), alls, radius)
+                    kept_i, kept_j, kept_s = [ki], [kj], [ks]
+                    n_kept = int(ks.numel())
             # (what an event leaves: the hits STRICTLY above the (K+1)-th best -- at most K; an upper bound is all the skip
             # rule above needs)
             known_total, since = k_global, 0
@@ -691,6 +691,30 @@ def merge_candidates(q_vid: torch.Tensor, r_vid: torch.Tensor, score: torch.Tens
     allp = allp[order]
     return ShardedCandidates(allp[:, 0].to(torch.int32), allp[:, 1].to(torch.int32),
                              allp[:, 2].to(torch.int32).view(torch.float32), allp[:, 3], allp[:, 4])
+
+
+def filter_hits(i: torch.Tensor, j: torch.Tensor, s: torch.Tensor, radius: float):
+    """The hits with score > radius (STRICT) -- what a re-threshold event keeps (apply_maxres, reached at vsc/index.py:147-154).
+    HBM lists: ONE pass of libvscmi's compaction kernel over the three arrays (`vsc_filter_hits`; the order of the survivors
+    is not kept -- the list is a set until the final sort); CPU tensors (gloo tests): a boolean mask."""
+    if not s.is_cuda or i.dtype != torch.int32 or j.dtype != torch.int32:
+        m = s > radius
+        return i[m], j[m], s[m]
+    import ctypes
+
+    from vsc2022_amd import _lib
+    from vsc2022_amd.engine import bind_aux_stream
+
+    n = int(s.numel())
+    i, j, s = i.contiguous(), j.contiguous(), s.contiguous()
+    oi, oj, os_ = torch.empty_like(i), torch.empty_like(j), torch.empty_like(s)
+    kept = ctypes.c_int64(0)
+    if n:
+        bind_aux_stream(s.device)
+        _lib.check(_lib.lib().vsc_filter_hits(i.data_ptr(), j.data_ptr(), s.data_ptr(), n, float(radius), oi.data_ptr(), oj.data_ptr(),
+                                              os_.data_ptr(), ctypes.byref(kept), s.device.index))
+    m = kept.value
+    return oi[:m], oj[:m], os_[:m]
 
 
 def argsort_scores_desc(s: torch.Tensor) -> torch.Tensor:
