@@ -324,6 +324,37 @@ def test_centred_int8_image_is_invisible_in_the_results(gpu, orc, nq, nr, d, K, 
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("spread", [0.0, 1e-6, 1e-4, 1e-2])
+def test_centred_image_of_nearly_identical_references(gpu, orc, spread):
+    """The hard case for the decomposition x.y = x.(y - mu) + x.mu: references that (nearly) equal their mean.  y - mu is
+    then all rounding (spread 0: exactly zero -- an empty image, E = N' = 0), every score is x.mu up to a few ulps and the
+    search's radius sits inside that cloud: what decides a pair is the slack for the roundings of x.mu (a tree of fmas
+    here, the ascending chain in the exact stage) and of y - mu.  Top-K, 3-NN and a range search against the oracle."""
+    from vsc2022_amd.vsc.index import FlatIndex
+
+    rng = np.random.default_rng(17)
+    d, nq, nr = 200, 500, 3000
+    centre = unit(rng, 1, d)
+    r = np.repeat(centre, nr, axis=0) + np.float32(spread) * rng.standard_normal((nr, d)).astype(np.float32)
+    r = np.ascontiguousarray(r.astype(np.float32))
+    q = shifted(rng, nq, d, 0.3)
+    idx = FlatIndex(d, options=opts(VSC_PREFILTER="2", VSC_I8="2", VSC_I8_CENTER="2"))
+    idx.profile(True)
+    idx.add(r)
+    for K in (100, 5000, 400000):
+        assert_same(idx.global_topk(q, K)[:3], orc.global_threshold_search(q, r, K))
+    D, I = idx.search(q, 3)
+    Do, Io = orc.knn(q, r, 3)
+    assert np.array_equal(I, Io) and np.array_equal(bits(D), bits(Do))
+    S = orc.scores(q[:64], r)
+    radius = float(np.median(S))
+    lims, Dr, Ir = idx.range_search(q[:64], radius)
+    ol, oD, oI = orc.range_search(q[:64], r, radius)
+    assert np.array_equal(lims, ol) and np.array_equal(Ir, oI) and np.array_equal(bits(Dr), bits(oD))
+    assert idx.get_option("i8_center_on") == 1.0 and i8_launches(idx) > 0
+
+
+@pytest.mark.gpu
 def test_centring_and_excluded_coordinates_together(gpu, orc):
     """Score-normalised rows WITH a common direction: one coordinate is 1 on every reference (left out of the image, its
     contribution in the rows' thresholds) and the other coordinates are centred; rows that break the constant coordinate
