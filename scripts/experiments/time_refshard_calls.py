@@ -22,3 +22,18 @@ t(lambda: idx.range_scores(q[:32], -1e10, 400000, device_out=True), "range_score
 t(lambda: idx.range_scores(q[32:96], 0.14785, 400000, device_out=True), "range_scores batch 32-96 at 0.14785")
 t(lambda: idx.range_scores(q[32:96], 0.14785, 400000, device_out=True), "again")
 t(lambda: idx.global_topk(q[32:96], 400000, device_out=True, seed_radius=0.14785), "seeded topk 400000")
+print("--- emulate_schedule_radius on this shard alone (what a tie on the K cut costs a reference-sharded top-K), one process")
+from vsc2022_amd import dist as vdist
+marks = []
+def rs(r0, r1, rad):
+    torch.cuda.synchronize(); a = time.perf_counter()
+    s = idx.range_scores(q[r0:r1], rad, 400000, device_out=True)
+    torch.cuda.synchronize(); marks.append((r0, r1, rad, int(s.numel()), time.perf_counter() - a, time.perf_counter()))
+    return s
+torch.cuda.synchronize(); t0 = time.perf_counter()
+rad = vdist.emulate_schedule_radius(rs, 4096, 200000, None, dev)
+torch.cuda.synchronize(); print("emulate_schedule_radius", round(time.perf_counter() - t0, 3), "s, radius", rad)
+prev = t0
+for r0, r1, rr, n, dt, t_end in marks:
+    print(f"  batch {r0}-{r1} radius {rr:.5f}: {n} scores, search {dt:.3f} s, since previous batch ended {t_end - dt - prev:.3f} s")
+    prev = t_end

@@ -162,7 +162,11 @@ def _full_worker(rank, world, port, out_dir):
 
         t_mark = [_time.perf_counter()]
 
-        def mark(what):   # VSC_TEST_TIMING=1: where the seconds of this test go (4 processes share one GPU)
+        # (VSC_TEST_TIMING=1: where the seconds of this test go.  On some boxes of the pool 35-55 s of it sit between the first and
+        # the second batch of the tie resolution (`emulate_schedule_radius`: every rank has just run an order statistic over its
+        # 1.28e8 scores of the first batch) -- four processes time-slicing ONE GPU; the same walk takes 0.3 s in one process
+        # (scripts/experiments/time_refshard_calls.py) and one process per GPU is the deployment)
+        def mark(what):
             if os.environ.get("VSC_TEST_TIMING") == "1":
                 torch.cuda.synchronize()
                 now = _time.perf_counter()
