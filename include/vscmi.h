@@ -82,8 +82,8 @@ int vsc_device_count(void);
  *   VSC_I8_MAX_REL=f          sqrt(dim) x mean(E_r / N'_r) of the references above which the index never starts
  *                             on int8 (default 0.35: the 8-bit bound would pass too much of the matrix)
  *   VSC_I8_EXCLUDE=0          keep coordinates on which all references agree inside the int8 images
- *   VSC_I8_CENTER=0|1|2       the int8 reference image holds y - mu, mu = the mean of the rows present when the image is first
- *                             written; the rows' x . mu moves their thresholds (exact: x.y = x.(y - mu) + x.mu).  1 (default):
+ *   VSC_I8_CENTER=0|1|2       the int8 reference image holds y - mu, mu = the mean of the rows present at the first search over
+ *                             >= 1024 rows (fixed from then on); the rows' x . mu moves their thresholds (exact: x.y = x.(y - mu) + x.mu).  1 (default):
  *                             when the mean carries >= 2 % of the rows' energy (uncentred embeddings; isotropic rows are left
  *                             alone), 0 never, 2 always (tests).  Read-only options "i8_center_on", "i8_center_share"
  *   VSC_I8_SORT=0             int8 launches see their rows in batch order (default: sorted by threshold / scale)

@@ -522,13 +522,14 @@ static int i8_after_add(vsc_index* idx, int64_t first_new, int64_t n, int64_t ne
     }
     bool same = ex.n == idx->i8_ex.n;
     for (int c = 0; same && c < ex.n; ++c) same = ex.idx[c] == idx->i8_ex.idx[c] && ex.val[c] == idx->i8_ex.val[c];
-    if (!same && first_new > 0) {
-        idx->i8_ex = ex;
-        idx->i8_dirty = true;  // the rows quantised so far left other coordinates out
-        return VSC_OK;
-    }
     idx->i8_ex = ex;
-    if (!idx->i8_mu_decided) VSC_TRY(i8_decide_centre(idx, first_new + n));
+    if (!same && first_new > 0) idx->i8_dirty = true;  // the rows quantised so far left other coordinates out
+    // the centre of the image: decided once, as soon as there are enough rows for their mean to mean something (a search
+    // after the first few rows must not fix it on one video's descriptors); rows quantised before that are rewritten
+    if (!idx->i8_mu_decided && (idx->i8_center != 1 || first_new + n >= 1024)) {
+        VSC_TRY(i8_decide_centre(idx, first_new + n));
+        if (idx->i8_mu_on && first_new > 0) idx->i8_dirty = true;
+    }
     if (idx->i8_dirty) return VSC_OK;  // everything is rewritten before the next search anyway
     return i8_quantise(idx, first_new, need_rows - first_new, first_new + n);
 }

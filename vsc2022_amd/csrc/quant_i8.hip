@@ -30,7 +30,7 @@
 // embeddings) spend their 8 bits on that direction: the scale follows mu, the bound grows, and at cosine 0.5 the
 // score-normalised search left int8 for fp16 (profiles/r06_distributions.md).  For ANY fixed vector mu
 //     x . y = x . (y - mu) + x . mu ,
-// so the reference image may hold y - mu (mu = the mean of the rows present when the image is first written; kept
+// so the reference image may hold y - mu (mu = the mean of the rows present at the first search over >= 1024 rows; kept
 // from then on) and the second term, a per-query-row constant like b above, moves the row's threshold
 // (row_center + row_bias_thresholds).  The image then represents y' = fl(y - mu): E is the residual of y', N' = ||y'||,
 // and the rounding of the subtraction itself, |y - mu - y'| <= 2^-24 |y - mu| per coordinate, is added to E.  The
