@@ -297,7 +297,7 @@ def shifted(rng, n, d, mean_cos, dominant=0, geometry_seed=3):
 def test_centred_int8_image_is_invisible_in_the_results(gpu, orc, nq, nr, d, K, k, cos, centre):
     """quant_i8.hip "CENTRED references": the int8 image holds y - mu, the rows' x . mu moves their thresholds.  Forced
     onto every pre-filtered batch (centre = 2: always; 1: decided from the mean's share of the energy), rows added in two
-    pieces (the centre is fixed at the first catch-up), top-K / k-NN / range search against the oracle bit for bit."""
+    pieces (the centre is fixed at the first catch-up that sees >= 1024 rows), top-K / k-NN / range search against the oracle bit for bit."""
     from vsc2022_amd.vsc.index import FlatIndex
 
     rng = np.random.default_rng(nq + d)
@@ -307,12 +307,13 @@ def test_centred_int8_image_is_invisible_in_the_results(gpu, orc, nq, nr, d, K, 
     idx = FlatIndex(d, options=opts(VSC_PREFILTER="2", VSC_I8="2", VSC_I8_CENTER=str(centre)))
     idx.profile(True)
     idx.add(r[: nr // 3])
-    top = idx.global_topk(q, K)          # (first search: the centre is decided on a third of the rows)
+    top = idx.global_topk(q, K)          # (first search, on a third of the rows)
     assert_same(top[:3], orc.global_threshold_search(q, r[: nr // 3], K))
     idx.add(r[nr // 3 :])
-    assert idx.get_option("i8_center_on") == (1.0 if (centre == 2 or cos >= 0.05) else 0.0)
     top = idx.global_topk(q, K)
     assert_same(top[:3], orc.global_threshold_search(q, r, K))
+    # (centre = 1: decided at the first catch-up over >= 1024 rows -- here the second one; the rows written before are rewritten)
+    assert idx.get_option("i8_center_on") == (1.0 if (centre == 2 or cos >= 0.05) else 0.0)
     D, I = idx.search(q, k)
     Do, Io = orc.knn(q, r, k)
     assert np.array_equal(I, Io) and np.array_equal(bits(D), bits(Do))
